@@ -1,0 +1,160 @@
+/*
+ * vq3_hip.h - C ABI of libvq3hip.so: the MI355X (gfx950) kernels behind the VGGT -> Perceiver -> Qwen3
+ * forward/backward path of Sycamorers/vggt-qwen3.
+ *
+ * The reference has no FFI of its own: its hot path is stock PyTorch modules called from
+ * src/models/vggt_qwen3_vlm.py:179-201 (VGGTQwen3VLM.forward). Each entry point below names the reference
+ * (or third-party) Python op it replaces, so a maintainer can bind it from the reference side with ctypes
+ * (see INTEGRATION.md). Conventions:
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; sizes are element counts;
+ *   - bf16 tensors are raw uint16 (round-to-nearest-even), "f32" tensors are IEEE float;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work, they never
+ *     synchronise, allocate or free, so they are hipGraph-capturable;
+ *   - return value 0 = enqueued, non-zero = argument/launch error, message via vq3_last_error().
+ */
+#ifndef VQ3_HIP_H
+#define VQ3_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQ3_ABI_VERSION 1
+
+int vq3_abi_version(void);
+const char* vq3_last_error(void);
+/* Name of the code object's target ("gfx950"). */
+const char* vq3_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GEMM  C = epilogue(alpha * A[M,K] . B[N,K]^T)     (bf16 in, f32 MFMA accumulate)
+ * Replaces torch.nn.functional.linear on every projection of the path:
+ *   Qwen3 q/k/v/o_proj, gate/up/down_proj, lm_head  (transformers/models/qwen3/modeling_qwen3.py:81-83,241-280,495)
+ *   Perceiver in_proj/out_proj/MHA projections/FFN   (src/models/projector_perceiver.py:31-42,59-67)
+ *   VGGT aggregator qkv/proj/fc1/fc2/patch-embed      (vggt.models.aggregator, un-vendored)
+ * and, with operands swapped or transposed copies, all dgrad / wgrad / attention products.
+ * Epilogue order: v = alpha*acc; v += bias[n]; (round to bf16 if C is bf16); v = act(v); v *= colscale[n];
+ *                 v += R[m,n]; v += C[m,n] if accumulate; store.
+ * Batches: blockIdx.z = b1*nb2 + b2; A += b1*sA1 + b2*sA2; B += b1*sB1 + (b2/b2divB)*sB2; C,R alike (no div).
+ * Requirements: K % 64 == 0, lda/ldb % 8 == 0, A/B 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct vq3_gemm_desc {
+  const void* A;        /* bf16 [M, lda] */
+  const void* B;        /* bf16 [N, ldb] */
+  void* C;              /* bf16 or f32 [M, ldc] */
+  const void* bias;     /* f32 [N] or NULL */
+  const void* colscale; /* f32 [N] or NULL */
+  const void* R;        /* residual, dtype of C, [M, ldr] or NULL */
+  int32_t M, N, K, lda, ldb, ldc, ldr;
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+  int32_t nb1, nb2, b2divB;
+  int32_t act;        /* 0 none, 1 GELU(erf), 2 SiLU */
+  int32_t out_f32;    /* 0: C/R bf16, 1: C/R f32 */
+  int32_t accumulate; /* C += */
+  float alpha;
+} vq3_gemm_desc;
+
+int vq3_gemm_bf16_nt(const vq3_gemm_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Normalisation
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Qwen3RMSNorm.forward (modeling_qwen3.py:59-64): y = w * bf16(x * rsqrt(mean(x^2) + eps)).
+ * x,y bf16 [rows, cols] (row stride = ldx / ldy elements), w bf16 [cols]; rstd f32 [rows] (optional, for bwd). */
+int vq3_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int32_t cols, int64_t ldx,
+                    int64_t ldy, float eps, void* stream);
+/* Backward of the above: dx = [dres +] rstd * (g - xhat * mean(g * xhat)), g = dy*w, xhat = x*rstd;
+ * dw_f32[cols] += sum_rows dy * xhat (f32 atomics; caller zeroes dw_f32). dres may be NULL; dx may alias dres. */
+int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                    float* dw_f32, int64_t rows, int32_t cols, float eps, void* stream);
+
+/* torch.nn.LayerNorm (projector_perceiver.py:39-40; VGGT Block.norm1/norm2, q_norm/k_norm).
+ * x: bf16 (x_f32=0) or f32 (x_f32=1) [rows, cols]; w,b f32 [cols]; y_bf16 and/or y_f32 may be NULL.
+ * Optional residual: the kernel normalises (x + res) where res has the dtype of x (Perceiver post-norm). */
+int vq3_layernorm_fwd(const void* x, const void* res, int32_t x_f32, const float* w, const float* b, void* y_bf16,
+                      float* y_f32, int64_t rows, int32_t cols, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Element-wise / data movement
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Qwen3MLP (modeling_qwen3.py:81-83): act[m, i] = silu(gu[m, i]) * gu[m, I + i]; gu bf16 [rows, 2I]. */
+int vq3_silu_mul_fwd(const void* gu, void* act, int64_t rows, int32_t inter, void* stream);
+/* dgu[m, i] = dact * up * silu'(gate); dgu[m, I+i] = dact * silu(gate). */
+int vq3_silu_mul_bwd(const void* dact, const void* gu, void* dgu, int64_t rows, int32_t inter, void* stream);
+
+/* Batched 2-D transpose of bf16 tiles with zero padding:
+ * for batch (i0,i1,i2): dst[c * ldd + r] = src[r * lds + c], r < R, c < C; dst columns R..Rpad-1 are zeroed.
+ * src += i0*s0 + i1*s1 + i2*s2; dst += i0*d0 + i1*d1 + i2*d2. */
+int vq3_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int32_t Rpad, int64_t lds, int64_t ldd,
+                       int32_t n0, int32_t n1, int32_t n2, int64_t s0, int64_t s1, int64_t s2, int64_t d0, int64_t d1,
+                       int64_t d2, void* stream);
+
+/* y = cast(x): f32 -> bf16 (dir 0) or bf16 -> f32 (dir 1), n elements. */
+int vq3_cast(const void* x, void* y, int64_t n, int32_t dir, void* stream);
+/* acc_bf16[i] (+)= src_f32[i]  (accumulate != 0 adds to the existing bf16 value in f32, rounds once). */
+int vq3_f32_to_bf16_acc(const float* src, void* acc_bf16, int64_t n, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Qwen3 attention (modeling_qwen3.py:104-170 RoPE, :237-253 q/k-norm, :185-207 eager attention)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* qkv bf16 [B*L, (Hq+2*Hkv)*D] (fused q|k|v projection output) ->
+ *   Q [B,Hq,L,D], K [B,Hkv,L,D], V [B,Hkv,L,D]  (bf16), with per-head RMSNorm(q_w / k_w, eps) and rotate-half RoPE
+ *   using cos/sin bf16 [L, D]. q_rstd f32 [B*L*Hq], k_rstd f32 [B*L*Hkv] (optional, saved for backward). */
+int vq3_qwen_qkprep_fwd(const void* qkv, const void* q_w, const void* k_w, const void* cos, const void* sin, void* Q,
+                        void* K, void* V, float* q_rstd, float* k_rstd, int32_t B, int32_t L, int32_t Hq, int32_t Hkv,
+                        int32_t D, float eps, void* stream);
+/* Backward: dQ,dK,dV (layouts as above) + saved qkv, rstd -> dqkv bf16 [B*L,(Hq+2Hkv)*D];
+ * dq_w_f32[D], dk_w_f32[D] += (f32 atomics, caller zeroes). */
+int vq3_qwen_qkprep_bwd(const void* dQ, const void* dK, const void* dV, const void* qkv, const void* q_w,
+                        const void* k_w, const void* cos, const void* sin, const float* q_rstd, const float* k_rstd,
+                        void* dqkv, float* dq_w_f32, float* dk_w_f32, int32_t B, int32_t L, int32_t Hq, int32_t Hkv,
+                        int32_t D, void* stream);
+
+/* Masked softmax over the last dim. S f32 [nb, Lq, ldS] -> P bf16 [nb, Lq, ldP]; columns >= Lk (up to ldP) zeroed.
+ * causal != 0: key j visible to query i iff j <= i. keymask u8 [nb / heads_per_mask, Lk] or NULL (1 = visible).
+ * Fully masked rows produce zeros. */
+int vq3_softmax_fwd(const float* S, void* P, const uint8_t* keymask, int32_t nb, int32_t heads_per_mask, int32_t Lq,
+                    int32_t Lk, int32_t ldS, int32_t ldP, int32_t causal, void* stream);
+/* dS = scale * P * (dP - rowsum(P*dP)); P bf16, dP f32 [nb,Lq,ldS], dS bf16 [nb,Lq,ldP] (pad columns zeroed). */
+int vq3_softmax_bwd(const void* P, const float* dP, void* dS, int32_t nb, int32_t Lq, int32_t Lk, int32_t ldS,
+                    int32_t ldP, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Embedding / splice / loss (vggt_qwen3_vlm.py:190-195; modeling_qwen3.py:495; loss_utils.py:32-71)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* inputs_embeds build: out[b,l,:] = srcmap[b,l] < 0 ? table[ids[b,l],:] : feat[b, srcmap[b,l], :].
+ * srcmap i32 [B,L] is the host-computed image of the reference's python loop
+ * `inputs_embeds[b, pos:pos+S] = features[b]` (last writer wins for repeated <image> tokens); the host has
+ * already raised for pos+S > L exactly as the reference's index assignment does. feat bf16 [B,S,H]. */
+int vq3_embed_splice_fwd(const int64_t* ids, const void* table, const void* feat, const int32_t* srcmap, void* out,
+                         int32_t B, int32_t L, int32_t H, int32_t S, void* stream);
+/* Backward of the above. sorted_ids/order = sort of ids over all B*L positions (stable): the embedding-table
+ * gradient (bf16 [V,H], tied with lm_head) gets += sum of dout rows per distinct id, skipping spliced positions
+ * (deterministic, no atomics). dfeat_f32 [B,S,H] += dout rows of spliced positions (f32 atomics; may be NULL). */
+int vq3_embed_splice_bwd(const int64_t* sorted_ids, const int64_t* order, const int32_t* srcmap, const void* dout,
+                         void* dtable_bf16, float* dfeat_f32, int32_t B, int32_t L, int32_t H, int32_t S, void* stream);
+/* out[i,:] = src[idx[i],:] for i < n (rows i >= n up to n_pad zero-filled). bf16 rows of `cols`. */
+int vq3_gather_rows(const void* src, const int32_t* idx, void* out, int32_t n, int32_t n_pad, int32_t cols,
+                    void* stream);
+/* dst[idx[i],:] (+)= src[i,:] for i < n (idx unique). */
+int vq3_scatter_rows(const void* src, const int32_t* idx, void* dst, int32_t n, int32_t cols, int32_t accumulate,
+                     void* stream);
+/* Cross entropy over bf16 logits [n, ldl] with V valid columns, targets i32 [n] (all valid):
+ * loss_sum_f32[0] += sum_i (logsumexp_i - logit_i[target_i]); dlogits (in place, bf16) = (softmax - onehot) * gscale,
+ * columns V..ldl-1 zeroed. Caller zeroes loss_sum and divides by n. */
+int vq3_cross_entropy_fwd_bwd(void* logits, const int32_t* targets, float* loss_sum_f32, int32_t n, int32_t V,
+                              int32_t ldl, float gscale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimiser (src/train/train_sft.py:147-156 torch.optim.AdamW; DeepSpeed bf16 keeps f32 master weights)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* master/m/v f32, grad bf16, w_bf16 (compute copy) updated in place. step >= 1. grad is scaled by gscale first. */
+int vq3_adamw_step(float* master, float* m, float* v, const void* grad_bf16, void* w_bf16, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int32_t step, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQ3_HIP_H */

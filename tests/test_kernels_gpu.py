@@ -1,0 +1,322 @@
+"""Per-kernel numerics on the MI355X: every C-ABI entry point against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vggt_qwen3_amd import ops as _ops
+    from vggt_qwen3_amd import _lib
+    _lib.load()
+    return _ops
+
+
+def _rand(shape, scale=1.0, dtype=BF16, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=F32) * scale).to(dtype).cuda()
+
+
+def _relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def _maxerr(a, b):
+    return (a.float() - b.float()).abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def test_gemm_identity_asymmetric(ops):
+    """A = I with an asymmetric B catches swapped row/col maps and permuted k order."""
+    K = 128
+    A = torch.eye(K, dtype=F32).to(BF16).cuda()
+    Bm = (torch.arange(200 * K, dtype=F32).reshape(200, K) % 251 - 125).to(BF16).cuda()  # exact small ints
+    out = ops.linear(A, Bm, out_dtype=F32)  # [K, 200] = I @ B^T
+    assert torch.equal(out, Bm.float().t().contiguous()), f"max err {_maxerr(out, Bm.float().t())}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1200, 2560, 4096), (1200, 6144, 2560), (77, 200, 192),
+                                   (24, 1000, 2560), (6174, 1024, 1024), (300, 151937 // 16, 256)])
+def test_gemm_shapes(ops, M, N, K):
+    A = _rand((M, K), 1.0, seed=1)
+    W = _rand((N, K), 1.0, seed=2)
+    ref = A.float() @ W.float().t()
+    out32 = ops.linear(A, W, out_dtype=F32)
+    assert _relerr(out32, ref) < 2e-6 * math.sqrt(K) + 1e-6, f"f32-out rel err {_relerr(out32, ref)}"
+    out16 = ops.linear(A, W)
+    assert _relerr(out16, ref) < 4e-3, f"bf16-out rel err {_relerr(out16, ref)}"
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 300, 520, 128
+    A = _rand((M, K), 0.5, seed=3); W = _rand((N, K), 0.5, seed=4)
+    bias = _rand((N,), 1.0, F32, seed=5); cs = _rand((N,), 1.0, F32, seed=6)
+    R16 = _rand((M, N), 1.0, seed=7); R32 = R16.float()
+    base = A.float() @ W.float().t()
+    # f32 out: bias + gelu + colscale + residual, alpha
+    out = ops.linear(A, W, bias=bias, colscale=cs, residual=R32, act=ops.ACT_GELU, out_dtype=F32, alpha=0.5)
+    ref = torch.nn.functional.gelu(base * 0.5 + bias) * cs + R32
+    assert _relerr(out, ref) < 1e-5, _relerr(out, ref)
+    # bf16 out with the PyTorch rounding points
+    out = ops.linear(A, W, bias=bias, residual=R16, act=ops.ACT_SILU)
+    t = (base + bias).to(BF16)
+    t = torch.nn.functional.silu(t.float()).to(BF16)
+    ref = (t.float() + R16.float()).to(BF16)
+    assert _maxerr(out, ref) <= 0.0625 and _relerr(out, ref) < 3e-3, (_maxerr(out, ref), _relerr(out, ref))
+    # accumulate
+    C = _rand((M, N), 1.0, seed=8)
+    C0 = C.clone()
+    ops.linear(A, W, out=C, accumulate=True)
+    assert _relerr(C, base + C0.float()) < 4e-3
+    C = _rand((M, N), 1.0, F32, seed=9); C0 = C.clone()
+    ops.linear(A, W, out=C, accumulate=True)
+    assert _relerr(C, base + C0) < 1e-5
+
+
+def test_gemm_batched_strided(ops):
+    """Attention-shaped use: batch (b, h) with K/V shared by groups of heads and a strided output."""
+    Bz, Hq, Hkv, L, D = 2, 8, 2, 200, 128
+    Q = _rand((Bz, Hq, L, D), 1.0, seed=10); Kt = _rand((Bz, Hkv, L, D), 1.0, seed=11)
+    S = torch.empty((Bz, Hq, L, 256), device="cuda", dtype=F32).fill_(float("nan"))
+    ops.gemm_raw(Q, Kt, S, L, L, D, D, D, 256, nb1=Bz, nb2=Hq, b2divB=Hq // Hkv, sA=(Hq * L * D, L * D),
+                 sB=(Hkv * L * D, L * D), sC=(Hq * L * 256, L * 256), alpha=D ** -0.5)
+    ref = torch.einsum("bhld,bhmd->bhlm", Q.float(), Kt.float().repeat_interleave(Hq // Hkv, 1)) * D ** -0.5
+    assert _relerr(S[..., :L], ref) < 1e-5
+    assert torch.isnan(S[..., L:]).all(), "columns beyond N must not be written"
+    # P @ V with V^T operand and output scattered into [B, L, Hq*D]
+    P = _rand((Bz, Hq, L, 256), 0.1, seed=12); P[..., L:] = 0
+    Vt = _rand((Bz, Hkv, D, 256), 1.0, seed=13)
+    O = torch.zeros((Bz, L, Hq * D), device="cuda", dtype=BF16)
+    ops.gemm_raw(P, Vt, O, L, D, 256, 256, 256, Hq * D, nb1=Bz, nb2=Hq, b2divB=Hq // Hkv, sA=(Hq * L * 256, L * 256),
+                 sB=(Hkv * D * 256, D * 256), sC=(L * Hq * D, D))
+    ref = torch.einsum("bhlm,bhdm->blhd", P.float(), Vt.float().repeat_interleave(Hq // Hkv, 1)).reshape(Bz, L, Hq * D)
+    assert _relerr(O, ref) < 4e-3
+
+
+def test_gemm_rejects_bad_args(ops):
+    from vggt_qwen3_amd._lib import Vq3Error
+    A = _rand((16, 100), seed=1); W = _rand((16, 100), seed=2)
+    with pytest.raises(Vq3Error):
+        ops.linear(A, W)  # K % 64 != 0
+
+
+# ------------------------------------------------------------------------------------------ norms
+def test_rmsnorm_fwd_bwd(ops):
+    rows, cols, eps = 1200, 2560, 1e-6
+    x = _rand((rows, cols), 2.0, seed=20); w = _rand((cols,), 1.0, seed=21)
+    y, rstd = ops.rmsnorm_fwd(x, w, eps, want_rstd=True)
+    xf = x.float()
+    rs = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    ref = (w.float() * (xf * rs).to(BF16).float()).to(BF16)
+    assert _relerr(y, ref) < 2e-3 and _maxerr(rstd, rs.squeeze(-1)) < 1e-5
+    # backward vs autograd (fp32, no intermediate rounding)
+    dy = _rand((rows, cols), 1.0, seed=22); dres = _rand((rows, cols), 1.0, seed=23)
+    xa = xf.clone().requires_grad_(True); wa = w.float().clone().requires_grad_(True)
+    ya = wa * (xa * torch.rsqrt(xa.pow(2).mean(-1, keepdim=True) + eps))
+    ya.backward(dy.float())
+    dw = torch.zeros(cols, device="cuda", dtype=F32)
+    dx = ops.rmsnorm_bwd(dy, x, w, rstd, dres, dw)
+    assert _relerr(dx, xa.grad + dres.float()) < 4e-3
+    assert _relerr(dw, wa.grad) < 1e-4
+
+
+@pytest.mark.parametrize("xdt", [BF16, F32])
+def test_layernorm_fwd(ops, xdt):
+    rows, cols, eps = 770, 4096, 1e-5
+    x = _rand((rows, cols), 2.0, xdt, seed=30); res = _rand((rows, cols), 1.0, xdt, seed=31)
+    w = _rand((cols,), 1.0, F32, seed=32); b = _rand((cols,), 1.0, F32, seed=33)
+    yb, yf = ops.layernorm_fwd(x, w, b, eps, res=res, want_bf16=True, want_f32=True)
+    s = x.float() + res.float()
+    if xdt == BF16:
+        s = s.to(BF16).float()
+    ref = torch.nn.functional.layer_norm(s, (cols,), w, b, eps)
+    assert _relerr(yf, ref) < 1e-5 and _relerr(yb, ref) < 3e-3
+    yb2, _ = ops.layernorm_fwd(x, w, b, eps)
+    assert _relerr(yb2, torch.nn.functional.layer_norm(x.float(), (cols,), w, b, eps)) < 3e-3
+
+
+# ------------------------------------------------------------------------------------------ element-wise
+def test_silu_mul_fwd_bwd(ops):
+    rows, inter = 300, 9728
+    gu = _rand((rows, 2 * inter), 1.5, seed=40)
+    act = ops.silu_mul_fwd(gu)
+    g, u = gu[:, :inter].float(), gu[:, inter:].float()
+    ref = torch.nn.functional.silu(g).to(BF16).float() * u
+    assert _relerr(act, ref) < 3e-3
+    dact = _rand((rows, inter), 1.0, seed=41)
+    ga = g.clone().requires_grad_(True); ua = u.clone().requires_grad_(True)
+    (torch.nn.functional.silu(ga) * ua).backward(dact.float())
+    dgu = ops.silu_mul_bwd(dact, gu)
+    assert _relerr(dgu[:, :inter], ga.grad) < 3e-3 and _relerr(dgu[:, inter:], ua.grad) < 3e-3
+
+
+def test_transpose(ops):
+    x = _rand((200, 128), seed=50)
+    t = ops.transpose2d(x, pad_to=64)
+    assert t.shape == (128, 256)
+    assert torch.equal(t[:, :200], x.t()) and (t[:, 200:] == 0).all()
+    # batched with strides: [2,3,70,40] -> [2,3,40,(70 -> 128)]
+    x = _rand((2, 3, 70, 40), seed=51)
+    out = torch.full((2, 3, 40, 128), 7.0, device="cuda", dtype=BF16)
+    ops.transpose_raw(x, out, 70, 40, 128, 40, 128, n=(1, 2, 3), s=(0, 3 * 70 * 40, 70 * 40), d=(0, 3 * 40 * 128, 40 * 128))
+    assert torch.equal(out[..., :70], x.transpose(-1, -2)) and (out[..., 70:] == 0).all()
+
+
+def test_cast_and_acc(ops):
+    x = _rand((1000003,), 3.0, F32, seed=60)
+    assert torch.equal(ops.cast(x, BF16), x.to(BF16))
+    xb = x.to(BF16)
+    assert torch.equal(ops.cast(xb, F32), xb.float())
+    acc = _rand((1000003,), 1.0, BF16, seed=61); acc0 = acc.clone()
+    ops.f32_to_bf16_acc(x, acc, True)
+    assert torch.equal(acc, (x + acc0.float()).to(BF16))
+
+
+def test_gather_scatter(ops):
+    src = _rand((1200, 2560), seed=70)
+    idx = torch.tensor([5, 1199, 0, 77, 640], dtype=torch.int32, device="cuda")
+    out = ops.gather_rows(src, idx, 5, 16)
+    assert torch.equal(out[:5], src[idx.long()]) and (out[5:] == 0).all()
+    dst = torch.zeros_like(src)
+    ops.scatter_rows(out, idx, dst, 5, False)
+    assert torch.equal(dst[idx.long()], src[idx.long()])
+    ops.scatter_rows(out, idx, dst, 5, True)
+    assert torch.equal(dst[idx.long()], (2 * src[idx.long()].float()).to(BF16))
+
+
+# ------------------------------------------------------------------------------------------ qwen attention pieces
+def _rope_tables(L, D, theta=5e6):
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=F32) / D))
+    fr = torch.arange(L, dtype=F32)[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], -1)
+    return emb.cos().to(BF16).cuda(), emb.sin().to(BF16).cuda()
+
+
+def _rot_half(x):
+    return torch.cat([-x[..., 64:], x[..., :64]], -1)
+
+
+def _qkprep_ref(qkv, qw, kw, cos, sin, B, L, Hq, Hkv, D, eps, exact_rounding):
+    x = qkv.float().reshape(B, L, Hq + 2 * Hkv, D)
+    q, k, v = x[:, :, :Hq], x[:, :, Hq:Hq + Hkv], x[:, :, Hq + Hkv:]
+
+    def norm(t, w):
+        n = t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + eps)
+        if exact_rounding:
+            n = n.to(BF16).float()
+        o = w.float() * n
+        return o.to(BF16).float() if exact_rounding else o
+
+    def rope(t):
+        c, s = cos.float()[None, :, None, :], sin.float()[None, :, None, :]
+        if exact_rounding:
+            return ((t * c).to(BF16).float() + (_rot_half(t) * s).to(BF16).float()).to(BF16).float()
+        return t * c + _rot_half(t) * s
+
+    return rope(norm(q, qw)).transpose(1, 2), rope(norm(k, kw)).transpose(1, 2), v.transpose(1, 2)
+
+
+def test_qkprep_fwd_bwd(ops):
+    B, L, Hq, Hkv, D, eps = 2, 200, 8, 2, 128, 1e-6
+    qkv = _rand((B * L, (Hq + 2 * Hkv) * D), 1.0, seed=80)
+    qw = (_rand((D,), 0.2, seed=81).float() + 1).to(BF16); kw = (_rand((D,), 0.2, seed=82).float() + 1).to(BF16)
+    cos, sin = _rope_tables(L, D)
+    Q, K, V, qr, kr = ops.qwen_qkprep_fwd(qkv, qw, kw, cos, sin, B, L, Hq, Hkv, D, eps)
+    rq, rk, rv = _qkprep_ref(qkv, qw, kw, cos, sin, B, L, Hq, Hkv, D, eps, True)
+    assert _relerr(Q, rq) < 2e-3 and _relerr(K, rk) < 2e-3 and torch.equal(V.float(), rv)
+    # backward vs autograd of the un-rounded function
+    xa = qkv.float().clone().requires_grad_(True); qwa = qw.float().clone().requires_grad_(True)
+    kwa = kw.float().clone().requires_grad_(True)
+    aq, ak, av = _qkprep_ref(xa, qwa, kwa, cos, sin, B, L, Hq, Hkv, D, eps, False)
+    dQ = _rand((B, Hq, L, D), 1.0, seed=83); dK = _rand((B, Hkv, L, D), 1.0, seed=84); dV = _rand((B, Hkv, L, D), 1.0, seed=85)
+    ((aq * dQ.float()).sum() + (ak * dK.float()).sum() + (av * dV.float()).sum()).backward()
+    dqw = torch.zeros(D, device="cuda", dtype=F32); dkw = torch.zeros(D, device="cuda", dtype=F32)
+    dqkv = ops.qwen_qkprep_bwd(dQ, dK, dV, qkv, qw, kw, cos, sin, qr, kr, dqw, dkw, B, L, Hq, Hkv, D)
+    assert _relerr(dqkv, xa.grad) < 4e-3, _relerr(dqkv, xa.grad)
+    assert _relerr(dqw, qwa.grad) < 1e-3 and _relerr(dkw, kwa.grad) < 1e-3
+
+
+def test_softmax_fwd_bwd(ops):
+    nb, Lq, Lk, ld = 12, 200, 200, 256
+    S = _rand((nb, Lq, ld), 3.0, F32, seed=90)
+    km = (torch.rand(3, Lk) > 0.2).to(torch.uint8); km[:, 0] = 1; km = km.cuda()
+    P = ops.softmax_fwd(S, km, 4, Lk, ld, True)
+    mask = torch.tril(torch.ones(Lq, Lk, device="cuda", dtype=torch.bool))[None] & km.bool().repeat_interleave(4, 0)[:, None, :]
+    ref = torch.softmax(S[..., :Lk].masked_fill(~mask, float("-inf")), -1)
+    assert _maxerr(P[..., :Lk], ref) < 4e-3 and (P[..., Lk:] == 0).all()
+    dP = _rand((nb, Lq, ld), 1.0, F32, seed=91)
+    dS = ops.softmax_bwd(P, dP, Lk, 0.25)
+    Pf = P.float()[..., :Lk]
+    refd = 0.25 * Pf * (dP[..., :Lk] - (Pf * dP[..., :Lk]).sum(-1, keepdim=True))
+    assert _relerr(dS[..., :Lk], refd) < 4e-3 and (dS[..., Lk:] == 0).all()
+    # non-causal, no mask
+    P2 = ops.softmax_fwd(S, None, 1, Lk, ld, False)
+    assert _maxerr(P2[..., :Lk], torch.softmax(S[..., :Lk], -1)) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------ embedding / loss / optimiser
+def test_embed_splice_fwd_bwd(ops):
+    B, L, H, S, V = 3, 200, 2560, 136, 1000
+    g = torch.Generator().manual_seed(100)
+    ids = torch.randint(0, V, (B, L), generator=g).cuda()
+    table = _rand((V, H), seed=101); feat = _rand((B, S, H), seed=102)
+    srcmap = torch.full((B, L), -1, dtype=torch.int32)
+    for b, pos in enumerate([10, 20, 64]):
+        srcmap[b, pos:pos + S] = torch.arange(S, dtype=torch.int32)
+    srcmap[2] = -1  # row without <image>
+    srcmap = srcmap.cuda()
+    out = ops.embed_splice_fwd(ids, table, feat, srcmap, B, L, H, S)
+    ref = table[ids]
+    for b in range(B):
+        sel = srcmap[b] >= 0
+        ref[b, sel] = feat[b, srcmap[b, sel].long()]
+    assert torch.equal(out, ref)
+    dout = _rand((B, L, H), seed=103)
+    sorted_ids, order = torch.sort(ids.reshape(-1), stable=True)
+    dtable = _rand((V, H), 0.1, seed=104); dtable0 = dtable.clone()
+    dfeat = torch.zeros((B, S, H), device="cuda", dtype=F32)
+    ops.embed_splice_bwd(sorted_ids, order, srcmap, dout, dtable, dfeat, B, L, H, S)
+    reft = torch.zeros((V, H), device="cuda", dtype=F32)
+    keep = (srcmap < 0).reshape(-1)
+    reft.index_add_(0, ids.reshape(-1)[keep], dout.reshape(-1, H).float()[keep])
+    assert _relerr(dtable, dtable0.float() + reft) < 4e-3
+    reff = torch.zeros_like(dfeat)
+    for b in range(B):
+        sel = srcmap[b] >= 0
+        reff[b, srcmap[b, sel].long()] = dout[b, sel].float()
+    assert torch.equal(dfeat, reff)
+
+
+def test_cross_entropy(ops):
+    n, V = 24, 151937
+    ld = (V + 7) // 8 * 8
+    logits = torch.zeros((n, ld), device="cuda", dtype=BF16)
+    logits[:, :V] = _rand((n, V), 2.0, seed=110)
+    tgt = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(111)).to(torch.int32).cuda()
+    la = logits[:, :V].float().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(la, tgt.long(), reduction="sum")
+    ref.backward()
+    loss = torch.zeros(1, device="cuda", dtype=F32)
+    ops.cross_entropy_fwd_bwd(logits, tgt, loss, n, V, 1.0 / n)
+    assert abs(loss.item() - ref.item()) / ref.item() < 1e-5
+    assert _relerr(logits[:, :V], la.grad / n) < 4e-3 and (logits[:, V:] == 0).all()
+
+
+def test_adamw(ops):
+    n = 1000003
+    p = _rand((n,), 1.0, F32, seed=120); g = _rand((n,), 0.1, BF16, seed=121)
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    m = torch.zeros_like(p); v = torch.zeros_like(p); w = torch.empty(n, device="cuda", dtype=BF16)
+    for step in (1, 2, 3):
+        ref_p.grad = g.float()
+        opt.step()
+        ops.adamw_step(p, m, v, g, w, 1e-3, 0.9, 0.999, 1e-8, 0.1, step)
+    assert _maxerr(p, ref_p.data) < 1e-5, _maxerr(p, ref_p.data)
+    assert torch.equal(w, p.to(BF16))

@@ -1,0 +1,90 @@
+"""ctypes binding of libvq3hip.so (C ABI declared in include/vq3_hip.h).
+
+The library is the product: there is no PyTorch/CPU fallback. If it is missing, ``load()`` raises.
+PyTorch is only used for device memory and streams; tensors cross the boundary as raw device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libvq3hip.so"
+
+c_p = C.c_void_p
+i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", c_p), ("B", c_p), ("C", c_p), ("bias", c_p), ("colscale", c_p), ("R", c_p),
+        ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32), ("ldr", i32),
+        ("sA1", i64), ("sA2", i64), ("sB1", i64), ("sB2", i64),
+        ("sC1", i64), ("sC2", i64), ("sR1", i64), ("sR2", i64),
+        ("nb1", i32), ("nb2", i32), ("b2divB", i32),
+        ("act", i32), ("out_f32", i32), ("accumulate", i32),
+        ("alpha", f32),
+    ]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES). Must match include/vq3_hip.h.
+SIGNATURES = {
+    "vq3_abi_version": [],
+    "vq3_last_error": [],
+    "vq3_target_arch": [],
+    "vq3_gemm_bf16_nt": [C.POINTER(GemmDesc), c_p],
+    "vq3_rmsnorm_fwd": [c_p, c_p, c_p, c_p, i64, i32, i64, i64, f32, c_p],
+    "vq3_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
+    "vq3_layernorm_fwd": [c_p, c_p, i32, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
+    "vq3_silu_mul_fwd": [c_p, c_p, i64, i32, c_p],
+    "vq3_silu_mul_bwd": [c_p, c_p, c_p, i64, i32, c_p],
+    "vq3_transpose_bf16": [c_p, c_p, i32, i32, i32, i64, i64, i32, i32, i32, i64, i64, i64, i64, i64, i64, c_p],
+    "vq3_cast": [c_p, c_p, i64, i32, c_p],
+    "vq3_f32_to_bf16_acc": [c_p, c_p, i64, i32, c_p],
+    "vq3_qwen_qkprep_fwd": [c_p] * 10 + [i32, i32, i32, i32, i32, f32, c_p],
+    "vq3_qwen_qkprep_bwd": [c_p] * 13 + [i32, i32, i32, i32, i32, c_p],
+    "vq3_softmax_fwd": [c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, i32, c_p],
+    "vq3_softmax_bwd": [c_p, c_p, c_p, i32, i32, i32, i32, i32, f32, c_p],
+    "vq3_embed_splice_fwd": [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p],
+    "vq3_embed_splice_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p],
+    "vq3_gather_rows": [c_p, c_p, c_p, i32, i32, i32, c_p],
+    "vq3_scatter_rows": [c_p, c_p, c_p, i32, i32, i32, c_p],
+    "vq3_cross_entropy_fwd_bwd": [c_p, c_p, c_p, i32, i32, i32, f32, c_p],
+    "vq3_adamw_step": [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p],
+}
+_RESTYPES = {"vq3_last_error": C.c_char_p, "vq3_target_arch": C.c_char_p}
+
+_lib = None
+
+
+class Vq3Error(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once). Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("VQ3_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise Vq3Error(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The HIP library is required; there is no CPU/PyTorch fallback."
+        )
+    lib = C.CDLL(str(path))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    if lib.vq3_abi_version() != 1:
+        raise Vq3Error(f"ABI version mismatch: library {lib.vq3_abi_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().vq3_last_error()
+        raise Vq3Error(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

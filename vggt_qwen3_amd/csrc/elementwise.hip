@@ -1,0 +1,453 @@
+// HBM-bound element-wise / data-movement kernels: SwiGLU gate, transposes, casts, row gather/scatter,
+// embedding + visual-span splice, masked softmax, cross entropy, fused AdamW. All 16-byte vectorised where the
+// layout allows; grid-stride over at most 2048 blocks for the flat ones (256 CUs x 8).
+#include "common.h"
+#include "vq3_hip.h"
+
+namespace {
+
+inline unsigned flat_grid(long n_items, int per_block) {
+  long b = (n_items + per_block - 1) / per_block;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ---------------------------------------------------------------- SwiGLU
+__global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act,
+                                                           long rows, int inter) {
+  const int cpr = inter / 8;  // 16B chunks per row
+  const long total = rows * cpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + r * 2L * inter + c);
+    const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + r * 2L * inter + inter + c);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // act_fn(gate) is a bf16 tensor, then * up -> bf16 (modeling_qwen3.py:82)
+      const float s = rbf(silu_f(bf2f((bf16_t)g[j])));
+      o[j] = (short)f2bf(s * bf2f((bf16_t)u[j]));
+    }
+    *reinterpret_cast<bf16x8*>(act + r * (long)inter + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restrict__ dact,
+                                                           const bf16_t* __restrict__ gu, bf16_t* __restrict__ dgu,
+                                                           long rows, int inter) {
+  const int cpr = inter / 8;
+  const long total = rows * cpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + r * 2L * inter + c);
+    const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + r * 2L * inter + inter + c);
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(dact + r * (long)inter + c);
+    bf16x8 og, ou;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gf = bf2f((bf16_t)g[j]), uf = bf2f((bf16_t)u[j]), df = bf2f((bf16_t)d[j]);
+      const float sg = 1.f / (1.f + __expf(-gf));
+      const float sl = gf * sg;
+      og[j] = (short)f2bf(df * uf * (sg * (1.f + gf * (1.f - sg))));
+      ou[j] = (short)f2bf(df * sl);
+    }
+    *reinterpret_cast<bf16x8*>(dgu + r * 2L * inter + c) = og;
+    *reinterpret_cast<bf16x8*>(dgu + r * 2L * inter + inter + c) = ou;
+  }
+}
+
+// ---------------------------------------------------------------- transpose (64x64 tiles through LDS)
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R,
+                                                        int C, int Rpad, long lds_, long ldd, int n1, int n2, long s0,
+                                                        long s1, long s2, long d0, long d1, long d2) {
+  __shared__ bf16_t tile[64][66];
+  const int bz = blockIdx.z;
+  const int i2 = bz % n2, i1 = (bz / n2) % n1, i0 = bz / (n2 * n1);
+  src += i0 * s0 + i1 * s1 + i2 * s2;
+  dst += i0 * d0 + i1 * d1 + i2 * d2;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    tile[rr][tx] = (r < R && c < C) ? src[(long)r * lds_ + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, r = r0 + tx;
+    if (c < C && r < Rpad) dst[(long)c * ldd + r] = tile[tx][cc];
+  }
+}
+
+// ---------------------------------------------------------------- casts
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    u32x2 o;
+    o[0] = pack2bf(v[0], v[1]);
+    o[1] = pack2bf(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(y + i * 4) = o;
+  }
+  if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) y[i] = f2bf(x[i]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n) {
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(x + i * 4);
+    *reinterpret_cast<f32x4*>(y + i * 4) =
+        f32x4{bf2f((bf16_t)v[0]), bf2f((bf16_t)v[1]), bf2f((bf16_t)v[2]), bf2f((bf16_t)v[3])};
+  }
+  if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) y[i] = bf2f(x[i]);
+}
+__global__ __launch_bounds__(256) void f32_to_bf16_acc_kernel(const float* __restrict__ src, bf16_t* __restrict__ acc,
+                                                              long n, int accumulate) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = src[i];
+    if (accumulate) v += bf2f(acc[i]);
+    acc[i] = f2bf(v);
+  }
+}
+
+// ---------------------------------------------------------------- row gather / scatter (bf16 rows)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          bf16_t* __restrict__ out, int n, int cols) {
+  const int i = blockIdx.x;
+  bf16_t* o = out + (long)i * cols;
+  if (i < n) {
+    const bf16_t* s = src + (long)idx[i] * cols;
+    for (int c = threadIdx.x * 8; c < cols; c += 2048) *reinterpret_cast<bf16x8*>(o + c) = *reinterpret_cast<const bf16x8*>(s + c);
+  } else {
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = threadIdx.x * 8; c < cols; c += 2048) *reinterpret_cast<bf16x8*>(o + c) = z;
+  }
+}
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ idx,
+                                                           bf16_t* __restrict__ dst, int cols, int accumulate) {
+  const int i = blockIdx.x;
+  const bf16_t* s = src + (long)i * cols;
+  bf16_t* d = dst + (long)idx[i] * cols;
+  for (int c = threadIdx.x * 8; c < cols; c += 2048) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(s + c);
+    if (accumulate) {
+      const bf16x8 o = *reinterpret_cast<const bf16x8*>(d + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)v[j]) + bf2f((bf16_t)o[j]));
+    }
+    *reinterpret_cast<bf16x8*>(d + c) = v;
+  }
+}
+
+// ---------------------------------------------------------------- embedding + splice
+// srcmap[b*L+l] < 0: row comes from table[ids]; otherwise from feat[b, srcmap, :] (vggt_qwen3_vlm.py:190-195).
+__global__ __launch_bounds__(256) void embed_splice_fwd_kernel(const int64_t* __restrict__ ids,
+                                                               const bf16_t* __restrict__ table,
+                                                               const bf16_t* __restrict__ feat,
+                                                               const int32_t* __restrict__ srcmap,
+                                                               bf16_t* __restrict__ out, int L, int H, int S) {
+  const long t = blockIdx.x;  // b*L + l
+  const int b = (int)(t / L);
+  const int sm = srcmap[t];
+  const bf16_t* s = sm < 0 ? table + ids[t] * (long)H : feat + ((long)b * S + sm) * H;
+  bf16_t* o = out + t * (long)H;
+  for (int c = threadIdx.x * 8; c < H; c += 2048) *reinterpret_cast<bf16x8*>(o + c) = *reinterpret_cast<const bf16x8*>(s + c);
+}
+
+// Backward into the (tied) embedding table gradient. `order` is the argsort of ids over all B*L positions and
+// sorted_ids the sorted values: the block whose position starts a run of equal ids sums the run and adds it to the
+// bf16 gradient row once (no atomics, deterministic). Positions that were overwritten by the splice are skipped.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ sorted_ids,
+                                                        const int64_t* __restrict__ order,
+                                                        const int32_t* __restrict__ srcmap,
+                                                        const bf16_t* __restrict__ dout, bf16_t* __restrict__ dtable,
+                                                        int T, int H) {
+  const int i = blockIdx.x;
+  const int64_t id = sorted_ids[i];
+  if (i > 0 && sorted_ids[i - 1] == id) return;
+  int end = i + 1;
+  while (end < T && sorted_ids[end] == id) ++end;
+  for (int c = threadIdx.x * 8; c < H; c += 2048) {
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool any = false;
+    for (int k = i; k < end; ++k) {
+      const long t = order[k];
+      if (srcmap[t] >= 0) continue;
+      any = true;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dout + t * (long)H + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += bf2f((bf16_t)v[j]);
+    }
+    if (!any) continue;
+    bf16_t* d = dtable + id * (long)H + c;
+    const bf16x8 o = *reinterpret_cast<const bf16x8*>(d);
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(a[j] + bf2f((bf16_t)o[j]));
+    *reinterpret_cast<bf16x8*>(d) = r;
+  }
+}
+// dfeat_f32[b, s, :] += dout[b, l, :] where srcmap[b,l] == s
+__global__ __launch_bounds__(256) void splice_bwd_kernel(const int32_t* __restrict__ srcmap,
+                                                         const bf16_t* __restrict__ dout, float* __restrict__ dfeat,
+                                                         int L, int H, int S) {
+  const long t = blockIdx.x;
+  const int sm = srcmap[t];
+  if (sm < 0) return;
+  const int b = (int)(t / L);
+  float* d = dfeat + ((long)b * S + sm) * H;
+  for (int c = threadIdx.x; c < H; c += 256) atomicAdd(&d[c], bf2f(dout[t * (long)H + c]));
+}
+
+// ---------------------------------------------------------------- masked softmax (one wave per row)
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, bf16_t* __restrict__ P,
+                                                          const uint8_t* __restrict__ keymask, int heads_per_mask,
+                                                          int Lq, int Lk, int ldS, int ldP, int causal, long nrows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int nbi = (int)(row / Lq), i = (int)(row - (long)nbi * Lq);
+  const float* s = S + row * (long)ldS;
+  bf16_t* p = P + row * (long)ldP;
+  const uint8_t* km = keymask ? keymask + (long)(nbi / heads_per_mask) * Lk : nullptr;
+  const int lim = causal ? (i + 1 < Lk ? i + 1 : Lk) : Lk;
+  float mx = -INFINITY;
+  for (int j = lane; j < lim; j += 64)
+    if (!km || km[j]) mx = fmaxf(mx, s[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < lim; j += 64)
+    if (!km || km[j]) sum += __expf(s[j] - mx);
+  sum = wave_sum(sum);
+  const float inv = (sum > 0.f) ? 1.f / sum : 0.f;
+  for (int j = lane; j < ldP; j += 64) {
+    float v = 0.f;
+    if (j < lim && (!km || km[j])) v = __expf(s[j] - mx) * inv;
+    p[j] = f2bf(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ P, const float* __restrict__ dP,
+                                                          bf16_t* __restrict__ dS, int Lk, int ldS, int ldP, float scale,
+                                                          long nrows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const bf16_t* p = P + row * (long)ldP;
+  const float* dp = dP + row * (long)ldS;
+  bf16_t* ds = dS + row * (long)ldP;
+  float t = 0.f;
+  for (int j = lane; j < Lk; j += 64) t += bf2f(p[j]) * dp[j];
+  t = wave_sum(t);
+  for (int j = lane; j < ldP; j += 64) {
+    float v = 0.f;
+    if (j < Lk) v = scale * bf2f(p[j]) * (dp[j] - t);
+    ds[j] = f2bf(v);
+  }
+}
+
+// ---------------------------------------------------------------- cross entropy (one block per row)
+__global__ __launch_bounds__(256) void cross_entropy_kernel(bf16_t* __restrict__ logits, const int32_t* __restrict__ tgt,
+                                                            float* __restrict__ loss_sum, int V, int ldl, float gscale) {
+  __shared__ float red[4];
+  bf16_t* lr = logits + (long)blockIdx.x * ldl;
+  const int t = tgt[blockIdx.x];
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < V; j += 256) mx = fmaxf(mx, bf2f(lr[j]));
+  mx = block_max<4>(mx, red);
+  float sum = 0.f;
+  for (int j = threadIdx.x; j < V; j += 256) sum += __expf(bf2f(lr[j]) - mx);
+  sum = block_sum<4>(sum, red);
+  const float lse = mx + __logf(sum);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, lse - bf2f(lr[t]));
+  __syncthreads();  // everyone has read lr[t]-independent data; target logit read above by thread 0 before rewrite
+  for (int j = threadIdx.x; j < ldl; j += 256) {
+    float g = 0.f;
+    if (j < V) g = (__expf(bf2f(lr[j]) - lse) - (j == t ? 1.f : 0.f)) * gscale;
+    lr[j] = f2bf(g);
+  }
+}
+
+// ---------------------------------------------------------------- AdamW (f32 master, bf16 compute copy)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m,
+                                                    float* __restrict__ v, const bf16_t* __restrict__ grad,
+                                                    bf16_t* __restrict__ w, long n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 p = *reinterpret_cast<const f32x4*>(master + i * 4);
+    f32x4 mm = *reinterpret_cast<const f32x4*>(m + i * 4);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + i * 4);
+    const bf16x4 gg = *reinterpret_cast<const bf16x4*>(grad + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = bf2f((bf16_t)gg[j]) * gscale;
+      mm[j] = b1 * mm[j] + (1.f - b1) * g;
+      vv[j] = b2 * vv[j] + (1.f - b2) * g * g;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      p[j] = p[j] * (1.f - lr * wd) - (lr / bc1) * (mm[j] / denom);
+    }
+    *reinterpret_cast<f32x4*>(master + i * 4) = p;
+    *reinterpret_cast<f32x4*>(m + i * 4) = mm;
+    *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+    u32x2 o;
+    o[0] = pack2bf(p[0], p[1]);
+    o[1] = pack2bf(p[2], p[3]);
+    *reinterpret_cast<u32x2*>(w + i * 4) = o;
+  }
+  if (blockIdx.x == 0) {
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+      const float g = bf2f(grad[i]) * gscale;
+      const float mi = b1 * m[i] + (1.f - b1) * g;
+      const float vi = b2 * v[i] + (1.f - b2) * g * g;
+      const float denom = sqrtf(vi) / bc2_sqrt + eps;
+      const float p = master[i] * (1.f - lr * wd) - (lr / bc1) * (mi / denom);
+      master[i] = p; m[i] = mi; v[i] = vi; w[i] = f2bf(p);
+    }
+  }
+}
+
+}  // namespace
+
+// ==================================================================== C ABI
+extern "C" int vq3_silu_mul_fwd(const void* gu, void* act, int64_t rows, int32_t inter, void* stream) {
+  VQ3_CHECK_ARG(gu && act && rows > 0 && inter > 0 && inter % 8 == 0, "silu_mul_fwd: bad args (inter %% 8)");
+  hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(flat_grid(rows * (inter / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)gu, (bf16_t*)act, (long)rows, inter);
+  VQ3_CHECK_LAUNCH("silu_mul_fwd");
+  return 0;
+}
+extern "C" int vq3_silu_mul_bwd(const void* dact, const void* gu, void* dgu, int64_t rows, int32_t inter, void* stream) {
+  VQ3_CHECK_ARG(dact && gu && dgu && rows > 0 && inter > 0 && inter % 8 == 0, "silu_mul_bwd: bad args");
+  hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(flat_grid(rows * (inter / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dact, (const bf16_t*)gu, (bf16_t*)dgu, (long)rows, inter);
+  VQ3_CHECK_LAUNCH("silu_mul_bwd");
+  return 0;
+}
+
+extern "C" int vq3_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int32_t Rpad, int64_t lds,
+                                  int64_t ldd, int32_t n0, int32_t n1, int32_t n2, int64_t s0, int64_t s1, int64_t s2,
+                                  int64_t d0, int64_t d1, int64_t d2, void* stream) {
+  VQ3_CHECK_ARG(src && dst && R > 0 && C > 0 && Rpad >= R, "transpose: bad shape");
+  VQ3_CHECK_ARG(lds >= C && ldd >= Rpad, "transpose: leading dims too small");
+  VQ3_CHECK_ARG(n0 >= 1 && n1 >= 1 && n2 >= 1 && (long)n0 * n1 * n2 <= 65535, "transpose: bad batch dims");
+  dim3 grid((Rpad + 63) / 64, (C + 63) / 64, n0 * n1 * n2);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R, C,
+                     Rpad, (long)lds, (long)ldd, n1, n2, (long)s0, (long)s1, (long)s2, (long)d0, (long)d1, (long)d2);
+  VQ3_CHECK_LAUNCH("transpose_bf16");
+  return 0;
+}
+
+extern "C" int vq3_cast(const void* x, void* y, int64_t n, int32_t dir, void* stream) {
+  VQ3_CHECK_ARG(x && y && n > 0 && (dir == 0 || dir == 1), "cast: bad args");
+  VQ3_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "cast: pointers must be 16-byte aligned");
+  if (dir == 0)
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(flat_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, (bf16_t*)y, (long)n);
+  else
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(flat_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (float*)y, (long)n);
+  VQ3_CHECK_LAUNCH("cast");
+  return 0;
+}
+
+extern "C" int vq3_f32_to_bf16_acc(const float* src, void* acc_bf16, int64_t n, int32_t accumulate, void* stream) {
+  VQ3_CHECK_ARG(src && acc_bf16 && n > 0, "f32_to_bf16_acc: bad args");
+  hipLaunchKernelGGL(f32_to_bf16_acc_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t*)acc_bf16, (long)n, accumulate);
+  VQ3_CHECK_LAUNCH("f32_to_bf16_acc");
+  return 0;
+}
+
+extern "C" int vq3_gather_rows(const void* src, const int32_t* idx, void* out, int32_t n, int32_t n_pad, int32_t cols,
+                               void* stream) {
+  VQ3_CHECK_ARG(src && idx && out && n >= 0 && n_pad >= n && n_pad > 0 && cols > 0 && cols % 8 == 0,
+                "gather_rows: bad args");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n_pad), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx,
+                     (bf16_t*)out, n, cols);
+  VQ3_CHECK_LAUNCH("gather_rows");
+  return 0;
+}
+extern "C" int vq3_scatter_rows(const void* src, const int32_t* idx, void* dst, int32_t n, int32_t cols,
+                                int32_t accumulate, void* stream) {
+  VQ3_CHECK_ARG(src && idx && dst && n > 0 && cols > 0 && cols % 8 == 0, "scatter_rows: bad args");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, idx,
+                     (bf16_t*)dst, cols, accumulate);
+  VQ3_CHECK_LAUNCH("scatter_rows");
+  return 0;
+}
+
+extern "C" int vq3_embed_splice_fwd(const int64_t* ids, const void* table, const void* feat, const int32_t* srcmap,
+                                    void* out, int32_t B, int32_t L, int32_t H, int32_t S, void* stream) {
+  VQ3_CHECK_ARG(ids && table && srcmap && out, "embed_splice_fwd: null pointer");
+  VQ3_CHECK_ARG(B > 0 && L > 0 && H > 0 && H % 8 == 0 && S >= 0, "embed_splice_fwd: bad shape");
+  VQ3_CHECK_ARG(S == 0 || feat, "embed_splice_fwd: feat is null but S > 0");
+  hipLaunchKernelGGL(embed_splice_fwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, ids,
+                     (const bf16_t*)table, (const bf16_t*)feat, srcmap, (bf16_t*)out, L, H, S);
+  VQ3_CHECK_LAUNCH("embed_splice_fwd");
+  return 0;
+}
+
+extern "C" int vq3_embed_splice_bwd(const int64_t* sorted_ids, const int64_t* order, const int32_t* srcmap,
+                                    const void* dout, void* dtable_bf16, float* dfeat_f32, int32_t B, int32_t L,
+                                    int32_t H, int32_t S, void* stream) {
+  VQ3_CHECK_ARG(sorted_ids && order && srcmap && dout, "embed_splice_bwd: null pointer");
+  VQ3_CHECK_ARG(B > 0 && L > 0 && H > 0 && H % 8 == 0, "embed_splice_bwd: bad shape");
+  if (dtable_bf16) {
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, sorted_ids, order, srcmap,
+                       (const bf16_t*)dout, (bf16_t*)dtable_bf16, B * L, H);
+    VQ3_CHECK_LAUNCH("embed_bwd");
+  }
+  if (dfeat_f32 && S > 0) {
+    hipLaunchKernelGGL(splice_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, srcmap, (const bf16_t*)dout,
+                       dfeat_f32, L, H, S);
+    VQ3_CHECK_LAUNCH("splice_bwd");
+  }
+  return 0;
+}
+
+extern "C" int vq3_softmax_fwd(const float* S, void* P, const uint8_t* keymask, int32_t nb, int32_t heads_per_mask,
+                               int32_t Lq, int32_t Lk, int32_t ldS, int32_t ldP, int32_t causal, void* stream) {
+  VQ3_CHECK_ARG(S && P && nb > 0 && Lq > 0 && Lk > 0 && ldS >= Lk && ldP >= Lk && heads_per_mask >= 1,
+                "softmax_fwd: bad args");
+  const long nrows = (long)nb * Lq;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S,
+                     (bf16_t*)P, keymask, heads_per_mask, Lq, Lk, ldS, ldP, causal, nrows);
+  VQ3_CHECK_LAUNCH("softmax_fwd");
+  return 0;
+}
+extern "C" int vq3_softmax_bwd(const void* P, const float* dP, void* dS, int32_t nb, int32_t Lq, int32_t Lk,
+                               int32_t ldS, int32_t ldP, float scale, void* stream) {
+  VQ3_CHECK_ARG(P && dP && dS && nb > 0 && Lq > 0 && Lk > 0 && ldS >= Lk && ldP >= Lk, "softmax_bwd: bad args");
+  const long nrows = (long)nb * Lq;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)P, dP, (bf16_t*)dS, Lk, ldS, ldP, scale, nrows);
+  VQ3_CHECK_LAUNCH("softmax_bwd");
+  return 0;
+}
+
+extern "C" int vq3_cross_entropy_fwd_bwd(void* logits, const int32_t* targets, float* loss_sum_f32, int32_t n,
+                                         int32_t V, int32_t ldl, float gscale, void* stream) {
+  VQ3_CHECK_ARG(logits && targets && loss_sum_f32 && n > 0 && V > 0 && ldl >= V, "cross_entropy: bad args");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (bf16_t*)logits, targets,
+                     loss_sum_f32, V, ldl, gscale);
+  VQ3_CHECK_LAUNCH("cross_entropy");
+  return 0;
+}
+
+extern "C" int vq3_adamw_step(float* master, float* m, float* v, const void* grad_bf16, void* w_bf16, int64_t n,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                              float gscale, void* stream) {
+  VQ3_CHECK_ARG(master && m && v && grad_bf16 && w_bf16 && n > 0 && step >= 1, "adamw: bad args");
+  VQ3_CHECK_ARG(((uintptr_t)master % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                    ((uintptr_t)grad_bf16 % 8 == 0) && ((uintptr_t)w_bf16 % 8 == 0),
+                "adamw: buffers must be 16-byte (f32) / 8-byte (bf16) aligned");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, master, m, v,
+                     (const bf16_t*)grad_bf16, (bf16_t*)w_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
+                     gscale);
+  VQ3_CHECK_LAUNCH("adamw");
+  return 0;
+}

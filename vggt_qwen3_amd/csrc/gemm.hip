@@ -1,0 +1,289 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T)
+//
+// Both operands are K-contiguous ("NT"): this is torch.nn.functional.linear(x, W) with x = A, W = B, the
+// shape every contraction on the VGGT / Perceiver / Qwen3 path takes (QKV/O/FFN projections, lm_head, and
+// - by swapping operand roles or feeding transposed copies - every dgrad/wgrad and attention product).
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles.
+// Staging: global_load_dwordx4 -> registers -> ds_write_b128 into a double-buffered, XOR-swizzled LDS image
+// (128-byte rows, 16-byte chunk index ^ (row & 7): conflict-free for both the ds_write_b128 and the
+// ds_read_b128 fragment reads). One barrier per K tile; next tile's global loads are issued before the MFMAs.
+// The MFMA is issued with W as the A operand and x as the B operand so each lane ends up with 4 consecutive
+// output columns of one output row -> 8/16-byte epilogue stores and row-wise epilogues without shuffles.
+#include "common.h"
+#include "vq3_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
+constexpr int SMEM_BYTES = 4 * TILE_BYTES;       // 2 stages x (A,B) = 64 KiB
+
+struct GemmParams {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;      // [N] or null
+  const float* colscale;  // [N] or null  (LayerScale gamma)
+  const void* R;          // residual, same dtype as C, or null
+  int M, N, K, lda, ldb, ldc, ldr;
+  long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+  int nb2, b2divB;
+  int act;         // 0 none, 1 gelu(erf), 2 silu
+  int out_f32;     // C / R dtype: 0 bf16, 1 f32
+  int accumulate;  // C += result
+  int vec_ok;      // C (and R) rows are 16B (f32) / 8B (bf16) aligned for 4-wide stores
+  float alpha;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return gelu_erf(v);
+  if (act == 2) return silu_f(v);
+  return v;
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
+  const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
+  const bf16_t* B = p.B + b1 * p.sB1 + (long)(b2 / p.b2divB) * p.sB2;
+  const long coff = b1 * p.sC1 + b2 * p.sC2;
+  const long roff = b1 * p.sR1 + b2 * p.sR2;
+
+  // ---- staging map: chunk c = tid + 256*i -> row = c>>3 (0..127), 16B chunk kc = c&7 ----
+  const int srow = tid >> 3, kc = tid & 7;
+  const bf16_t* ga[4];
+  const bf16_t* gb[4];
+  int lds_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = srow + 32 * i;
+    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+    int rb = n0 + row; rb = rb < p.N ? rb : p.N - 1;
+    ga[i] = A + (long)ra * p.lda + kc * 8;
+    gb[i] = B + (long)rb * p.ldb + kc * 8;
+    lds_off[i] = row * 128 + ((kc ^ (row & 7)) << 4);
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra_[4], rb_[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra_[i] = *reinterpret_cast<const u32x4*>(ga[i]);
+    rb_[i] = *reinterpret_cast<const u32x4*>(gb[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<u32x4*>(smem + lds_off[i]) = ra_[i];
+    *reinterpret_cast<u32x4*>(smem + TILE_BYTES + lds_off[i]) = rb_[i];
+  }
+  __syncthreads();
+
+  // fragment read offsets (within one operand tile), k-step 0; k-step 1 flips chunk bit 2
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wm * 64 + i * 16 + fr;
+    a_off[i] = row * 128 + ((fq ^ (row & 7)) << 4);
+    const int rowb = wn * 64 + i * 16 + fr;
+    b_off[i] = rowb * 128 + ((fq ^ (rowb & 7)) << 4);
+  }
+
+  const int nt = p.K / BK;
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const bool more = (t + 1 < nt);
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ga[i] += BK;
+        gb[i] += BK;
+        ra_[i] = *reinterpret_cast<const u32x4*>(ga[i]);
+        rb_[i] = *reinterpret_cast<const u32x4*>(gb[i]);
+      }
+    }
+    const char* As = smem + cur * (2 * TILE_BYTES);
+    const char* Bs = As + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xa[4], wb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // chunk (ks*4 + fq) ^ (row&7): ks*4 only touches bit 2 -> xor 64 bytes
+        xa[i] = *reinterpret_cast<const bf16x8*>(As + (a_off[i] ^ (ks << 6)));
+        wb[i] = *reinterpret_cast<const bf16x8*>(Bs + (b_off[i] ^ (ks << 6)));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      char* Ad = smem + (cur ^ 1) * (2 * TILE_BYTES);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<u32x4*>(Ad + lds_off[i]) = ra_[i];
+        *reinterpret_cast<u32x4*>(Ad + TILE_BYTES + lds_off[i]) = rb_[i];
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane owns C[m][n..n+3], m = m0+wm*64+i*16+fr, n = n0+wn*64+j*16+4*fq ----
+  typedef typename std::conditional<OUT_F32, float, bf16_t>::type out_t;
+  out_t* C = reinterpret_cast<out_t*>(p.C) + coff;
+  const out_t* R = p.R ? reinterpret_cast<const out_t*>(p.R) + roff : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * fq;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+      const bool full = (n + 3 < p.N);
+      const int nv = full ? 4 : (p.N - n);
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nv) v[r] += p.bias[n + r];
+      }
+      if (!OUT_F32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+      }
+      if (p.act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = apply_act(v[r], p.act);
+          if (!OUT_F32) v[r] = rbf(v[r]);
+        }
+      }
+      if (p.colscale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nv) {
+            v[r] *= p.colscale[n + r];
+            if (!OUT_F32) v[r] = rbf(v[r]);
+          }
+      }
+      out_t* cp = C + (long)m * p.ldc + n;
+      const out_t* rp = R ? R + (long)m * p.ldr + n : nullptr;
+      if (full && p.vec_ok) {
+        if (OUT_F32) {
+          if (rp) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+          }
+          if (p.accumulate) {
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += cv[r];
+          }
+          *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          if (rp) {
+            const u32x2 rv = *reinterpret_cast<const u32x2*>(rp);
+            v[0] = rbf(v[0] + bf2f((bf16_t)(rv[0] & 0xffff)));
+            v[1] = rbf(v[1] + bf2f((bf16_t)(rv[0] >> 16)));
+            v[2] = rbf(v[2] + bf2f((bf16_t)(rv[1] & 0xffff)));
+            v[3] = rbf(v[3] + bf2f((bf16_t)(rv[1] >> 16)));
+          }
+          if (p.accumulate) {
+            const u32x2 cv = *reinterpret_cast<const u32x2*>(cp);
+            v[0] += bf2f((bf16_t)(cv[0] & 0xffff));
+            v[1] += bf2f((bf16_t)(cv[0] >> 16));
+            v[2] += bf2f((bf16_t)(cv[1] & 0xffff));
+            v[3] += bf2f((bf16_t)(cv[1] >> 16));
+          }
+          u32x2 o;
+          o[0] = pack2bf(v[0], v[1]);
+          o[1] = pack2bf(v[2], v[3]);
+          *reinterpret_cast<u32x2*>(cp) = o;
+        }
+      } else {
+        for (int r = 0; r < nv; ++r) {
+          float x = v[r];
+          if (OUT_F32) {
+            if (rp) x += (float)reinterpret_cast<const float*>(rp)[r];
+            if (p.accumulate) x += reinterpret_cast<const float*>(cp)[r];
+            reinterpret_cast<float*>(cp)[r] = x;
+          } else {
+            if (rp) x = rbf(x + bf2f(reinterpret_cast<const bf16_t*>(rp)[r]));
+            if (p.accumulate) x += bf2f(reinterpret_cast<const bf16_t*>(cp)[r]);
+            reinterpret_cast<bf16_t*>(cp)[r] = f2bf(x);
+          }
+        }
+      }
+    }
+  }
+}
+
+bool g_attr_set = false;
+
+}  // namespace
+
+extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
+  VQ3_CHECK_ARG(d != nullptr, "gemm: null descriptor");
+  VQ3_CHECK_ARG(d->A && d->B && d->C, "gemm: null operand pointer");
+  VQ3_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+  VQ3_CHECK_ARG(d->K % BK == 0, "gemm: K=%d must be a multiple of %d (pad operands with zeros)", d->K, BK);
+  VQ3_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm: lda=%d / ldb=%d must be multiples of 8", d->lda, d->ldb);
+  VQ3_CHECK_ARG(d->lda >= d->K && d->ldb >= d->K, "gemm: leading dims smaller than K");
+  VQ3_CHECK_ARG(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0), "gemm: A/B must be 16-byte aligned");
+  VQ3_CHECK_ARG(d->sA1 % 8 == 0 && d->sA2 % 8 == 0 && d->sB1 % 8 == 0 && d->sB2 % 8 == 0,
+                "gemm: batch strides of A/B must be multiples of 8 elements");
+  VQ3_CHECK_ARG(d->ldc >= d->N, "gemm: ldc=%d < N=%d", d->ldc, d->N);
+  VQ3_CHECK_ARG(d->nb1 >= 1 && d->nb2 >= 1 && d->b2divB >= 1, "gemm: bad batch dims");
+  VQ3_CHECK_ARG((long)d->nb1 * d->nb2 <= 65535, "gemm: too many batches");
+  VQ3_CHECK_ARG(d->act >= 0 && d->act <= 2, "gemm: bad activation %d", d->act);
+  VQ3_CHECK_ARG(!(d->R) || d->ldr >= d->N, "gemm: ldr < N");
+
+  GemmParams p;
+  p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;
+  p.bias = (const float*)d->bias; p.colscale = (const float*)d->colscale; p.R = d->R;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
+  p.sA1 = d->sA1; p.sA2 = d->sA2; p.sB1 = d->sB1; p.sB2 = d->sB2;
+  p.sC1 = d->sC1; p.sC2 = d->sC2; p.sR1 = d->sR1; p.sR2 = d->sR2;
+  p.nb2 = d->nb2; p.b2divB = d->b2divB;
+  p.act = d->act; p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.alpha = d->alpha;
+  const int esz = d->out_f32 ? 4 : 2;
+  bool vec = (d->ldc % 4 == 0) && (d->sC1 % 4 == 0) && (d->sC2 % 4 == 0) && ((uintptr_t)d->C % (4 * esz) == 0);
+  if (d->R) vec = vec && (d->ldr % 4 == 0) && (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0) && ((uintptr_t)d->R % (4 * esz) == 0);
+  p.vec_ok = vec ? 1 : 0;
+
+  if (!g_attr_set) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      vq3_set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      return 2;
+    }
+    g_attr_set = true;
+  }
+  dim3 grid((d->M + BM - 1) / BM, (d->N + BN - 1) / BN, d->nb1 * d->nb2);
+  VQ3_CHECK_ARG(grid.y <= 65535, "gemm: N too large for grid.y");
+  hipStream_t s = (hipStream_t)stream;
+  if (d->out_f32)
+    hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), SMEM_BYTES, s, p);
+  else
+    hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), SMEM_BYTES, s, p);
+  VQ3_CHECK_LAUNCH("gemm_bf16_nt");
+  return 0;
+}

@@ -1,0 +1,211 @@
+// RMSNorm (fwd/bwd) and LayerNorm (fwd) for gfx950. HBM-bound row kernels: one 64-lane wave per row,
+// 16-byte vector loads, wave shuffles for the row reductions (no LDS on the forward path).
+#include "common.h"
+#include "vq3_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------- RMSNorm forward
+// y = w * bf16(x * rsqrt(mean(x^2) + eps))   (modeling_qwen3.py:59-64: the cast to bf16 happens BEFORE the
+// multiply by the weight)
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, float* __restrict__ rstd,
+                                                          long rows, int cols, long ldx, long ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * ldx;
+  float ss = 0.f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = bf2f((bf16_t)v[j]);
+      ss += f * f;
+    }
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)cols + eps);
+  if (rstd && lane == 0) rstd[row] = rs;
+  bf16_t* yr = y + row * ldy;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
+    const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float n = rbf(bf2f((bf16_t)v[j]) * rs);
+      o[j] = (short)f2bf(bf2f((bf16_t)wv[j]) * n);
+    }
+    *reinterpret_cast<bf16x8*>(yr + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------- RMSNorm backward
+// 16 rows per block (4 waves x 4 rows); dw partials are summed in LDS, then one f32 atomic per column per block.
+constexpr int RB_ROWS = 16;
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w, const float* __restrict__ rstd,
+                                                          const bf16_t* dres, bf16_t* dx, float* __restrict__ dw,
+                                                          long rows, int cols) {
+  extern __shared__ float dw_s[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < cols; c += 256) dw_s[c] = 0.f;
+  __syncthreads();
+  for (int rr = 0; rr < RB_ROWS / 4; ++rr) {
+    const long row = (long)blockIdx.x * RB_ROWS + rr * 4 + wid;
+    if (row >= rows) continue;
+    const float rs = rstd[row];
+    const bf16_t* xr = x + row * (long)cols;
+    const bf16_t* gr = dy + row * (long)cols;
+    float dot = 0.f;
+    for (int c = lane * 8; c < cols; c += 512) {
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c);
+      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(gr + c);
+      const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = bf2f((bf16_t)xv[j]) * rs;
+        const float d = bf2f((bf16_t)gv[j]);
+        dot += d * bf2f((bf16_t)wv[j]) * xh;
+        atomicAdd(&dw_s[c + j], d * xh);
+      }
+    }
+    dot = wave_sum(dot) / (float)cols;
+    const bf16_t* rr_ = dres ? dres + row * (long)cols : nullptr;
+    bf16_t* dxr = dx + row * (long)cols;
+    for (int c = lane * 8; c < cols; c += 512) {
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c);
+      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(gr + c);
+      const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
+      bf16x8 rv;
+      if (rr_) rv = *reinterpret_cast<const bf16x8*>(rr_ + c);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = bf2f((bf16_t)xv[j]) * rs;
+        const float g = bf2f((bf16_t)gv[j]) * bf2f((bf16_t)wv[j]);
+        float d = rs * (g - xh * dot);
+        if (rr_) d += bf2f((bf16_t)rv[j]);
+        o[j] = (short)f2bf(d);
+      }
+      *reinterpret_cast<bf16x8*>(dxr + c) = o;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float v = dw_s[c];
+    if (v != 0.f) atomicAdd(&dw[c], v);
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm forward
+template <bool X_F32>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ res_,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            bf16_t* y_bf16, float* y_f32, long rows, int cols,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  auto ld4 = [&](const void* base, int c, float (&o)[4]) {
+    if (X_F32) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + row * (long)cols + c);
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    } else {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(base) + row * (long)cols + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = bf2f((bf16_t)v[j]);
+    }
+  };
+  auto ldrow = [&](int c, float (&o)[4]) {
+    ld4(x_, c, o);
+    if (res_) {
+      float r[4];
+      ld4(res_, c, r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] += r[j];
+        if (!X_F32) o[j] = rbf(o[j]);  // bf16 tensors: the sum is a bf16 tensor in PyTorch
+      }
+    }
+  };
+  float s = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    float v[4];
+    ldrow(c, v);
+    s += v[0] + v[1] + v[2] + v[3];
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    float v[4];
+    ldrow(c, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = v[j] - mean;
+      q += d * d;
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+  for (int c = lane * 4; c < cols; c += 256) {
+    float v[4];
+    ldrow(c, v);
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rs * wv[j] + bv[j];
+    if (y_f32) *reinterpret_cast<f32x4*>(y_f32 + row * (long)cols + c) = f32x4{o[0], o[1], o[2], o[3]};
+    if (y_bf16) {
+      u32x2 p;
+      p[0] = pack2bf(o[0], o[1]);
+      p[1] = pack2bf(o[2], o[3]);
+      *reinterpret_cast<u32x2*>(y_bf16 + row * (long)cols + c) = p;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vq3_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int32_t cols,
+                               int64_t ldx, int64_t ldy, float eps, void* stream) {
+  VQ3_CHECK_ARG(x && w && y, "rmsnorm_fwd: null pointer");
+  VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0, "rmsnorm_fwd: cols=%d must be a positive multiple of 8", cols);
+  VQ3_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= cols && ldy >= cols, "rmsnorm_fwd: bad row strides");
+  VQ3_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)w % 16 == 0),
+                "rmsnorm_fwd: pointers must be 16-byte aligned");
+  const long nblk = (rows + 3) / 4;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (const bf16_t*)w, (bf16_t*)y, rstd, (long)rows, cols, (long)ldx, (long)ldy, eps);
+  VQ3_CHECK_LAUNCH("rmsnorm_fwd");
+  return 0;
+}
+
+extern "C" int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
+                               void* dx, float* dw_f32, int64_t rows, int32_t cols, float eps, void* stream) {
+  (void)eps;
+  VQ3_CHECK_ARG(dy && x && w && rstd && dx && dw_f32, "rmsnorm_bwd: null pointer");
+  VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 16384, "rmsnorm_bwd: bad cols=%d", cols);
+  const long nblk = (rows + RB_ROWS - 1) / RB_ROWS;
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)nblk), dim3(256), cols * sizeof(float), (hipStream_t)stream,
+                     (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx,
+                     dw_f32, (long)rows, cols);
+  VQ3_CHECK_LAUNCH("rmsnorm_bwd");
+  return 0;
+}
+
+extern "C" int vq3_layernorm_fwd(const void* x, const void* res, int32_t x_f32, const float* w, const float* b,
+                                 void* y_bf16, float* y_f32, int64_t rows, int32_t cols, float eps, void* stream) {
+  VQ3_CHECK_ARG(x && w && b && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
+  VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_fwd: cols=%d must be a positive multiple of 4", cols);
+  const long nblk = (rows + 3) / 4;
+  if (x_f32)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, res, w,
+                       b, (bf16_t*)y_bf16, y_f32, (long)rows, cols, eps);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, res, w,
+                       b, (bf16_t*)y_bf16, y_f32, (long)rows, cols, eps);
+  VQ3_CHECK_LAUNCH("layernorm_fwd");
+  return 0;
+}

@@ -1,0 +1,284 @@
+"""Tensor-level wrappers over the C ABI (include/vq3_hip.h): they take torch CUDA tensors, check shapes/dtypes on the
+host, and enqueue the HIP kernel on torch's current stream. No math happens in Python or in torch here."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise _lib.Vq3Error(f"{name}: expected a CUDA (HIP) tensor; the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise _lib.Vq3Error(f"{name}: expected dtype {dtype}, got {t.dtype}")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
+             *, bias=None, colscale=None, R=None, ldr: int = 0, nb1: int = 1, nb2: int = 1, b2divB: int = 1,
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), act: int = 0, accumulate: bool = False, alpha: float = 1.0,
+             a_off: int = 0, b_off: int = 0, c_off: int = 0, r_off: int = 0) -> None:
+    """Raw descriptor launch. A/B bf16; C bf16 or f32 (decides out_f32). Offsets are in elements."""
+    _req(A, BF16, "gemm A"); _req(B, BF16, "gemm B")
+    if C.dtype not in (BF16, F32):
+        raise _lib.Vq3Error(f"gemm C: dtype must be bf16 or f32, got {C.dtype}")
+    if R is not None and R.dtype != C.dtype:
+        raise _lib.Vq3Error("gemm: residual dtype must equal C dtype")
+    if bias is not None: _req(bias, F32, "gemm bias")
+    if colscale is not None: _req(colscale, F32, "gemm colscale")
+    d = GemmDesc()
+    d.A = A.data_ptr() + 2 * a_off
+    d.B = B.data_ptr() + 2 * b_off
+    d.C = C.data_ptr() + C.element_size() * c_off
+    d.bias = _p(bias); d.colscale = _p(colscale)
+    d.R = None if R is None else R.data_ptr() + R.element_size() * r_off
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = M, N, K, lda, ldb, ldc, ldr
+    d.sA1, d.sA2 = sA; d.sB1, d.sB2 = sB; d.sC1, d.sC2 = sC; d.sR1, d.sR2 = sR
+    d.nb1, d.nb2, d.b2divB = nb1, nb2, b2divB
+    d.act = act; d.out_f32 = 1 if C.dtype == F32 else 0; d.accumulate = 1 if accumulate else 0
+    d.alpha = alpha
+    check(_lib.load().vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, *, bias=None, colscale=None, residual=None, act: int = 0,
+           out: Optional[torch.Tensor] = None, out_dtype=BF16, accumulate: bool = False,
+           alpha: float = 1.0) -> torch.Tensor:
+    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T). x, w: 2-D bf16 with unit inner stride."""
+    assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise _lib.Vq3Error(f"linear: K mismatch {K} vs {K2}")
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=out_dtype)
+    assert out.stride(1) == 1 and out.shape == (M, N)
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        ldr = residual.stride(0)
+    gemm_raw(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, colscale=colscale, R=residual,
+             ldr=ldr, act=act, accumulate=accumulate, alpha=alpha)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- norms
+def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, want_rstd: bool = False):
+    _req(x, BF16, "rmsnorm x"); _req(w, BF16, "rmsnorm w")
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), device=x.device, dtype=BF16)
+    rstd = torch.empty((rows,), device=x.device, dtype=F32) if want_rstd else None
+    check(_lib.load().vq3_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), _p(rstd), rows, cols, x.stride(0),
+                                      y.stride(0), eps, _stream()), "vq3_rmsnorm_fwd")
+    return (y, rstd) if want_rstd else y
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres, dw_f32, eps: float = 0.0):
+    """Returns dx (bf16) = [dres +] d/dx; accumulates into dw_f32 (caller zeroes)."""
+    _req(dy, BF16, "rmsnorm_bwd dy"); _req(x, BF16, "rmsnorm_bwd x"); _req(dw_f32, F32, "rmsnorm_bwd dw")
+    assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.load().vq3_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres),
+                                      dx.data_ptr(), dw_f32.data_ptr(), rows, cols, eps, _stream()), "vq3_rmsnorm_bwd")
+    return dx
+
+
+def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, *, res=None, want_bf16=True,
+                  want_f32=False):
+    assert x.is_contiguous() and x.dim() == 2
+    _req(w, F32, "layernorm w"); _req(b, F32, "layernorm b")
+    if x.dtype not in (BF16, F32):
+        raise _lib.Vq3Error("layernorm: x must be bf16 or f32")
+    if res is not None:
+        assert res.dtype == x.dtype and res.is_contiguous() and res.shape == x.shape
+    rows, cols = x.shape
+    yb = torch.empty((rows, cols), device=x.device, dtype=BF16) if want_bf16 else None
+    yf = torch.empty((rows, cols), device=x.device, dtype=F32) if want_f32 else None
+    check(_lib.load().vq3_layernorm_fwd(x.data_ptr(), _p(res), 1 if x.dtype == F32 else 0, w.data_ptr(), b.data_ptr(),
+                                        _p(yb), _p(yf), rows, cols, eps, _stream()), "vq3_layernorm_fwd")
+    return yb, yf
+
+
+# ----------------------------------------------------------------------------------------------- element-wise
+def silu_mul_fwd(gu: torch.Tensor) -> torch.Tensor:
+    _req(gu, BF16, "silu_mul gu")
+    assert gu.is_contiguous() and gu.dim() == 2 and gu.shape[1] % 2 == 0
+    rows, two_i = gu.shape
+    act = torch.empty((rows, two_i // 2), device=gu.device, dtype=BF16)
+    check(_lib.load().vq3_silu_mul_fwd(gu.data_ptr(), act.data_ptr(), rows, two_i // 2, _stream()), "vq3_silu_mul_fwd")
+    return act
+
+
+def silu_mul_bwd(dact: torch.Tensor, gu: torch.Tensor) -> torch.Tensor:
+    _req(dact, BF16, "silu_mul_bwd dact"); _req(gu, BF16, "silu_mul_bwd gu")
+    assert dact.is_contiguous() and gu.is_contiguous()
+    rows, two_i = gu.shape
+    dgu = torch.empty_like(gu)
+    check(_lib.load().vq3_silu_mul_bwd(dact.data_ptr(), gu.data_ptr(), dgu.data_ptr(), rows, two_i // 2, _stream()),
+          "vq3_silu_mul_bwd")
+    return dgu
+
+
+def transpose_raw(src, dst, R, C, Rpad, lds, ldd, n=(1, 1, 1), s=(0, 0, 0), d=(0, 0, 0), src_off=0, dst_off=0):
+    _req(src, BF16, "transpose src"); _req(dst, BF16, "transpose dst")
+    check(_lib.load().vq3_transpose_bf16(src.data_ptr() + 2 * src_off, dst.data_ptr() + 2 * dst_off, R, C, Rpad, lds,
+                                         ldd, n[0], n[1], n[2], s[0], s[1], s[2], d[0], d[1], d[2], _stream()),
+          "vq3_transpose_bf16")
+
+
+def transpose2d(x: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
+    """[R, C] bf16 -> [C, round_up(R, pad_to)] with zero padding."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    Rp = round_up(R, pad_to)
+    out = torch.empty((Cc, Rp), device=x.device, dtype=BF16)
+    transpose_raw(x, out, R, Cc, Rp, x.stride(0), Rp)
+    return out
+
+
+def cast(x: torch.Tensor, dtype) -> torch.Tensor:
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=dtype)
+    if x.dtype == F32 and dtype == BF16:
+        d = 0
+    elif x.dtype == BF16 and dtype == F32:
+        d = 1
+    else:
+        raise _lib.Vq3Error(f"cast: unsupported {x.dtype} -> {dtype}")
+    if x.numel():
+        check(_lib.load().vq3_cast(x.data_ptr(), y.data_ptr(), x.numel(), d, _stream()), "vq3_cast")
+    return y
+
+
+def f32_to_bf16_acc(src: torch.Tensor, acc: torch.Tensor, accumulate: bool) -> None:
+    _req(src, F32, "f32_to_bf16_acc src"); _req(acc, BF16, "f32_to_bf16_acc acc")
+    assert src.is_contiguous() and acc.is_contiguous() and src.numel() == acc.numel()
+    check(_lib.load().vq3_f32_to_bf16_acc(src.data_ptr(), acc.data_ptr(), src.numel(), 1 if accumulate else 0,
+                                          _stream()), "vq3_f32_to_bf16_acc")
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, n: int, n_pad: int) -> torch.Tensor:
+    _req(src, BF16, "gather_rows src"); _req(idx, torch.int32, "gather_rows idx")
+    assert src.is_contiguous() and src.dim() == 2
+    out = torch.empty((n_pad, src.shape[1]), device=src.device, dtype=BF16)
+    check(_lib.load().vq3_gather_rows(src.data_ptr(), idx.data_ptr(), out.data_ptr(), n, n_pad, src.shape[1],
+                                      _stream()), "vq3_gather_rows")
+    return out
+
+
+def scatter_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor, n: int, accumulate: bool) -> None:
+    _req(src, BF16, "scatter_rows src"); _req(idx, torch.int32, "scatter_rows idx"); _req(dst, BF16, "scatter dst")
+    assert src.is_contiguous() and dst.is_contiguous() and src.shape[1] == dst.shape[1]
+    if n > 0:
+        check(_lib.load().vq3_scatter_rows(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), n, src.shape[1],
+                                           1 if accumulate else 0, _stream()), "vq3_scatter_rows")
+
+
+# ----------------------------------------------------------------------------------------------- Qwen3 attention
+def qwen_qkprep_fwd(qkv, q_w, k_w, cos, sin, B, L, Hq, Hkv, D, eps, want_rstd=True):
+    _req(qkv, BF16, "qkprep qkv"); assert qkv.is_contiguous() and qkv.shape == (B * L, (Hq + 2 * Hkv) * D)
+    _req(cos, BF16, "qkprep cos"); _req(sin, BF16, "qkprep sin")
+    assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[-2:] == (L, D)
+    dev = qkv.device
+    Q = torch.empty((B, Hq, L, D), device=dev, dtype=BF16)
+    K = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
+    V = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
+    qr = torch.empty((B * L * Hq,), device=dev, dtype=F32) if want_rstd else None
+    kr = torch.empty((B * L * Hkv,), device=dev, dtype=F32) if want_rstd else None
+    check(_lib.load().vq3_qwen_qkprep_fwd(qkv.data_ptr(), q_w.data_ptr(), k_w.data_ptr(), cos.data_ptr(),
+                                          sin.data_ptr(), Q.data_ptr(), K.data_ptr(), V.data_ptr(), _p(qr), _p(kr), B,
+                                          L, Hq, Hkv, D, eps, _stream()), "vq3_qwen_qkprep_fwd")
+    return Q, K, V, qr, kr
+
+
+def qwen_qkprep_bwd(dQ, dK, dV, qkv, q_w, k_w, cos, sin, qr, kr, dq_w_f32, dk_w_f32, B, L, Hq, Hkv, D):
+    for t in (dQ, dK, dV, qkv):
+        _req(t, BF16, "qkprep_bwd"); assert t.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    check(_lib.load().vq3_qwen_qkprep_bwd(dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), qkv.data_ptr(), q_w.data_ptr(),
+                                          k_w.data_ptr(), cos.data_ptr(), sin.data_ptr(), qr.data_ptr(), kr.data_ptr(),
+                                          dqkv.data_ptr(), dq_w_f32.data_ptr(), dk_w_f32.data_ptr(), B, L, Hq, Hkv, D,
+                                          _stream()), "vq3_qwen_qkprep_bwd")
+    return dqkv
+
+
+def softmax_fwd(S: torch.Tensor, keymask: Optional[torch.Tensor], heads_per_mask: int, Lk: int, ldP: int,
+                causal: bool) -> torch.Tensor:
+    """S f32 [nb, Lq, ldS] -> P bf16 [nb, Lq, ldP]."""
+    _req(S, F32, "softmax S"); assert S.is_contiguous() and S.dim() == 3
+    nb, Lq, ldS = S.shape
+    if keymask is not None:
+        _req(keymask, torch.uint8, "softmax keymask"); assert keymask.is_contiguous()
+    P = torch.empty((nb, Lq, ldP), device=S.device, dtype=BF16)
+    check(_lib.load().vq3_softmax_fwd(S.data_ptr(), P.data_ptr(), _p(keymask), nb, heads_per_mask, Lq, Lk, ldS, ldP,
+                                      1 if causal else 0, _stream()), "vq3_softmax_fwd")
+    return P
+
+
+def softmax_bwd(P: torch.Tensor, dP: torch.Tensor, Lk: int, scale: float) -> torch.Tensor:
+    _req(P, BF16, "softmax_bwd P"); _req(dP, F32, "softmax_bwd dP")
+    assert P.is_contiguous() and dP.is_contiguous()
+    nb, Lq, ldP = P.shape
+    ldS = dP.shape[2]
+    dS = torch.empty_like(P)
+    check(_lib.load().vq3_softmax_bwd(P.data_ptr(), dP.data_ptr(), dS.data_ptr(), nb, Lq, Lk, ldS, ldP, scale,
+                                      _stream()), "vq3_softmax_bwd")
+    return dS
+
+
+# ----------------------------------------------------------------------------------------------- embedding / loss
+def embed_splice_fwd(ids, table, feat, srcmap, B, L, H, S):
+    _req(ids, torch.int64, "embed ids"); _req(table, BF16, "embed table"); _req(srcmap, torch.int32, "embed srcmap")
+    assert ids.is_contiguous() and table.is_contiguous() and srcmap.is_contiguous()
+    if feat is not None:
+        _req(feat, BF16, "embed feat"); assert feat.is_contiguous() and feat.shape == (B, S, H)
+    out = torch.empty((B, L, H), device=table.device, dtype=BF16)
+    check(_lib.load().vq3_embed_splice_fwd(ids.data_ptr(), table.data_ptr(), _p(feat), srcmap.data_ptr(),
+                                           out.data_ptr(), B, L, H, S if feat is not None else 0, _stream()),
+          "vq3_embed_splice_fwd")
+    return out
+
+
+def embed_splice_bwd(sorted_ids, order, srcmap, dout, dtable, dfeat_f32, B, L, H, S):
+    _req(dout, BF16, "embed_bwd dout"); assert dout.is_contiguous()
+    check(_lib.load().vq3_embed_splice_bwd(sorted_ids.data_ptr(), order.data_ptr(), srcmap.data_ptr(), dout.data_ptr(),
+                                           _p(dtable), _p(dfeat_f32), B, L, H, S, _stream()), "vq3_embed_splice_bwd")
+
+
+def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, loss_sum: torch.Tensor, n: int, V: int,
+                          gscale: float) -> None:
+    _req(logits, BF16, "ce logits"); _req(targets, torch.int32, "ce targets"); _req(loss_sum, F32, "ce loss_sum")
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    check(_lib.load().vq3_cross_entropy_fwd_bwd(logits.data_ptr(), targets.data_ptr(), loss_sum.data_ptr(), n, V,
+                                                logits.stride(0), gscale, _stream()), "vq3_cross_entropy_fwd_bwd")
+
+
+def adamw_step(master, m, v, grad, w, lr, beta1, beta2, eps, wd, step, gscale=1.0) -> None:
+    _req(master, F32, "adamw master"); _req(m, F32, "adamw m"); _req(v, F32, "adamw v")
+    _req(grad, BF16, "adamw grad"); _req(w, BF16, "adamw w")
+    n = master.numel()
+    assert m.numel() == n and v.numel() == n and grad.numel() == n and w.numel() == n
+    check(_lib.load().vq3_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), w.data_ptr(), n,
+                                     lr, beta1, beta2, eps, wd, step, gscale, _stream()), "vq3_adamw_step")
