@@ -1,0 +1,97 @@
+"""Pins the CPU oracle to the golden vectors produced by the reference itself (tools/make_golden.py)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import collate as ocollate
+from oracle import perceiver as operc
+from oracle import qwen3 as oq
+from oracle import vlm as ovlm
+from tests.golden_io import GOLDEN, bf16, load, meta, weights
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def _qcfg(m):
+    return oq.Qwen3Cfg(hidden_size=m["hidden_size"], num_hidden_layers=m["num_hidden_layers"],
+                       num_attention_heads=m["num_attention_heads"], num_key_value_heads=m["num_key_value_heads"],
+                       head_dim=m["head_dim"], intermediate_size=m["intermediate_size"],
+                       vocab_size=m.get("vocab_size", m.get("vocab")), rms_norm_eps=m["rms_norm_eps"],
+                       rope_theta=m["rope_theta"])
+
+
+def test_qwen3_forward_and_grads_match_hf():
+    z = load("qwen3_tiny.npz")
+    cfg = _qcfg(meta(z, "config"))
+    sd = {k: v.clone().requires_grad_(True) for k, v in weights(z).items()}
+    emb = bf16(z["inputs_embeds"]).clone().requires_grad_(True)
+    mask, labels = torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"])
+    hs = []
+    loss, logits = oq.causal_lm(emb, mask, labels, sd, cfg, collect=hs)
+    assert abs(loss.item() - float(z["loss"])) < 2e-3 * abs(float(z["loss"]))
+    valid = mask.bool()
+    assert relerr(logits[valid], bf16(z["logits"])[valid]) < 1e-2
+    # per-layer hidden states (HF hidden_states[i+1] is the output of layer i; the last one is post final norm)
+    assert relerr(hs[0][valid], bf16(z["hidden_1"])[valid]) < 1e-2
+    loss.backward()
+    assert relerr(emb.grad, bf16(z["d_inputs_embeds"])) < 2e-2
+    for name in ("model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight",
+                 "model.layers.0.self_attn.k_norm.weight", "model.layers.1.input_layernorm.weight",
+                 "model.norm.weight", "model.embed_tokens.weight"):
+        assert relerr(sd[name].grad, bf16(z["g:" + name])) < 3e-2, name
+
+
+def test_perceiver_matches_reference():
+    z = load("perceiver_tiny.npz")
+    m = meta(z, "config")
+    sd = {k: v.float() for k, v in weights(z).items()}
+    out = operc.projector(torch.from_numpy(z["tokens"]), sd, m["num_heads"], m["num_layers"])
+    assert relerr(out, torch.from_numpy(z["out"])) < 1e-5
+
+
+def test_collate_token_indices_bit_exact():
+    from transformers import AutoTokenizer
+    z = load("vlm_tiny.npz")
+    m = meta(z)
+    tok = AutoTokenizer.from_pretrained(str(GOLDEN / "tiny_tokenizer"))
+    tok.add_tokens(["<image>"])
+    assert tok.convert_tokens_to_ids("<image>") == m["image_id"]
+    qs = json.loads(bytes(z["questions"]).decode()); ans = json.loads(bytes(z["answers"]).decode())
+    out = ocollate.collate_text(tok, qs, ans, m["max_length"], m["num_vis_tokens"], m["geom_tokens"])
+    assert np.array_equal(out["input_ids"].numpy(), z["input_ids"])
+    assert np.array_equal(out["attention_mask"].numpy(), z["attention_mask"])
+    assert np.array_equal(out["labels"].numpy(), z["labels"])
+
+
+def test_vlm_forward_matches_reference():
+    z = load("vlm_tiny.npz")
+    m = meta(z)
+    sd = weights(z)
+    geom = {k: torch.from_numpy(z["geom:" + k]) for k in ("R", "t", "K", "depth_hist")}
+    ids = torch.from_numpy(z["input_ids"])
+    out = ovlm.forward(bf16(z["agg"]), geom, ids, torch.from_numpy(z["attention_mask"]),
+                       torch.from_numpy(z["labels"]), sd, _qcfg(m), heads=m["num_heads"], num_layers=m["num_layers"],
+                       num_vis_tokens=m["num_vis_tokens"], geom_tokens=m["geom_tokens"], image_id=m["image_id"])
+    assert relerr(out["vis_tokens"], torch.from_numpy(z["vis_tokens"])) < 1e-5
+    assert relerr(out["features"][:, :m["geom_tokens"]], torch.from_numpy(z["geom_feats"])) < 1e-5
+    assert torch.equal(out["inputs_embeds"], bf16(z["inputs_embeds"]))
+    assert abs(out["loss"].item() - float(z["loss"])) < 2e-3 * abs(float(z["loss"]))
+    # integer image of the splice loop
+    sm = ovlm.splice_srcmap(ids, m["num_vis_tokens"] + m["geom_tokens"], m["image_id"])
+    pos = (ids == m["image_id"]).nonzero()
+    for b, p in pos.tolist():
+        assert sm[b, p] == 0 and sm[b, p + m["num_vis_tokens"] + m["geom_tokens"] - 1] == m["num_vis_tokens"] + m["geom_tokens"] - 1
+    assert (sm >= 0).sum().item() == len(pos) * (m["num_vis_tokens"] + m["geom_tokens"])
+
+
+def test_splice_overrun_raises_like_reference():
+    ids = torch.tensor([[1, 2, 7, 3]])
+    with pytest.raises(RuntimeError):
+        ovlm.splice(torch.zeros(1, 4, 8), ids, torch.ones(1, 3, 8), image_id=7)
+    with pytest.raises(RuntimeError):
+        ovlm.splice_srcmap(ids, 3, 7)
