@@ -1,0 +1,482 @@
+"""Qwen3 causal LM on the HIP kernels: forward to the loss and a hand-written backward.
+
+Mirrors transformers' Qwen3ForCausalLM (modeling_qwen3.py:49-508) as the reference's VGGTQwen3VLM uses it
+(src/models/vggt_qwen3_vlm.py:36-42,190,196-201): same module/parameter names (so reference checkpoints load),
+`get_input_embeddings()`, `resize_token_embeddings()`, `config.hidden_size`. All arithmetic is in libvq3hip.so.
+
+Memory layout (sized for 288 GB HBM3E: everything replicated, nothing sharded):
+  flat_w   bf16  every parameter, one buffer; per layer [qkv | o | gate_up | down | 4 norm vectors] so the fused
+                 QKV and gate|up GEMMs read one contiguous weight and a layer is one contiguous all-reduce bucket
+  flat_g   bf16  gradients, same layout (parameters' .grad are views)
+  flat_wt  bf16  transposed copies [K, N] of the matrix weights for the dgrad GEMMs (the GEMM kernel is NT-only);
+                 refreshed by `refresh_transposed()` after every optimiser step
+"""
+from __future__ import annotations
+
+import json
+import math
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import BF16, F32, round_up
+
+
+@dataclass
+class Qwen3Config:
+    hidden_size: int = 2560
+    num_hidden_layers: int = 36
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    intermediate_size: int = 9728
+    vocab_size: int = 151936
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 5_000_000.0
+    tie_word_embeddings: bool = True
+    initializer_range: float = 0.02
+
+    @classmethod
+    def qwen3_4b(cls) -> "Qwen3Config":
+        return cls()
+
+    @classmethod
+    def from_json(cls, path) -> "Qwen3Config":
+        d = json.loads(Path(path).read_text())
+        rp = d.get("rope_parameters") or {}
+        return cls(hidden_size=d["hidden_size"], num_hidden_layers=d["num_hidden_layers"],
+                   num_attention_heads=d["num_attention_heads"], num_key_value_heads=d["num_key_value_heads"],
+                   head_dim=d.get("head_dim") or d["hidden_size"] // d["num_attention_heads"],
+                   intermediate_size=d["intermediate_size"], vocab_size=d["vocab_size"],
+                   rms_norm_eps=d.get("rms_norm_eps", 1e-6),
+                   rope_theta=float(rp.get("rope_theta", d.get("rope_theta", 10000.0))),
+                   tie_word_embeddings=d.get("tie_word_embeddings", True),
+                   initializer_range=d.get("initializer_range", 0.02))
+
+
+class _W(nn.Module):
+    """Parameter holder with the HF module name (q_proj, input_layernorm, ...). Never called."""
+
+    def __init__(self, weight: torch.Tensor):
+        super().__init__()
+        self.weight = nn.Parameter(weight, requires_grad=True)
+
+
+class _Attn(nn.Module):
+    pass
+
+
+class _MLP(nn.Module):
+    pass
+
+
+class _Layer(nn.Module):
+    pass
+
+
+class _Body(nn.Module):
+    pass
+
+
+class Qwen3ForCausalLM(nn.Module):
+    def __init__(self, config: Qwen3Config, device="cuda", seed: Optional[int] = 0):
+        super().__init__()
+        self.config = config
+        c = config
+        H, I, D = c.hidden_size, c.intermediate_size, c.head_dim
+        self.Hq, self.Hkv, self.D = c.num_attention_heads, c.num_key_value_heads, D
+        if D != 128:
+            raise ops._lib.Vq3Error("Qwen3 HIP path requires head_dim == 128")
+        if H % 64 or I % 64 or (self.Hq * D) % 64:
+            raise ops._lib.Vq3Error("hidden/intermediate sizes must be multiples of 64")
+        self.nqkv = (self.Hq + 2 * self.Hkv) * D
+        self.device_ = torch.device(device)
+        self._rope_cache: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._alloc(c.vocab_size, seed)
+
+    # ------------------------------------------------------------------ storage
+    def _layout(self, vocab: int):
+        c = self.config
+        H, I, D = c.hidden_size, c.intermediate_size, c.head_dim
+        ent = [("embed", (vocab, H))]
+        for i in range(c.num_hidden_layers):
+            ent += [(f"l{i}.qkv", (self.nqkv, H)), (f"l{i}.o", (H, self.Hq * D)), (f"l{i}.gu", (2 * I, H)),
+                    (f"l{i}.down", (H, I)), (f"l{i}.ln1", (H,)), (f"l{i}.ln2", (H,)), (f"l{i}.qn", (D,)),
+                    (f"l{i}.kn", (D,))]
+        ent.append(("norm", (H,)))
+        off, table = 0, {}
+        for name, shape in ent:
+            n = math.prod(shape)
+            table[name] = (off, shape)
+            off += round_up(n, 64)  # keep every tensor 128-byte aligned
+        return table, off
+
+    def _alloc(self, vocab: int, seed: Optional[int], old: Optional[Dict[str, torch.Tensor]] = None):
+        c = self.config
+        dev = self.device_
+        self.vocab = vocab
+        self.table, total = self._layout(vocab)
+        self.flat_w = torch.zeros(total, device=dev, dtype=BF16)
+        self.flat_g = torch.zeros(total, device=dev, dtype=BF16)
+        self._w = {n: self.flat_w[o:o + math.prod(s)].view(s) for n, (o, s) in self.table.items()}
+        self._g = {n: self.flat_g[o:o + math.prod(s)].view(s) for n, (o, s) in self.table.items()}
+        # transposed copies for dgrad: Wt[K, round_up(N, 64)]
+        self.vocab_p = round_up(vocab, 64)
+        tt, toff = {}, 0
+        for n, (o, s) in self.table.items():
+            if len(s) == 2:
+                Np = round_up(s[0], 64)
+                tt[n] = (toff, (s[1], Np))
+                toff += s[1] * Np
+        self.flat_wt = torch.zeros(toff, device=dev, dtype=BF16)
+        self._wt = {n: self.flat_wt[o:o + math.prod(s)].view(s) for n, (o, s) in tt.items()}
+        if seed is not None:
+            g = torch.Generator(device="cpu").manual_seed(seed)
+            for n, w in self._w.items():
+                if w.dim() == 2:
+                    # chunked host-side normal init (std = initializer_range), like HF _init_weights
+                    rows = w.shape[0]
+                    step = max(1, (1 << 24) // w.shape[1])
+                    for r in range(0, rows, step):
+                        blk = torch.randn((min(step, rows - r), w.shape[1]), generator=g) * c.initializer_range
+                        w[r:r + blk.shape[0]].copy_(blk.to(BF16))
+                else:
+                    w.fill_(1.0)
+        if old is not None:
+            for n, t in old.items():
+                if n == "embed":
+                    k = min(t.shape[0], vocab)
+                    self._w["embed"][:k].copy_(t[:k])
+                    if vocab > k:  # HF mean-resizing is random; use the mean row (deterministic)
+                        self._w["embed"][k:].copy_(t.float().mean(0, keepdim=True).to(BF16).expand(vocab - k, -1))
+                else:
+                    self._w[n].copy_(t)
+        self._build_modules()
+        self.refresh_transposed()
+
+    def _build_modules(self):
+        c = self.config
+        H, I, D = c.hidden_size, c.intermediate_size, c.head_dim
+        body = _Body()
+        body.embed_tokens = _W(self._w["embed"])
+        layers = []
+        for i in range(c.num_hidden_layers):
+            L = _Layer()
+            a = _Attn()
+            qkv = self._w[f"l{i}.qkv"]
+            a.q_proj = _W(qkv[: self.Hq * D])
+            a.k_proj = _W(qkv[self.Hq * D:(self.Hq + self.Hkv) * D])
+            a.v_proj = _W(qkv[(self.Hq + self.Hkv) * D:])
+            a.o_proj = _W(self._w[f"l{i}.o"])
+            a.q_norm = _W(self._w[f"l{i}.qn"])
+            a.k_norm = _W(self._w[f"l{i}.kn"])
+            m = _MLP()
+            gu = self._w[f"l{i}.gu"]
+            m.gate_proj = _W(gu[:I])
+            m.up_proj = _W(gu[I:])
+            m.down_proj = _W(self._w[f"l{i}.down"])
+            L.self_attn, L.mlp = a, m
+            L.input_layernorm = _W(self._w[f"l{i}.ln1"])
+            L.post_attention_layernorm = _W(self._w[f"l{i}.ln2"])
+            layers.append(L)
+        body.layers = nn.ModuleList(layers)
+        body.norm = _W(self._w["norm"])
+        self.model = body
+        self.lm_head = _W(self._w["embed"])
+        self.lm_head.weight = body.embed_tokens.weight  # tied (modeling_qwen3.py `_tied_weights_keys`)
+        self._bind_grads()
+
+    def _grad_views(self) -> Dict[str, torch.Tensor]:
+        c = self.config
+        I, D = c.intermediate_size, c.head_dim
+        out = {"model.embed_tokens.weight": self._g["embed"], "model.norm.weight": self._g["norm"]}
+        for i in range(c.num_hidden_layers):
+            p = f"model.layers.{i}."
+            qkv, gu = self._g[f"l{i}.qkv"], self._g[f"l{i}.gu"]
+            out[p + "self_attn.q_proj.weight"] = qkv[: self.Hq * D]
+            out[p + "self_attn.k_proj.weight"] = qkv[self.Hq * D:(self.Hq + self.Hkv) * D]
+            out[p + "self_attn.v_proj.weight"] = qkv[(self.Hq + self.Hkv) * D:]
+            out[p + "self_attn.o_proj.weight"] = self._g[f"l{i}.o"]
+            out[p + "self_attn.q_norm.weight"] = self._g[f"l{i}.qn"]
+            out[p + "self_attn.k_norm.weight"] = self._g[f"l{i}.kn"]
+            out[p + "mlp.gate_proj.weight"] = gu[:I]
+            out[p + "mlp.up_proj.weight"] = gu[I:]
+            out[p + "mlp.down_proj.weight"] = self._g[f"l{i}.down"]
+            out[p + "input_layernorm.weight"] = self._g[f"l{i}.ln1"]
+            out[p + "post_attention_layernorm.weight"] = self._g[f"l{i}.ln2"]
+        return out
+
+    def _bind_grads(self):
+        self.grad_views = self._grad_views()
+
+    def publish_grads(self):
+        """Expose the flat gradient buffer through the parameters' .grad (for stock torch optimisers / DDP)."""
+        named = dict(self.named_parameters())
+        for n, g in self.grad_views.items():
+            named[n].grad = g
+
+    def zero_grad_flat(self):
+        self.flat_g.zero_()
+
+    def refresh_transposed(self):
+        """Re-derive the [K, N] copies after the weights changed (load / optimiser step)."""
+        for n, wt in self._wt.items():
+            w = self._w[n]
+            ops.transpose_raw(w, wt, w.shape[0], w.shape[1], wt.shape[1], w.shape[1], wt.shape[1])
+
+    # ------------------------------------------------------------------ HF-compatible surface
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def resize_token_embeddings(self, n: int):
+        if n == self.vocab:
+            return self.model.embed_tokens
+        old = {k: v.clone() for k, v in self._w.items()}
+        self.config.vocab_size = n
+        self._alloc(n, None, old)
+        return self.model.embed_tokens
+
+    def load_hf_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        named = dict(self.named_parameters())
+        missing = []
+        with torch.no_grad():
+            for n, p in named.items():
+                if n in sd:
+                    p.copy_(sd[n].to(device=p.device, dtype=p.dtype))
+                elif n == "lm_head.weight" and "model.embed_tokens.weight" in sd:
+                    pass
+                else:
+                    missing.append(n)
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}...")
+        self.refresh_transposed()
+        return missing
+
+    @classmethod
+    def from_pretrained_dir(cls, path, device="cuda") -> "Qwen3ForCausalLM":
+        """Local directory with config.json + *.safetensors (no network access is ever attempted)."""
+        from safetensors.torch import load_file
+        path = Path(path)
+        cfg = Qwen3Config.from_json(path / "config.json")
+        m = cls(cfg, device=device, seed=None)
+        sd = {}
+        for f in sorted(path.glob("*.safetensors")):
+            sd.update(load_file(str(f)))
+        m.load_hf_state_dict(sd, strict=True)
+        return m
+
+    # ------------------------------------------------------------------ helpers
+    def rope(self, L: int):
+        """cos/sin tables as HF builds them: fp32 angles, cat(freqs, freqs), cast to bf16 (modeling_qwen3.py:104-146).
+        Parameter-free table, built once per sequence length on the host."""
+        if L not in self._rope_cache:
+            D, th = self.D, self.config.rope_theta
+            inv = 1.0 / (th ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+            fr = (inv[:, None] @ torch.arange(L, dtype=torch.float)[None, :]).transpose(0, 1)
+            emb = torch.cat((fr, fr), dim=-1)
+            self._rope_cache[L] = (emb.cos().to(BF16).to(self.device_).contiguous(),
+                                   emb.sin().to(BF16).to(self.device_).contiguous())
+        return self._rope_cache[L]
+
+    # ------------------------------------------------------------------ forward
+    def _attention_fwd(self, i, xn, B, L, keymask, ctx):
+        c = self.config
+        Hq, Hkv, D, G = self.Hq, self.Hkv, self.D, self.Hq // self.Hkv
+        Lp = round_up(L, 64)
+        cos, sin = self.rope(L)
+        qkv = ops.linear(xn, self._w[f"l{i}.qkv"])
+        Q, K, V, qr, kr = ops.qwen_qkprep_fwd(qkv, self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin, B, L, Hq, Hkv,
+                                              D, c.rms_norm_eps, want_rstd=ctx is not None)
+        S = torch.empty((B * Hq, L, Lp), device=xn.device, dtype=F32)
+        ops.gemm_raw(Q, K, S, L, L, D, D, D, Lp, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * D, L * D),
+                     sB=(Hkv * L * D, L * D), sC=(Hq * L * Lp, L * Lp), alpha=D ** -0.5)
+        P = ops.softmax_fwd(S, keymask, Hq, L, Lp, True)
+        Vt = torch.empty((B, Hkv, D, Lp), device=xn.device, dtype=BF16)
+        ops.transpose_raw(V, Vt, L, D, Lp, D, Lp, n=(1, B, Hkv), s=(0, Hkv * L * D, L * D), d=(0, Hkv * D * Lp, D * Lp))
+        ao = torch.empty((B * L, Hq * D), device=xn.device, dtype=BF16)
+        ops.gemm_raw(P, Vt, ao, L, D, Lp, Lp, Lp, Hq * D, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * Lp, L * Lp),
+                     sB=(Hkv * D * Lp, D * Lp), sC=(L * Hq * D, D))
+        if ctx is not None:
+            ctx.update(qkv=qkv, Q=Q, K=K, V=V, qr=qr, kr=kr, P=P, ao=ao)
+        return ao
+
+    def forward_hidden(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, save: bool):
+        """36x decoder layer (modeling_qwen3.py:294-323, 367-427). Returns (h_last [B*L,H] pre-final-norm, saved)."""
+        B, L, H = inputs_embeds.shape
+        c = self.config
+        keymask = (attention_mask != 0).to(torch.uint8).contiguous()
+        h = inputs_embeds.reshape(B * L, H)
+        saved: List[dict] = []
+        for i in range(c.num_hidden_layers):
+            ctx = {} if save else None
+            xn1, r1 = ops.rmsnorm_fwd(h, self._w[f"l{i}.ln1"], c.rms_norm_eps, want_rstd=True)
+            ao = self._attention_fwd(i, xn1, B, L, keymask, ctx)
+            h_mid = ops.linear(ao, self._w[f"l{i}.o"], residual=h)
+            xn2, r2 = ops.rmsnorm_fwd(h_mid, self._w[f"l{i}.ln2"], c.rms_norm_eps, want_rstd=True)
+            gu = ops.linear(xn2, self._w[f"l{i}.gu"])
+            act = ops.silu_mul_fwd(gu)
+            h_out = ops.linear(act, self._w[f"l{i}.down"], residual=h_mid)
+            if save:
+                ctx.update(h_in=h, r1=r1, xn1=xn1, h_mid=h_mid, r2=r2, xn2=xn2, gu=gu, act=act)
+                saved.append(ctx)
+            h = h_out
+        return h, {"layers": saved, "B": B, "L": L, "keymask": keymask}
+
+    @staticmethod
+    def label_rows(labels: torch.Tensor):
+        """loss_utils.py:49-71: position t predicts labels[t+1]; rows whose shifted label is -100 are ignored.
+        Returns (row indices i32 [n], targets i32 [n]) - host-visible n (one small sync, like the reference's
+        `.nonzero()` on the <image> positions)."""
+        B, L = labels.shape
+        shift = torch.full_like(labels, -100)
+        shift[:, :-1] = labels[:, 1:]
+        flat = shift.reshape(-1)
+        idx = (flat != -100).nonzero(as_tuple=False).squeeze(1)
+        return idx.to(torch.int32), flat[idx].to(torch.int32)
+
+    def loss_head(self, h_last: torch.Tensor, labels: torch.Tensor, save: bool):
+        """Final RMSNorm + tied lm_head + shifted mean cross-entropy, evaluated only on the rows that carry a label
+        (the other rows of the reference's [B,L,V] logits never reach the loss). Also leaves d(loss)/d(logits) in
+        place for the backward."""
+        c = self.config
+        H = c.hidden_size
+        idx, tgt = self.label_rows(labels)
+        n = int(idx.numel())
+        if n == 0:
+            return torch.full((), float("nan"), device=h_last.device, dtype=F32), None
+        hs = ops.gather_rows(h_last, idx, n, n)
+        hn, rstd = ops.rmsnorm_fwd(hs, self._w["norm"], c.rms_norm_eps, want_rstd=True)
+        ldl = self.vocab_p
+        logits = torch.empty((n, ldl), device=h_last.device, dtype=BF16)
+        ops.gemm_raw(hn, self._w["embed"], logits, n, self.vocab, H, H, H, ldl)
+        loss_sum = torch.zeros(1, device=h_last.device, dtype=F32)
+        ops.cross_entropy_fwd_bwd(logits, tgt, loss_sum, n, self.vocab, 1.0 / n)
+        loss = (loss_sum / n).reshape(())
+        ctx = dict(idx=idx, n=n, hs=hs, hn=hn, rstd=rstd, dlogits=logits) if save else None
+        return loss, ctx
+
+    def logits_all(self, h_last: torch.Tensor) -> torch.Tensor:
+        """Full [rows, vocab] logits (inference / parity checks only)."""
+        c = self.config
+        hn = ops.rmsnorm_fwd(h_last, self._w["norm"], c.rms_norm_eps)
+        out = torch.empty((h_last.shape[0], self.vocab_p), device=h_last.device, dtype=BF16)
+        ops.gemm_raw(hn, self._w["embed"], out, h_last.shape[0], self.vocab, c.hidden_size, c.hidden_size,
+                     c.hidden_size, self.vocab_p)
+        return out[:, : self.vocab]
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, name: str, dY: torch.Tensor, X: torch.Tensor, accumulate: bool):
+        """dW[N,K] (+)= dY^T[N,M] . X[M,K]: both operands are transposed (zero-padded M) to make M the contiguous
+        contraction dim of the NT GEMM."""
+        M = dY.shape[0]
+        dYt = ops.transpose2d(dY, 64)
+        Xt = ops.transpose2d(X, 64)
+        g = self._g[name]
+        ops.gemm_raw(dYt, Xt, g, g.shape[0], g.shape[1], dYt.shape[1], dYt.shape[1], Xt.shape[1], g.shape[1],
+                     accumulate=accumulate)
+
+    def _norm_wgrad(self, name: str, dw_f32: torch.Tensor, accumulate: bool):
+        ops.f32_to_bf16_acc(dw_f32, self._g[name], accumulate)
+
+    def _attention_bwd(self, i, ctx, d_ao, B, L):
+        Hq, Hkv, D, G = self.Hq, self.Hkv, self.D, self.Hq // self.Hkv
+        Lp = round_up(L, 64)
+        dev = d_ao.device
+        Q, K, V, P = ctx["Q"], ctx["K"], ctx["V"], ctx["P"]
+        # dP[b,h] = dAO[b,h] . V[b,h/G]^T
+        dP = torch.empty((B * Hq, L, Lp), device=dev, dtype=F32)
+        ops.gemm_raw(d_ao, V, dP, L, L, D, Hq * D, D, Lp, nb1=B, nb2=Hq, b2divB=G, sA=(L * Hq * D, D),
+                     sB=(Hkv * L * D, L * D), sC=(Hq * L * Lp, L * Lp))
+        dS = ops.softmax_bwd(P, dP, L, D ** -0.5)
+        # dQ[b,h] = dS[b,h] . K[b,h/G]   (needs K^T as the NT B operand)
+        Kt = torch.empty((B, Hkv, D, Lp), device=dev, dtype=BF16)
+        ops.transpose_raw(K, Kt, L, D, Lp, D, Lp, n=(1, B, Hkv), s=(0, Hkv * L * D, L * D), d=(0, Hkv * D * Lp, D * Lp))
+        dQ = torch.empty((B, Hq, L, D), device=dev, dtype=BF16)
+        ops.gemm_raw(dS, Kt, dQ, L, D, Lp, Lp, Lp, D, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * Lp, L * Lp),
+                     sB=(Hkv * D * Lp, D * Lp), sC=(Hq * L * D, L * D))
+        # dK[b,kv] = sum_g dS[b,h]^T . Q[b,h] ; dV[b,kv] = sum_g P[b,h]^T . dAO[b,h]: the (g, query) pair is the
+        # contraction dim -> transposed, zero-padded copies [.., G*Lp]
+        GL = G * Lp
+        dSt = torch.empty((B, Hkv, L, GL), device=dev, dtype=BF16)
+        Pt = torch.empty((B, Hkv, L, GL), device=dev, dtype=BF16)
+        for src, dst in ((dS, dSt), (P, Pt)):
+            ops.transpose_raw(src, dst, L, L, Lp, Lp, GL, n=(B, Hkv, G), s=(Hq * L * Lp, G * L * Lp, L * Lp),
+                              d=(Hkv * L * GL, L * GL, Lp))
+        Qt = torch.empty((B, Hkv, D, GL), device=dev, dtype=BF16)
+        ops.transpose_raw(Q, Qt, L, D, Lp, D, GL, n=(B, Hkv, G), s=(Hq * L * D, G * L * D, L * D),
+                          d=(Hkv * D * GL, D * GL, Lp))
+        dAOt = torch.empty((B, Hkv, D, GL), device=dev, dtype=BF16)
+        ops.transpose_raw(d_ao, dAOt, L, D, Lp, Hq * D, GL, n=(B, Hkv, G), s=(L * Hq * D, G * D, D),
+                          d=(Hkv * D * GL, D * GL, Lp))
+        dK = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
+        dV = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
+        ops.gemm_raw(dSt, Qt, dK, L, D, GL, GL, GL, D, nb1=B, nb2=Hkv, sA=(Hkv * L * GL, L * GL),
+                     sB=(Hkv * D * GL, D * GL), sC=(Hkv * L * D, L * D))
+        ops.gemm_raw(Pt, dAOt, dV, L, D, GL, GL, GL, D, nb1=B, nb2=Hkv, sA=(Hkv * L * GL, L * GL),
+                     sB=(Hkv * D * GL, D * GL), sC=(Hkv * L * D, L * D))
+        return dQ, dK, dV
+
+    def backward_hidden(self, saved, dh: torch.Tensor, accumulate: bool, gscale_hook=None, layer_done=None):
+        """Backward through the decoder stack. dh: d(loss)/d(h_last) [B*L, H] bf16. Gradients go to flat_g
+        (accumulate=False overwrites). layer_done(i) is called when layer i's gradients are final (DP overlap hook).
+        Returns d(inputs_embeds) [B*L, H]."""
+        c = self.config
+        B, L = saved["B"], saved["L"]
+        H, D = c.hidden_size, self.D
+        dev = dh.device
+        cos, sin = self.rope(L)
+        for i in reversed(range(c.num_hidden_layers)):
+            ctx = saved["layers"][i]
+            # down_proj
+            d_act = ops.linear(dh, self._wt[f"l{i}.down"])
+            self._wgrad(f"l{i}.down", dh, ctx["act"], accumulate)
+            dgu = ops.silu_mul_bwd(d_act, ctx["gu"])
+            d_xn2 = ops.linear(dgu, self._wt[f"l{i}.gu"])
+            self._wgrad(f"l{i}.gu", dgu, ctx["xn2"], accumulate)
+            dw = torch.zeros(H, device=dev, dtype=F32)
+            dh_mid = ops.rmsnorm_bwd(d_xn2, ctx["h_mid"], self._w[f"l{i}.ln2"], ctx["r2"], dh, dw)
+            self._norm_wgrad(f"l{i}.ln2", dw, accumulate)
+            # o_proj
+            d_ao = ops.linear(dh_mid, self._wt[f"l{i}.o"])
+            self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
+            dQ, dK, dV = self._attention_bwd(i, ctx, d_ao, B, L)
+            dqw = torch.zeros(D, device=dev, dtype=F32)
+            dkw = torch.zeros(D, device=dev, dtype=F32)
+            dqkv = ops.qwen_qkprep_bwd(dQ, dK, dV, ctx["qkv"], self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin,
+                                       ctx["qr"], ctx["kr"], dqw, dkw, B, L, self.Hq, self.Hkv, D)
+            self._norm_wgrad(f"l{i}.qn", dqw, accumulate)
+            self._norm_wgrad(f"l{i}.kn", dkw, accumulate)
+            d_xn1 = ops.linear(dqkv, self._wt[f"l{i}.qkv"])
+            self._wgrad(f"l{i}.qkv", dqkv, ctx["xn1"], accumulate)
+            dw1 = torch.zeros(H, device=dev, dtype=F32)
+            dh = ops.rmsnorm_bwd(d_xn1, ctx["h_in"], self._w[f"l{i}.ln1"], ctx["r1"], dh_mid, dw1)
+            self._norm_wgrad(f"l{i}.ln1", dw1, accumulate)
+            if layer_done is not None:
+                layer_done(i)
+        return dh
+
+    def backward_loss_head(self, head_ctx, rows: int, gscale: float, accumulate: bool) -> torch.Tensor:
+        """Backward of loss_head: returns d(loss)/d(h_last) [rows, H] (zero on rows without a label) and writes the
+        lm_head contribution to the tied embedding gradient."""
+        c = self.config
+        H = c.hidden_size
+        dev = head_ctx["hn"].device
+        n, dlog = head_ctx["n"], head_ctx["dlogits"]
+        # d(hn) = dlogits[n, Vp] . E[V, H]  via E^T [H, Vp]
+        d_hn = torch.empty((n, H), device=dev, dtype=BF16)
+        ops.gemm_raw(dlog, self._wt["embed"], d_hn, n, H, self.vocab_p, self.vocab_p, self.vocab_p, H, alpha=gscale)
+        # dE[V, H] (+)= dlogits^T[V, n] . hn[n, H]
+        dlt = ops.transpose2d(dlog[:, : self.vocab], 64)
+        hnt = ops.transpose2d(head_ctx["hn"], 64)
+        ops.gemm_raw(dlt, hnt, self._g["embed"], self.vocab, H, dlt.shape[1], dlt.shape[1], hnt.shape[1], H,
+                     accumulate=accumulate, alpha=gscale)
+        dw = torch.zeros(H, device=dev, dtype=F32)
+        d_hs = ops.rmsnorm_bwd(d_hn, head_ctx["hs"], self._w["norm"], head_ctx["rstd"], None, dw)
+        self._norm_wgrad("norm", dw, accumulate)
+        dh = torch.zeros((rows, H), device=dev, dtype=BF16)
+        ops.scatter_rows(d_hs, head_ctx["idx"], dh, n, False)
+        return dh

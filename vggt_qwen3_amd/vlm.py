@@ -1,0 +1,323 @@
+"""VGGTQwen3VLM on the HIP kernels - drop-in for the reference's src/models/vggt_qwen3_vlm.py:15-201.
+
+Same dataclass fields, constructor, attribute names (.tokenizer .text_model .vision_model .projector .geom_head
+.num_vis_tokens .geom_tokens), parameter names and `forward(images, geom_token, input_ids, attention_mask, labels)
+-> loss` contract, including the reference's quirks: only the first `num_vis_tokens` aggregator
+tokens are used, the visual span OVERWRITES the rows after <image>, encode_images runs without gradient, and a span
+that overruns the sequence raises RuntimeError.
+
+The loss returned by forward() is attached to autograd through one custom Function whose backward runs the
+hand-written HIP backward of the whole text model (+ geom_head), so `accelerator.backward(loss)` /
+`loss.backward()` in the reference trainer (train_sft.py:217) works unchanged.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import BF16, F32, round_up
+from .perceiver import PerceiverConfig, PerceiverProjector
+from .qwen3 import Qwen3Config, Qwen3ForCausalLM
+
+GEOM_FEATURE_DIM = 37  # R(9) + t(3) + K(9) + depth_hist(16)   (vggt_qwen3_vlm.py:51)
+
+
+@dataclass
+class VisionLanguageConfig:
+    text_model_name: str
+    vision_ckpt_dir: str
+    num_vis_tokens: int = 64
+    geom_tokens: int = 0
+    projector_cfg: Optional[PerceiverConfig] = None
+    freeze_vision: bool = True
+    dtype: str = "bfloat16"
+    # --- extensions (all optional; the reference's 7 fields above are unchanged) ---
+    text_config: Optional[Qwen3Config] = None    # random-init text model of this shape (no files, no network)
+    vision_config: Optional[dict] = None         # kwargs for vggt_qwen3_amd.vggt.VGGT (e.g. reduced depth in tests)
+    vision_module: Optional[nn.Module] = None    # inject any module exposing .aggregator(images) and .embed_dim
+    device: str = "cuda"
+    seed: int = 0
+
+
+class _StubTokenizer:
+    """Used only when text_model_name has no tokenizer files (synthetic benchmarks): knows `<image>`."""
+
+    def __init__(self, vocab_size: int):
+        self.vocab = {"<pad>": 0}
+        self._n = vocab_size
+        self.pad_token_id = 0
+
+    def get_vocab(self):
+        return dict(self.vocab)
+
+    def add_tokens(self, toks):
+        for t in toks:
+            self.vocab[t] = self._n
+            self._n += 1
+        return len(toks)
+
+    def convert_tokens_to_ids(self, t):
+        return self.vocab[t]
+
+    def __len__(self):
+        return self._n
+
+
+class _GeomLinear(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        lin = nn.Linear(fin, fout)  # default torch init, like the reference's nn.Sequential(nn.Linear, ...)
+        self.weight, self.bias = lin.weight, lin.bias
+
+
+class _TextLossFn(torch.autograd.Function):
+    """Connects the hand-written forward/backward to autograd: inputs are the trainable parameters (so their .grad
+    gets populated) and the geom features; output is the scalar loss."""
+
+    @staticmethod
+    def forward(ctx, model: "VGGTQwen3VLM", state: dict, geom_feats, *params):
+        ctx.model, ctx.state = model, state
+        ctx.has_geom = geom_feats is not None
+        return state["loss"].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, st = ctx.model, ctx.state
+        gscale = float(grad_out.item())
+        d_geom = model._backward_text(st, gscale, accumulate=False)
+        named = dict(model.text_model.named_parameters())
+        grads = []
+        for n in model._text_param_names:
+            grads.append(model.text_model.grad_views[n].clone() if n in model.text_model.grad_views else None)
+        return (None, None, d_geom if ctx.has_geom else None, *grads)
+
+
+class VGGTQwen3VLM(nn.Module):
+    def __init__(self, config: VisionLanguageConfig) -> None:
+        super().__init__()
+        dev = torch.device(config.device)
+        self.device_ = dev
+        # ---- text model + tokenizer (vggt_qwen3_vlm.py:31-42)
+        if config.text_config is not None:
+            self.text_model = Qwen3ForCausalLM(config.text_config, device=dev, seed=config.seed)
+            self.tokenizer = self._load_tokenizer(config.text_model_name, self.text_model.vocab)
+        else:
+            path = Path(config.text_model_name)
+            if not path.is_dir():
+                raise FileNotFoundError(
+                    f"text_model_name={config.text_model_name!r} is not a local directory; this build never fetches "
+                    "from the network. Pass a directory with config.json + *.safetensors, or text_config=...")
+            self.text_model = Qwen3ForCausalLM.from_pretrained_dir(path, device=dev)
+            self.tokenizer = self._load_tokenizer(config.text_model_name, self.text_model.vocab)
+        added = 0
+        if "<image>" not in self.tokenizer.get_vocab():
+            added = self.tokenizer.add_tokens(["<image>"])
+        if added:
+            self.text_model.resize_token_embeddings(len(self.tokenizer))
+        self.image_id = self.tokenizer.convert_tokens_to_ids("<image>")
+        # ---- vision tower (vggt_qwen3_vlm.py:43-45,60-111)
+        self.vision_model = self._load_vggt(config)
+        for p in self.vision_model.parameters():
+            p.requires_grad_(not config.freeze_vision)
+        # ---- projector + geom head (vggt_qwen3_vlm.py:46-56): fp32 parameters like the reference
+        H = self.text_model.config.hidden_size
+        g = torch.Generator().manual_seed(config.seed + 1)
+        with torch.random.fork_rng():
+            torch.manual_seed(config.seed + 1)
+            self.projector = PerceiverProjector(config.projector_cfg or PerceiverConfig(),
+                                                in_dim=self.vision_model.embed_dim, out_dim=H)
+            self.geom_head = nn.ModuleList([_GeomLinear(GEOM_FEATURE_DIM, H), nn.SiLU(), _GeomLinear(H, H)])
+        self.projector.to(dev)
+        self.geom_head.to(dev)
+        self.num_vis_tokens = config.num_vis_tokens
+        self.geom_tokens = config.geom_tokens
+        self._text_param_names = [n for n, _ in self.text_model.named_parameters()]
+
+    # ------------------------------------------------------------------ loaders
+    @staticmethod
+    def _load_tokenizer(name: str, vocab: int):
+        p = Path(name)
+        if p.is_dir() and any((p / f).exists() for f in ("tokenizer.json", "tokenizer_config.json", "vocab.json")):
+            from transformers import AutoTokenizer  # tokenizer only: host-side plumbing, local files only
+            return AutoTokenizer.from_pretrained(str(p), local_files_only=True)
+        return _StubTokenizer(vocab)
+
+    def _load_vggt(self, config: VisionLanguageConfig) -> nn.Module:
+        if config.vision_module is not None:
+            return config.vision_module
+        from .vggt import VGGT
+        kw = dict(img_size=518, patch_size=14, embed_dim=1024)
+        kw.update(config.vision_config or {})
+        model = VGGT(device=self.device_, seed=config.seed + 2, **kw)
+        ckpt = Path(config.vision_ckpt_dir) / "vggt_1B_commercial.pt"
+        if ckpt.exists():
+            sd = torch.load(ckpt, map_location="cpu")
+            if isinstance(sd, dict):
+                sd = sd.get("model", sd.get("state_dict", sd))
+            model.load_reference_state_dict(sd)
+        else:
+            print(f"Warning: checkpoint file {ckpt} not found, using random initialization")
+        model.eval()
+        model.embed_dim = 2 * model.aggregator.embed_dim  # frame|global concat (vggt_qwen3_vlm.py:107-109)
+        return model
+
+    # ------------------------------------------------------------------ encoders
+    @torch.no_grad()
+    def encode_images(self, images: torch.Tensor) -> torch.Tensor:
+        """images [B, V, C, H, W] -> [B, num_vis_tokens, hidden] (vggt_qwen3_vlm.py:128-162)."""
+        B, V = images.shape[:2]
+        toks, _ = self.vision_model.aggregator(images)
+        agg = toks[-1]
+        if agg.dim() == 3:
+            agg = agg[:, : self.num_vis_tokens, :]
+        elif agg.dim() == 4:
+            agg = agg.reshape(B, -1, agg.shape[-1])[:, : self.num_vis_tokens, :]
+        return self.projector(agg.contiguous())
+
+    def _geom_inputs(self, geom_token) -> Optional[torch.Tensor]:
+        if not geom_token or self.geom_tokens == 0:
+            return None
+        feats = torch.cat([geom_token["R"], geom_token["t"], geom_token["K"], geom_token["depth_hist"]], dim=-1)
+        return feats.to(self.device_, F32).mean(dim=1)  # [B, 37]: input plumbing (mean over views)
+
+    def _geom_fwd(self, feats: torch.Tensor, save: bool):
+        """geom_head (vggt_qwen3_vlm.py:51-56,164-177): Linear(37->H) - SiLU - Linear(H->H), then 8 identical tokens."""
+        B = feats.shape[0]
+        H = self.text_model.config.hidden_size
+        x = torch.zeros((B, 64), device=feats.device, dtype=BF16)
+        x[:, :GEOM_FEATURE_DIM] = feats.to(BF16)
+        w0 = torch.zeros((H, 64), device=feats.device, dtype=BF16)
+        w0[:, :GEOM_FEATURE_DIM] = ops.cast(self.geom_head[0].weight.detach().contiguous(), BF16)
+        w2 = ops.cast(self.geom_head[2].weight.detach().contiguous(), BF16)
+        z = ops.linear(x, w0, bias=self.geom_head[0].bias.detach(), out_dtype=F32)            # pre-activation
+        a = ops.linear(x, w0, bias=self.geom_head[0].bias.detach(), act=ops.ACT_SILU)         # bf16 SiLU(z)
+        y = ops.linear(a, w2, bias=self.geom_head[2].bias.detach(), out_dtype=F32)            # [B, H] fp32
+        ctx = dict(x=x, z=z, a=a, w2=w2) if save else None
+        return y, ctx
+
+    def encode_geom(self, geom_token: Optional[Dict[str, torch.Tensor]]) -> Optional[torch.Tensor]:
+        feats = self._geom_inputs(geom_token)
+        if feats is None:
+            return None
+        y, _ = self._geom_fwd(feats, False)
+        return y.unsqueeze(1).expand(-1, self.geom_tokens, -1)
+
+    # ------------------------------------------------------------------ splice (integer work, host side)
+    def _srcmap(self, input_ids: torch.Tensor, S: int) -> torch.Tensor:
+        """Integer image of `for b, pos in nonzero(ids == image_id): emb[b, pos:pos+S] = features[b]`
+        (vggt_qwen3_vlm.py:191-195), last writer wins; raises like the reference when a span overruns."""
+        B, L = input_ids.shape
+        pos = (input_ids == self.image_id).nonzero(as_tuple=False).tolist()
+        m = torch.full((B, L), -1, dtype=torch.int32)
+        for b, p in pos:
+            if p + S > L:
+                raise RuntimeError(f"The expanded size of the tensor ({L - p}) must match the existing size ({S}) at "
+                                   f"non-singleton dimension 0 (visual span at position {p} overruns L={L})")
+            m[b, p:p + S] = torch.arange(S, dtype=torch.int32)
+        return m.to(input_ids.device)
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward_state(self, images, geom_token, input_ids, attention_mask, labels, need_grad: bool) -> dict:
+        """Runs the whole path on the HIP kernels and returns a state dict with `loss` (+ what backward needs)."""
+        tm = self.text_model
+        H = tm.config.hidden_size
+        input_ids = input_ids.to(self.device_)
+        attention_mask = attention_mask.to(self.device_)
+        labels = labels.to(self.device_)
+        B, L = input_ids.shape
+        vis = self.encode_images(images.to(self.device_))                                     # [B, Nv, H] fp32
+        gfeat = self._geom_inputs(geom_token)
+        geom_ctx, gy = None, None
+        if gfeat is not None:
+            gy, geom_ctx = self._geom_fwd(gfeat, need_grad)
+            feats = torch.cat([gy.unsqueeze(1).expand(-1, self.geom_tokens, -1), vis], dim=1)
+        else:
+            feats = vis
+        S = feats.shape[1]
+        feats16 = ops.cast(feats.contiguous(), BF16)
+        srcmap = self._srcmap(input_ids, S)
+        emb = ops.embed_splice_fwd(input_ids.contiguous(), tm._w["embed"], feats16, srcmap, B, L, H, S)
+        h_last, saved = tm.forward_hidden(emb, attention_mask, save=need_grad)
+        loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad)
+        return dict(loss=loss, saved=saved, head=head_ctx, srcmap=srcmap, input_ids=input_ids, B=B, L=L, S=S,
+                    geom_ctx=geom_ctx, geom_y=gy, emb=emb, h_last=h_last)
+
+    def _backward_text(self, st: dict, gscale: float, accumulate: bool, layer_done=None):
+        """Backward of everything that has gradients in the reference: Qwen3 (all parameters, tied embedding) and,
+        when geometry tokens are present, geom_head. Returns d(loss)/d(geom_head output) or None."""
+        tm = self.text_model
+        H = tm.config.hidden_size
+        B, L, S = st["B"], st["L"], st["S"]
+        if st["head"] is None:
+            return None
+        dh = tm.backward_loss_head(st["head"], B * L, gscale, accumulate)
+        d_emb = tm.backward_hidden(st["saved"], dh, accumulate, layer_done=layer_done)
+        ids = st["input_ids"].reshape(-1)
+        sorted_ids, order = torch.sort(ids, stable=True)
+        dfeat = None
+        if st["geom_ctx"] is not None:
+            dfeat = torch.zeros((B, S, H), device=d_emb.device, dtype=F32)
+        ops.embed_splice_bwd(sorted_ids, order, st["srcmap"], d_emb, tm._g["embed"], dfeat, B, L, H, S)
+        if dfeat is None:
+            return None
+        return dfeat[:, : self.geom_tokens].sum(dim=1)  # the 8 geom tokens are one expanded vector
+
+    def geom_head_backward(self, st: dict, d_y: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Gradients of geom_head's four tensors given d(loss)/d(output) [B, H] fp32 (tiny: M = batch size)."""
+        g = st["geom_ctx"]
+        x, z, a, w2 = g["x"], g["z"], g["a"], g["w2"]
+        B, H = d_y.shape
+        dev = d_y.device
+        dy16 = ops.cast(d_y.contiguous(), BF16)
+        dyt, at_, xt = ops.transpose2d(dy16, 64), ops.transpose2d(a, 64), ops.transpose2d(x, 64)
+        ones = torch.zeros((8, 64), device=dev, dtype=BF16)
+        ones[0, :B] = 1.0                                     # row 0 sums over the batch inside the GEMM
+        # layer 2: dW2 = dy^T a ; db2 = sum_b dy ; da = dy W2
+        dW2 = torch.empty((H, H), device=dev, dtype=F32)
+        ops.gemm_raw(dyt, at_, dW2, H, H, 64, 64, 64, H)
+        db2 = torch.empty((8, H), device=dev, dtype=F32)
+        ops.gemm_raw(ones, dyt, db2, 8, H, 64, 64, 64, H)
+        da = ops.linear(dy16, ops.transpose2d(w2, 64))         # [B, H] bf16
+        # SiLU backward through the SwiGLU kernel with up == 1: dgate = da * silu'(z)
+        gu = torch.ones((B, 2 * H), device=dev, dtype=BF16)
+        gu[:, :H] = ops.cast(z, BF16)
+        dz16 = ops.silu_mul_bwd(da, gu)[:, :H].contiguous()
+        dzt = ops.transpose2d(dz16, 64)
+        dW0 = torch.empty((H, 64), device=dev, dtype=F32)
+        ops.gemm_raw(dzt, xt, dW0, H, 64, 64, 64, 64, 64)
+        db0 = torch.empty((8, H), device=dev, dtype=F32)
+        ops.gemm_raw(ones, dzt, db0, 8, H, 64, 64, 64, H)
+        return {"0.weight": dW0[:, :GEOM_FEATURE_DIM].contiguous(), "0.bias": db0[0].contiguous(), "2.weight": dW2,
+                "2.bias": db2[0].contiguous()}
+
+    def forward(self, images, geom_token, input_ids, attention_mask, labels) -> torch.Tensor:
+        need_grad = torch.is_grad_enabled() and self.training
+        st = self.forward_state(images, geom_token, input_ids, attention_mask, labels, need_grad)
+        if not need_grad:
+            return st["loss"]
+        self._last_state = st
+        params = [p for _, p in self.text_model.named_parameters()]
+        geom_in = None
+        if st["geom_ctx"] is not None:
+            geom_in = _GeomBridge.apply(self, st, *[self.geom_head[0].weight, self.geom_head[0].bias,
+                                                    self.geom_head[2].weight, self.geom_head[2].bias])
+        return _TextLossFn.apply(self, st, geom_in, *params)
+
+
+class _GeomBridge(torch.autograd.Function):
+    """Carries d(loss)/d(geom features) back into geom_head's fp32 parameters."""
+
+    @staticmethod
+    def forward(ctx, model, st, *params):
+        ctx.model, ctx.st = model, st
+        return st["geom_y"].detach().clone()
+
+    @staticmethod
+    def backward(ctx, d_y):
+        g = ctx.model.geom_head_backward(ctx.st, d_y)
+        return (None, None, g["0.weight"], g["0.bias"], g["2.weight"], g["2.bias"])
