@@ -148,6 +148,28 @@ int vq3_cross_entropy_fwd_bwd(void* logits, const int32_t* targets, float* loss_
                               int32_t ldl, float gscale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * VGGT aggregator (un-vendored `vggt` package: vggt.models.aggregator.Aggregator, vggt.layers.{block,attention,rope,
+ * vision_transformer}); call site in the reference: src/models/vggt_qwen3_vlm.py:144
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Patch extraction for the 14x14/stride-14 patch-embed conv, fused with the aggregator's ImageNet normalisation:
+ * images f32 [NI,3,H,W] in [0,1] -> patches bf16 [NI*(H/p)*(W/p), Kp], k = c*p*p + ky*p + kx, columns >= 3*p*p zeroed
+ * (Kp % 64 == 0 so the result feeds vq3_gemm_bf16_nt). mean/std are 3 host floats each. */
+int vq3_im2col_norm(const float* images, void* patches, int32_t NI, int32_t H, int32_t W, int32_t p, int32_t Kp,
+                    const float* mean3_host, const float* std3_host, void* stream);
+/* Attention.forward prologue (vggt/layers/attention.py): qkv bf16 [T, 3*NH*64] -> Q,K,V bf16 [T/N, NH, N, 64];
+ * optional per-head LayerNorm on q,k (f32 weight/bias [64]) and 2-D RoPE (vggt/layers/rope.py; cos/sin bf16
+ * [maxpos+1, 32]); token n of a group sits in frame position n % tokens_per_frame; the first patch_start tokens of a
+ * frame are special tokens at position 0, patch p at (p / Wp + 1, p % Wp + 1). */
+int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b,
+                   const void* cos, const void* sin, void* Q, void* K, void* V, int64_t T, int32_t N, int32_t NH,
+                   int32_t head_dim, int32_t tokens_per_frame, int32_t patch_start, int32_t Wp, int32_t use_norm,
+                   int32_t use_rope, float eps, void* stream);
+/* F.scaled_dot_product_attention(q, k, v), non-causal, head_dim 64: Q,K bf16 [G*NH, N, 64], Vt bf16 [G*NH, 64, Np]
+ * (V transposed, zero padded, Np % 64 == 0) -> O bf16 token-major O[(g*N + n)*ldo + h*64 + d]. */
+int vq3_flash_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int32_t G, int32_t NH, int32_t N,
+                       int32_t Np, int32_t head_dim, int64_t ldo, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Optimiser (src/train/train_sft.py:147-156 torch.optim.AdamW; DeepSpeed bf16 keeps f32 master weights)
  * ---------------------------------------------------------------------------------------------------------- */
 /* master/m/v f32, grad bf16, w_bf16 (compute copy) updated in place. step >= 1. grad is scaled by gscale first. */

@@ -1,0 +1,287 @@
+// VGGT aggregator kernels (multi-view ViT): patch im2col with fused ImageNet normalisation, per-head q/k
+// LayerNorm + 2-D RoPE + head split, and a flash-style attention forward (head_dim 64, non-causal) with LDS-staged,
+// XOR-swizzled K / V^T tiles and v_mfma_f32_32x32x16_bf16 chains kept in registers:
+//   S^T = K . Q^T        (A = K tile rows, B = Q fragment held in VGPRs for the whole kernel)
+//   O^T += V^T . P^T     (the S^T accumulator, exponentiated and packed to bf16, IS the B operand: no LDS round trip)
+// so every softmax statistic of a query row lives on the lane that owns that query column.
+#include "common.h"
+#include "vq3_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ im2col
+// images f32 [NI, 3, H, W] in [0,1]; out bf16 [NI*Hp*Wp, Kp], k = c*p*p + ky*p + kx, columns >= 3*p*p zero.
+// The reference casts images to bf16 first and normalises in bf16 (two rounded ops).
+__global__ __launch_bounds__(256) void im2col_norm_kernel(const float* __restrict__ img, bf16_t* __restrict__ out,
+                                                          int H, int W, int p, int Hp, int Wp, int Kp, float m0,
+                                                          float m1, float m2, float s0, float s1, float s2) {
+  const long patch = blockIdx.x;  // ni*Hp*Wp + py*Wp + px
+  const int px = (int)(patch % Wp), py = (int)((patch / Wp) % Hp);
+  const long ni = patch / ((long)Wp * Hp);
+  const int K = 3 * p * p;
+  bf16_t* o = out + patch * (long)Kp;
+  for (int k = threadIdx.x; k < Kp; k += 256) {
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / (p * p), r = k - c * p * p, ky = r / p, kx = r - ky * p;
+      const float x = rbf(img[((ni * 3 + c) * H + (py * p + ky)) * (long)W + (px * p + kx)]);
+      const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+      const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+      v = rbf(rbf(x - rbf(mean)) / rbf(sd));
+    }
+    o[k] = f2bf(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ q/k prep
+// qkv bf16 [T, 3*C] (columns: q heads | k heads | v heads, head-major) -> Q,K,V bf16 [G, NH, N, 64], T = G*N.
+// Optional LayerNorm over the 64 head features (qk_norm) and 2-D RoPE: the first 32 features rotate with the
+// patch row (y), the last 32 with the patch column (x), rotate-half inside each 32-block; tokens < patch_start of a
+// frame sit at position 0 (identity). cos/sin tables bf16 [maxpos+1, 32].
+__global__ __launch_bounds__(256) void vit_qkprep_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ qn_w,
+                                                         const float* __restrict__ qn_b, const float* __restrict__ kn_w,
+                                                         const float* __restrict__ kn_b, const bf16_t* __restrict__ cs,
+                                                         const bf16_t* __restrict__ sn, bf16_t* __restrict__ Q,
+                                                         bf16_t* __restrict__ K, bf16_t* __restrict__ V, int N, int NH,
+                                                         int P, int patch_start, int Wp, int use_norm, int use_rope,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long t = blockIdx.x;
+  const long g = t / N;
+  const int n = (int)(t - g * N);
+  const int C = NH * 64;
+  const bf16_t* row = qkv + t * 3L * C;
+  int py = 0, px = 0;
+  if (use_rope) {
+    const int tp = n % P;
+    if (tp >= patch_start) {
+      py = (tp - patch_start) / Wp + 1;
+      px = (tp - patch_start) % Wp + 1;
+    }
+  }
+  const int pos = lane < 32 ? py : px;
+  const int f = lane & 31;
+  float c = 1.f, s = 0.f;
+  if (use_rope) {
+    c = bf2f(cs[pos * 32 + f]);
+    s = bf2f(sn[pos * 32 + f]);
+  }
+  for (int hh = wid; hh < 3 * NH; hh += 4) {
+    const int which = hh / NH, h = hh - which * NH;
+    float x = bf2f(row[which * C + h * 64 + lane]);
+    bf16_t* dst = (which == 0 ? Q : (which == 1 ? K : V)) + ((g * NH + h) * (long)N + n) * 64;
+    if (which < 2) {
+      if (use_norm) {
+        const float mean = wave_sum(x) * (1.f / 64.f);
+        const float d = x - mean;
+        const float rs = rsqrtf(wave_sum(d * d) * (1.f / 64.f) + eps);
+        const float* w = which == 0 ? qn_w : kn_w;
+        const float* b = which == 0 ? qn_b : kn_b;
+        x = rbf(d * rs * w[lane] + b[lane]);
+      }
+      if (use_rope) {
+        const float partner = __shfl_xor(x, 16, 64);
+        const float rot = (f < 16) ? -partner : partner;
+        x = rbf(rbf(x * c) + rbf(rot * s));
+      }
+    }
+    dst[lane] = f2bf(x);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ flash attention
+// Q,K bf16 [NB, N, 64]; Vt bf16 [NB, 64, Np] (V transposed, zero-padded to Np % 64 == 0); O bf16 token-major:
+// O[(g*N + q) * ldo + h*64 + d] with NB = G*NH, g = nb / NH, h = nb % NH.
+// Block = 4 waves x 32 query rows; KV tile = 64 keys. LDS: K tile [64][64] and V^T tile [64][64], 16-byte chunks
+// XOR-swizzled with (row >> 1) & 7 so the fragment reads (lane = row) are conflict-free / 2-way.
+constexpr int FA_Q = 128, FA_KV = 64;
+
+__device__ __forceinline__ int fa_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                              const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
+                                                              int N, int Np, int NH, long ldo, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * FA_KV * 128];
+  char* Ks = smem;
+  char* Vs = smem + FA_KV * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const long nb = blockIdx.y;
+  const int q0 = blockIdx.x * FA_Q + wid * 32;
+  const bf16_t* Qb = Q + nb * (long)N * 64;
+  const bf16_t* Kb = K + nb * (long)N * 64;
+  const bf16_t* Vb = Vt + nb * 64L * Np;
+
+  // Q fragments: B operand, lane (r,h) holds Q[q0+r][16s + 8h .. +8]
+  bf16x8 qf[4];
+  {
+    int qr = q0 + r;
+    qr = qr < N ? qr : N - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 16 * s + 8 * h);
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging: 512 16-byte chunks per tile, 2 per thread: chunk id c = tid + 256*i -> row c>>3, chunk c&7
+  const int srow0 = tid >> 3, sch = tid & 7;
+  const int nt = (N + FA_KV - 1) / FA_KV;
+  u32x4 kreg[2], vreg[2];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = srow0 + 32 * i;
+      int kr = t * FA_KV + row;
+      kr = kr < N ? kr : N - 1;
+      kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (long)kr * 64 + sch * 8);
+      vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (long)row * Np + t * FA_KV + sch * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = srow0 + 32 * i;
+      *reinterpret_cast<u32x4*>(Ks + fa_swz(row, sch)) = kreg[i];
+      *reinterpret_cast<u32x4*>(Vs + fa_swz(row, sch)) = vreg[i];
+    }
+  };
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const bool more = t + 1 < nt;
+    if (more) load_tile(t + 1);
+    // ---- S^T = K . Q^T for the two 32-key sub-tiles
+    f32x16 s0, s1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Ks + fa_swz(r, 2 * s + h));
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Ks + fa_swz(32 + r, 2 * s + h));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+    }
+    // ---- online softmax (per query column = per lane pair (lane, lane^32))
+    const int kbase = t * FA_KV;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key0 = kbase + (i & 3) + 8 * (i >> 2) + 4 * h;
+      s0[i] = (key0 < N) ? s0[i] * scale_log2e : -INFINITY;
+      s1[i] = (key0 + 32 < N) ? s1[i] * scale_log2e : -INFINITY;
+      mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s0[i] = exp2f(s0[i] - m_new);
+      s1[i] = exp2f(s1[i] - m_new);
+      ps += s0[i] + s1[i];
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+    // ---- O^T += V^T . P^T : B operand = packed S^T registers 8s'..8s'+7 (k order: 16s' + 8(j>>2) + 4h + (j&3))
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(sub == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
+        // A operand = V^T fragment: lane (d = r [+32], h), element j <-> key 32*sub + 16*sp + 8*(j>>2) + 4h + (j&3)
+        const int kb = 32 * sub + 16 * sp + 4 * h;  // first run of 4 keys; second run at +8
+        bf16x8 va, vb;
+        {
+          const u32x2 a0 = *reinterpret_cast<const u32x2*>(Vs + fa_swz(r, kb >> 3) + ((kb & 7) << 1));
+          const u32x2 a1 = *reinterpret_cast<const u32x2*>(Vs + fa_swz(r, (kb + 8) >> 3) + ((kb & 7) << 1));
+          const u32x2 b0 = *reinterpret_cast<const u32x2*>(Vs + fa_swz(32 + r, kb >> 3) + ((kb & 7) << 1));
+          const u32x2 b1 = *reinterpret_cast<const u32x2*>(Vs + fa_swz(32 + r, (kb + 8) >> 3) + ((kb & 7) << 1));
+          u32x4 ta = {a0[0], a0[1], a1[0], a1[1]};
+          u32x4 tb = {b0[0], b0[1], b1[0], b1[1]};
+          va = __builtin_bit_cast(bf16x8, ta);
+          vb = __builtin_bit_cast(bf16x8, tb);
+        }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf, o1, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) store_tile();
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns query q0+r, d = 32*db + (i&3) + 8*(i>>2) + 4h
+  const int q = q0 + r;
+  if (q < N) {
+    const float inv = 1.f / l_run;
+    const long g = nb / NH;
+    const int hd = (int)(nb % NH);
+    bf16_t* orow = O + (g * N + q) * ldo + hd * 64;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int d = 8 * i4 + 4 * h;
+      u32x2 w0, w1;
+      w0[0] = pack2bf(o0[4 * i4 + 0] * inv, o0[4 * i4 + 1] * inv);
+      w0[1] = pack2bf(o0[4 * i4 + 2] * inv, o0[4 * i4 + 3] * inv);
+      w1[0] = pack2bf(o1[4 * i4 + 0] * inv, o1[4 * i4 + 1] * inv);
+      w1[1] = pack2bf(o1[4 * i4 + 2] * inv, o1[4 * i4 + 3] * inv);
+      *reinterpret_cast<u32x2*>(orow + d) = w0;
+      *reinterpret_cast<u32x2*>(orow + 32 + d) = w1;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vq3_im2col_norm(const float* images, void* patches, int32_t NI, int32_t H, int32_t W, int32_t p,
+                               int32_t Kp, const float* mean3_host, const float* std3_host, void* stream) {
+  VQ3_CHECK_ARG(images && patches && mean3_host && std3_host, "im2col_norm: null pointer");
+  VQ3_CHECK_ARG(NI > 0 && p > 0 && H % p == 0 && W % p == 0 && Kp >= 3 * p * p, "im2col_norm: bad shape");
+  const int Hp = H / p, Wp = W / p;
+  hipLaunchKernelGGL(im2col_norm_kernel, dim3((unsigned)((long)NI * Hp * Wp)), dim3(256), 0, (hipStream_t)stream, images,
+                     (bf16_t*)patches, H, W, p, Hp, Wp, Kp, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0],
+                     std3_host[1], std3_host[2]);
+  VQ3_CHECK_LAUNCH("im2col_norm");
+  return 0;
+}
+
+extern "C" int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* qn_b, const float* kn_w,
+                              const float* kn_b, const void* cos, const void* sin, void* Q, void* K, void* V, int64_t T,
+                              int32_t N, int32_t NH, int32_t head_dim, int32_t tokens_per_frame, int32_t patch_start,
+                              int32_t Wp, int32_t use_norm, int32_t use_rope, float eps, void* stream) {
+  VQ3_CHECK_ARG(qkv && Q && K && V, "vit_qkprep: null pointer");
+  VQ3_CHECK_ARG(head_dim == 64, "vit_qkprep: head_dim must be 64, got %d", head_dim);
+  VQ3_CHECK_ARG(T > 0 && N > 0 && T % N == 0 && NH > 0, "vit_qkprep: bad shape");
+  VQ3_CHECK_ARG(!use_norm || (qn_w && qn_b && kn_w && kn_b), "vit_qkprep: norm weights missing");
+  VQ3_CHECK_ARG(!use_rope || (cos && sin && tokens_per_frame > 0 && Wp > 0), "vit_qkprep: rope tables missing");
+  hipLaunchKernelGGL(vit_qkprep_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, qn_w,
+                     qn_b, kn_w, kn_b, (const bf16_t*)cos, (const bf16_t*)sin, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V, N, NH,
+                     tokens_per_frame, patch_start, Wp, use_norm, use_rope, eps);
+  VQ3_CHECK_LAUNCH("vit_qkprep");
+  return 0;
+}
+
+extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int32_t G, int32_t NH,
+                                  int32_t N, int32_t Np, int32_t head_dim, int64_t ldo, float scale, void* stream) {
+  VQ3_CHECK_ARG(Q && K && Vt && O, "flash_attn_fwd: null pointer");
+  VQ3_CHECK_ARG(head_dim == 64, "flash_attn_fwd: head_dim must be 64, got %d", head_dim);
+  VQ3_CHECK_ARG(G > 0 && NH > 0 && N > 0 && Np >= N && Np % 64 == 0, "flash_attn_fwd: bad shape (Np %% 64)");
+  VQ3_CHECK_ARG((long)G * NH <= 65535, "flash_attn_fwd: too many (group, head) pairs");
+  VQ3_CHECK_ARG(ldo >= (long)NH * 64 && ldo % 4 == 0, "flash_attn_fwd: bad ldo");
+  dim3 grid((N + FA_Q - 1) / FA_Q, G * NH);
+  hipLaunchKernelGGL(flash_attn_hd64_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
+                     (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, N, Np, NH, (long)ldo,
+                     scale * 1.44269504088896340736f);
+  VQ3_CHECK_LAUNCH("flash_attn_fwd");
+  return 0;
+}

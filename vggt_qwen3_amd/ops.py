@@ -282,3 +282,53 @@ def adamw_step(master, m, v, grad, w, lr, beta1, beta2, eps, wd, step, gscale=1.
     assert m.numel() == n and v.numel() == n and grad.numel() == n and w.numel() == n
     check(_lib.load().vq3_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), w.data_ptr(), n,
                                      lr, beta1, beta2, eps, wd, step, gscale, _stream()), "vq3_adamw_step")
+
+
+# ----------------------------------------------------------------------------------------------- VGGT
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def im2col_norm(images: torch.Tensor, p: int, Kp: int) -> torch.Tensor:
+    """images f32 [NI,3,H,W] -> bf16 [NI*(H/p)*(W/p), Kp] normalised patches."""
+    import ctypes as C
+    _req(images, F32, "im2col images"); assert images.is_contiguous() and images.dim() == 4 and images.shape[1] == 3
+    NI, _, H, W = images.shape
+    out = torch.empty((NI * (H // p) * (W // p), Kp), device=images.device, dtype=BF16)
+    mean = (C.c_float * 3)(*IMAGENET_MEAN); std = (C.c_float * 3)(*IMAGENET_STD)
+    check(_lib.load().vq3_im2col_norm(images.data_ptr(), out.data_ptr(), NI, H, W, p, Kp, mean, std, _stream()),
+          "vq3_im2col_norm")
+    return out
+
+
+def vit_qkprep(qkv, N, NH, *, qn=None, kn=None, cos=None, sin=None, tokens_per_frame=0, patch_start=0, Wp=0,
+               eps=1e-5):
+    """qkv bf16 [T, 3*NH*64] -> Q, K, V bf16 [T/N, NH, N, 64]."""
+    _req(qkv, BF16, "vit_qkprep qkv"); assert qkv.is_contiguous()
+    T = qkv.shape[0]
+    G = T // N
+    dev = qkv.device
+    Q = torch.empty((G, NH, N, 64), device=dev, dtype=BF16)
+    K = torch.empty_like(Q); V = torch.empty_like(Q)
+    use_norm = qn is not None
+    use_rope = cos is not None
+    check(_lib.load().vq3_vit_qkprep(qkv.data_ptr(), _p(qn[0]) if use_norm else None, _p(qn[1]) if use_norm else None,
+                                     _p(kn[0]) if use_norm else None, _p(kn[1]) if use_norm else None, _p(cos), _p(sin),
+                                     Q.data_ptr(), K.data_ptr(), V.data_ptr(), T, N, NH, 64, tokens_per_frame,
+                                     patch_start, Wp, 1 if use_norm else 0, 1 if use_rope else 0, eps, _stream()),
+          "vq3_vit_qkprep")
+    return Q, K, V
+
+
+def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(Q K^T / 8) V for Q,K,V bf16 [G, NH, N, 64] -> token-major [G*N, NH*64]."""
+    _req(Q, BF16, "flash Q"); assert Q.is_contiguous() and K.is_contiguous() and V.is_contiguous()
+    G, NH, N, D = Q.shape
+    Np = round_up(N, 64)
+    Vt = torch.empty((G, NH, D, Np), device=Q.device, dtype=BF16)
+    transpose_raw(V, Vt, N, D, Np, D, Np, n=(1, 1, G * NH), s=(0, 0, N * D), d=(0, 0, D * Np))
+    if out is None:
+        out = torch.empty((G * N, NH * D), device=Q.device, dtype=BF16)
+    check(_lib.load().vq3_flash_attn_fwd(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), G, NH, N, Np, D,
+                                         out.stride(0), D ** -0.5, _stream()), "vq3_flash_attn_fwd")
+    return out
