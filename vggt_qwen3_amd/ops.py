@@ -14,6 +14,10 @@ F32 = torch.float32
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 
+# When set to a list, every GEMM launch is bracketed by HIP events on the launch stream and
+# (algorithmic FLOPs, start, end) is appended: bench.py's live roofline measurement.
+GEMM_PROFILE = None
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -58,6 +62,13 @@ def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, 
     d.nb1, d.nb2, d.b2divB = nb1, nb2, b2divB
     d.act = act; d.out_f32 = 1 if C.dtype == F32 else 0; d.accumulate = 1 if accumulate else 0
     d.alpha = alpha
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")
+        e1.record()
+        GEMM_PROFILE.append((2.0 * M * N * K * nb1 * nb2, e0, e1))
+        return
     check(_lib.load().vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")
 
 

@@ -1,0 +1,141 @@
+"""Data-parallel Stage-1 step around VGGTQwen3VLM: the MI355X-native replacement for the reference's
+Accelerate/DeepSpeed loop body (src/train/train_sft.py:138-163 optimiser + schedule, :208-220 step).
+
+One process per GPU. Every rank holds the full model (288 GB HBM3E: bf16 weights + bf16 grads + transposed copies +
+fp32 master/Adam state of the 4 B trainable parameters is ~72 GB, so nothing is sharded - no ZeRO). The only exchange
+is a SUM all-reduce of the flat bf16 gradient buffer over RCCL/xGMI, issued bucket by bucket from inside the
+hand-written backward (layers 35 -> 0) on a side stream so it overlaps the remaining backward; the 1/world factor is
+folded into the fused AdamW kernel. Semantics kept from the reference: two LR groups selected by parameter NAME
+("projector"/"geom_head" -> proj_lr, else lr), AdamW(weight_decay) on every parameter, cosine schedule with warm-up
+stepped once per optimiser step, loss/grad_accum scaling, and `max_steps` counting micro-batches."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .ops import BF16, F32
+from .vlm import VGGTQwen3VLM
+
+
+def cosine_with_warmup(step: int, warmup: int, total: int) -> float:
+    """transformers.get_cosine_schedule_with_warmup multiplier (num_cycles = 0.5)."""
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    progress = float(step - warmup) / float(max(1, total - warmup))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+
+
+class Stage1Trainer:
+    def __init__(self, model: VGGTQwen3VLM, *, lr=5e-6, proj_lr=1e-4, weight_decay=0.1, warmup_ratio=0.03,
+                 max_steps=30000, grad_accum=32, betas=(0.9, 0.999), eps=1e-8, bucket_layers: int = 4,
+                 process_group=None):
+        self.model = model
+        self.tm = model.text_model
+        self.lr, self.proj_lr, self.wd = lr, proj_lr, weight_decay
+        self.betas, self.eps = betas, eps
+        self.grad_accum = grad_accum
+        self.max_steps = max_steps
+        self.warmup = int(warmup_ratio * max_steps)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.micro = 0       # micro-batches seen (the reference's `step`)
+        self.opt_step = 0    # optimiser / scheduler steps
+        dev = self.tm.flat_w.device
+        n = self.tm.flat_w.numel()
+        # fp32 master weights + Adam moments for the text model (flat) and geom_head (small, flat)
+        self.master = ops.cast(self.tm.flat_w, F32)
+        self.m = torch.zeros(n, device=dev, dtype=F32)
+        self.v = torch.zeros(n, device=dev, dtype=F32)
+        self.geom_params = [p for _, p in model.geom_head.named_parameters()]
+        gn = sum(p.numel() for p in self.geom_params)
+        self.geom_master = torch.cat([p.detach().reshape(-1).float() for p in self.geom_params]).contiguous()
+        self.geom_m = torch.zeros(gn, device=dev, dtype=F32)
+        self.geom_v = torch.zeros(gn, device=dev, dtype=F32)
+        self.geom_grad = torch.zeros(gn, device=dev, dtype=F32)
+        self.geom_w16 = torch.zeros(gn, device=dev, dtype=BF16)
+        self._geom_has_grad = False
+        # all-reduce buckets over flat_g: groups of `bucket_layers` layers (contiguous), norm with the last group,
+        # the tied embedding last (its gradient is completed by the embedding backward at the very end)
+        self.buckets: Dict[int, tuple] = {}
+        L = self.tm.config.num_hidden_layers
+        tab = self.tm.table
+        def span(first, last_name):
+            o0 = tab[first][0]
+            o1, s1 = tab[last_name]
+            return o0, ops.round_up(o1 + math.prod(s1), 64)
+        for g0 in range(0, L, bucket_layers):
+            g1 = min(L, g0 + bucket_layers) - 1
+            last = "norm" if g1 == L - 1 else f"l{g1}.kn"
+            self.buckets[g0] = span(f"l{g0}.qkv", last)
+        self.embed_span = span("embed", "embed")
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self._works: List = []
+
+    # ------------------------------------------------------------------ communication
+    def _allreduce_span(self, lo: int, hi: int):
+        if self.world == 1:
+            return
+        buf = self.tm.flat_g[lo:hi]
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _layer_done(self, i: int):
+        if i in self.buckets:
+            self._allreduce_span(*self.buckets[i])
+
+    # ------------------------------------------------------------------ one micro-batch
+    def micro_step(self, batch: dict) -> torch.Tensor:
+        """forward + backward (+ gradient all-reduce, AdamW, schedule on accumulation boundaries). Returns the loss."""
+        model, tm = self.model, self.tm
+        k = self.micro % self.grad_accum
+        boundary = (k == self.grad_accum - 1)
+        accumulate = k != 0
+        st = model.forward_state(batch["pixel_values"], batch.get("geom_token"), batch["input_ids"],
+                                 batch["attention_mask"], batch["labels"], need_grad=True)
+        hook = self._layer_done if (boundary and self.world > 1) else None
+        d_geom = model._backward_text(st, 1.0 / self.grad_accum, accumulate, layer_done=hook)
+        if d_geom is not None:
+            g = model.geom_head_backward(st, d_geom)
+            flat = torch.cat([g["0.weight"].reshape(-1), g["0.bias"].reshape(-1), g["2.weight"].reshape(-1),
+                              g["2.bias"].reshape(-1)])
+            if accumulate and self._geom_has_grad:
+                self.geom_grad += flat
+            else:
+                self.geom_grad.copy_(flat)
+            self._geom_has_grad = True
+        if boundary:
+            self._optimizer_step()
+        self.micro += 1
+        return st["loss"]
+
+    def _optimizer_step(self):
+        tm = self.tm
+        if self.world > 1:
+            self._allreduce_span(*self.embed_span)
+            if self._geom_has_grad:
+                dist.all_reduce(self.geom_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.opt_step += 1
+        mult = cosine_with_warmup(self.opt_step - 1, self.warmup, self.max_steps)
+        gscale = 1.0 / self.world
+        ops.adamw_step(self.master, self.m, self.v, tm.flat_g, tm.flat_w, self.lr * mult, self.betas[0], self.betas[1],
+                       self.eps, self.wd, self.opt_step, gscale)
+        tm.refresh_transposed()
+        if self._geom_has_grad:
+            ops.adamw_step(self.geom_master, self.geom_m, self.geom_v, ops.cast(self.geom_grad, BF16), self.geom_w16,
+                           self.proj_lr * mult, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step, gscale)
+            off = 0
+            with torch.no_grad():
+                for p in self.geom_params:
+                    p.copy_(self.geom_master[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+            self._geom_has_grad = False
+
+    def lrs(self):
+        mult = cosine_with_warmup(max(0, self.opt_step - 1), self.warmup, self.max_steps)
+        return self.lr * mult, self.proj_lr * mult
