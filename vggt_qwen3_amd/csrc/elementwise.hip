@@ -60,24 +60,52 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------- transpose (64x64 tiles through LDS)
+// 16-byte global loads and stores on both sides when the leading dimensions allow (vec != 0), scalar at the edges.
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R,
                                                         int C, int Rpad, long lds_, long ldd, int n1, int n2, long s0,
-                                                        long s1, long s2, long d0, long d1, long d2) {
-  __shared__ bf16_t tile[64][66];
+                                                        long s1, long s2, long d0, long d1, long d2, int vec) {
+  __shared__ bf16_t tile[64][72];
   const int bz = blockIdx.z;
   const int i2 = bz % n2, i1 = (bz / n2) % n1, i0 = bz / (n2 * n1);
   src += i0 * s0 + i1 * s1 + i2 * s2;
   dst += i0 * d0 + i1 * d1 + i2 * d2;
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int rr = ty; rr < 64; rr += 4) {
-    const int r = r0 + rr, c = c0 + tx;
-    tile[rr][tx] = (r < R && c < C) ? src[(long)r * lds_ + c] : (bf16_t)0;
+  // load: 64 rows x 8 chunks of 8 elements; thread -> (row = id>>3, chunk = id&7), two passes
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int id = threadIdx.x + pass * 256;
+    const int rr = id >> 3, ch = id & 7;
+    const int r = r0 + rr, c = c0 + ch * 8;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < R) {
+      if (vec && c + 8 <= C) {
+        v = *reinterpret_cast<const bf16x8*>(src + (long)r * lds_ + c);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (c + j < C) v[j] = (short)src[(long)r * lds_ + c + j];
+      }
+    }
+    *reinterpret_cast<bf16x8*>(&tile[rr][ch * 8]) = v;
   }
   __syncthreads();
-  for (int cc = ty; cc < 64; cc += 4) {
-    const int c = c0 + cc, r = r0 + tx;
-    if (c < C && r < Rpad) dst[(long)c * ldd + r] = tile[tx][cc];
+  // store: dst row = c (64 of them), 8 chunks of 8 consecutive r
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int id = threadIdx.x + pass * 256;
+    const int cc = id >> 3, ch = id & 7;
+    const int c = c0 + cc, r = r0 + ch * 8;
+    if (c >= C || r >= Rpad) continue;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (short)tile[ch * 8 + j][cc];
+    if (vec && r + 8 <= Rpad) {
+      *reinterpret_cast<bf16x8*>(dst + (long)c * ldd + r) = v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (r + j < Rpad) dst[(long)c * ldd + r + j] = (bf16_t)v[j];
+    }
   }
 }
 
@@ -333,8 +361,11 @@ extern "C" int vq3_transpose_bf16(const void* src, void* dst, int32_t R, int32_t
   VQ3_CHECK_ARG(lds >= C && ldd >= Rpad, "transpose: leading dims too small");
   VQ3_CHECK_ARG(n0 >= 1 && n1 >= 1 && n2 >= 1 && (long)n0 * n1 * n2 <= 65535, "transpose: bad batch dims");
   dim3 grid((Rpad + 63) / 64, (C + 63) / 64, n0 * n1 * n2);
+  const bool al = (lds % 8 == 0) && (ldd % 8 == 0) && (s0 % 8 == 0) && (s1 % 8 == 0) && (s2 % 8 == 0) && (d0 % 8 == 0) &&
+                  (d1 % 8 == 0) && (d2 % 8 == 0) && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R, C,
-                     Rpad, (long)lds, (long)ldd, n1, n2, (long)s0, (long)s1, (long)s2, (long)d0, (long)d1, (long)d2);
+                     Rpad, (long)lds, (long)ldd, n1, n2, (long)s0, (long)s1, (long)s2, (long)d0, (long)d1, (long)d2,
+                     al ? 1 : 0);
   VQ3_CHECK_LAUNCH("transpose_bf16");
   return 0;
 }

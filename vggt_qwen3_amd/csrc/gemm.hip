@@ -29,6 +29,7 @@ struct GemmParams {
   int M, N, K, lda, ldb, ldc, ldr;
   long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
   int nb2, b2divB;
+  int mtiles, ntiles;
   int act;         // 0 none, 1 gelu(erf), 2 silu
   int out_f32;     // C / R dtype: 0 bf16, 1 f32
   int accumulate;  // C += result
@@ -47,7 +48,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own
+  // 4 MiB L2), so give every XCD a contiguous run of the (n-tile major, m-tile minor) order: the m-tiles that
+  // re-read one weight tile then hit the same L2. Bijective for any grid size.
+  int m0, n0;
+  {
+    const int nwg = p.mtiles * p.ntiles;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, idx = orig >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    m0 = (lin % p.mtiles) * BM;
+    n0 = (lin / p.mtiles) * BN;
+  }
   const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
   const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
   const bf16_t* B = p.B + b1 * p.sB1 + (long)(b2 / p.b2divB) * p.sB2;
@@ -75,19 +88,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra_[4], rb_[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra_[i] = *reinterpret_cast<const u32x4*>(ga[i]);
-    rb_[i] = *reinterpret_cast<const u32x4*>(gb[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<u32x4*>(smem + lds_off[i]) = ra_[i];
-    *reinterpret_cast<u32x4*>(smem + TILE_BYTES + lds_off[i]) = rb_[i];
-  }
-  __syncthreads();
-
   // fragment read offsets (within one operand tile), k-step 0; k-step 1 flips chunk bit 2
   const int fr = lane & 15, fq = lane >> 4;
   int a_off[4], b_off[4];
@@ -100,19 +100,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   }
 
   const int nt = p.K / BK;
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    const bool more = (t + 1 < nt);
-    if (more) {
+  // Two named register sets: while tile t is multiplied out of LDS, tile t+1 sits in one set (already requested
+  // a step ago) and tile t+2 is being requested into the other: global-load latency gets two MFMA phases of cover.
+  u32x4 s0a[4], s0b[4], s1a[4], s1b[4];
+  auto gload = [&](u32x4 (&ra)[4], u32x4 (&rb)[4], int tile) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ga[i] += BK;
-        gb[i] += BK;
-        ra_[i] = *reinterpret_cast<const u32x4*>(ga[i]);
-        rb_[i] = *reinterpret_cast<const u32x4*>(gb[i]);
-      }
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const u32x4*>(ga[i] + (long)tile * BK);
+      rb[i] = *reinterpret_cast<const u32x4*>(gb[i] + (long)tile * BK);
     }
-    const char* As = smem + cur * (2 * TILE_BYTES);
+  };
+  auto lstore = [&](const u32x4 (&ra)[4], const u32x4 (&rb)[4], int buf) {
+    char* Ad = smem + buf * (2 * TILE_BYTES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(Ad + lds_off[i]) = ra[i];
+      *reinterpret_cast<u32x4*>(Ad + TILE_BYTES + lds_off[i]) = rb[i];
+    }
+  };
+  auto compute = [&](int buf) {
+    const char* As = smem + buf * (2 * TILE_BYTES);
     const char* Bs = As + TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -129,16 +136,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     }
-    if (more) {
-      char* Ad = smem + (cur ^ 1) * (2 * TILE_BYTES);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<u32x4*>(Ad + lds_off[i]) = ra_[i];
-        *reinterpret_cast<u32x4*>(Ad + TILE_BYTES + lds_off[i]) = rb_[i];
-      }
-    }
+  };
+
+  // Loads and LDS stores are issued UNCONDITIONALLY (tile index clamped to the last tile): with branches around them
+  // hipcc's s_waitcnt insertion merges the two paths and drains vmcnt(0) before every ds_write; straight-line code
+  // gets the counted vmcnt(8..15) that leaves the newest tile's loads in flight. The redundant tail loads/stores
+  // touch only the last tile / the LDS buffer nobody reads any more.
+  const int last = nt - 1;
+  gload(s0a, s0b, 0);
+  lstore(s0a, s0b, 0);
+  gload(s0a, s0b, 1 < last ? 1 : last);
+  __syncthreads();
+  for (int t = 0; t < nt; t += 2) {
+    // even step: LDS[0] = tile t, set0 = tile t+1, request tile t+2 into set1
+    gload(s1a, s1b, t + 2 < last ? t + 2 : last);
+    compute(0);
+    lstore(s0a, s0b, 1);
     __syncthreads();
-    cur ^= 1;
+    if (t + 1 >= nt) break;
+    // odd step: LDS[1] = tile t+1, set1 = tile t+2, request tile t+3 into set0
+    gload(s0a, s0b, t + 3 < last ? t + 3 : last);
+    compute(1);
+    lstore(s1a, s1b, 0);
+    __syncthreads();
   }
 
   // ---- epilogue: lane owns C[m][n..n+3], m = m0+wm*64+i*16+fr, n = n0+wn*64+j*16+4*fq ----
@@ -277,8 +297,10 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
     }
     g_attr_set = true;
   }
-  dim3 grid((d->M + BM - 1) / BM, (d->N + BN - 1) / BN, d->nb1 * d->nb2);
-  VQ3_CHECK_ARG(grid.y <= 65535, "gemm: N too large for grid.y");
+  p.mtiles = (d->M + BM - 1) / BM;
+  p.ntiles = (d->N + BN - 1) / BN;
+  VQ3_CHECK_ARG((long)p.mtiles * p.ntiles < (1L << 31), "gemm: too many tiles");
+  dim3 grid(p.mtiles * p.ntiles, 1, d->nb1 * d->nb2);
   hipStream_t s = (hipStream_t)stream;
   if (d->out_f32)
     hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), SMEM_BYTES, s, p);

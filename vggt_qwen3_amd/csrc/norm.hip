@@ -42,8 +42,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------- RMSNorm backward
-// 16 rows per block (4 waves x 4 rows); dw partials are summed in LDS, then one f32 atomic per column per block.
+// 16 rows per block (4 waves x 4 rows). A wave keeps its row's x / dy / w chunks in registers (one HBM read), and its
+// dw partials in registers across its rows; partials meet in LDS once per block, then one f32 atomic per column.
 constexpr int RB_ROWS = 16;
+template <int NCH>  // cols <= NCH * 512
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* dres, bf16_t* dx, float* __restrict__ dw,
@@ -51,45 +53,67 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
   extern __shared__ float dw_s[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int c = threadIdx.x; c < cols; c += 256) dw_s[c] = 0.f;
-  __syncthreads();
+  float dwacc[NCH][8];
+  bf16x8 wv[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c = lane * 8 + ch * 512;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwacc[ch][j] = 0.f;
+    if (c < cols) wv[ch] = *reinterpret_cast<const bf16x8*>(w + c);
+  }
   for (int rr = 0; rr < RB_ROWS / 4; ++rr) {
     const long row = (long)blockIdx.x * RB_ROWS + rr * 4 + wid;
-    if (row >= rows) continue;
+    if (row >= rows) break;
     const float rs = rstd[row];
     const bf16_t* xr = x + row * (long)cols;
     const bf16_t* gr = dy + row * (long)cols;
+    bf16x8 xv[NCH], gv[NCH];
     float dot = 0.f;
-    for (int c = lane * 8; c < cols; c += 512) {
-      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c);
-      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(gr + c);
-      const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xh = bf2f((bf16_t)xv[j]) * rs;
-        const float d = bf2f((bf16_t)gv[j]);
-        dot += d * bf2f((bf16_t)wv[j]) * xh;
-        atomicAdd(&dw_s[c + j], d * xh);
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = lane * 8 + ch * 512;
+      if (c < cols) {
+        xv[ch] = *reinterpret_cast<const bf16x8*>(xr + c);
+        gv[ch] = *reinterpret_cast<const bf16x8*>(gr + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = bf2f((bf16_t)xv[ch][j]) * rs;
+          const float d = bf2f((bf16_t)gv[ch][j]);
+          dot += d * bf2f((bf16_t)wv[ch][j]) * xh;
+          dwacc[ch][j] += d * xh;
+        }
       }
     }
     dot = wave_sum(dot) / (float)cols;
     const bf16_t* rr_ = dres ? dres + row * (long)cols : nullptr;
     bf16_t* dxr = dx + row * (long)cols;
-    for (int c = lane * 8; c < cols; c += 512) {
-      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c);
-      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(gr + c);
-      const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
-      bf16x8 rv;
-      if (rr_) rv = *reinterpret_cast<const bf16x8*>(rr_ + c);
-      bf16x8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xh = bf2f((bf16_t)xv[j]) * rs;
-        const float g = bf2f((bf16_t)gv[j]) * bf2f((bf16_t)wv[j]);
-        float d = rs * (g - xh * dot);
-        if (rr_) d += bf2f((bf16_t)rv[j]);
-        o[j] = (short)f2bf(d);
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = lane * 8 + ch * 512;
+      if (c < cols) {
+        bf16x8 rv;
+        if (rr_) rv = *reinterpret_cast<const bf16x8*>(rr_ + c);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = bf2f((bf16_t)xv[ch][j]) * rs;
+          const float g = bf2f((bf16_t)gv[ch][j]) * bf2f((bf16_t)wv[ch][j]);
+          float d = rs * (g - xh * dot);
+          if (rr_) d += bf2f((bf16_t)rv[j]);
+          o[j] = (short)f2bf(d);
+        }
+        *reinterpret_cast<bf16x8*>(dxr + c) = o;
       }
-      *reinterpret_cast<bf16x8*>(dxr + c) = o;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c = lane * 8 + ch * 512;
+    if (c < cols) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&dw_s[c + j], dwacc[ch][j]);
     }
   }
   __syncthreads();
@@ -188,9 +212,17 @@ extern "C" int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   VQ3_CHECK_ARG(dy && x && w && rstd && dx && dw_f32, "rmsnorm_bwd: null pointer");
   VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 16384, "rmsnorm_bwd: bad cols=%d", cols);
   const long nblk = (rows + RB_ROWS - 1) / RB_ROWS;
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)nblk), dim3(256), cols * sizeof(float), (hipStream_t)stream,
-                     (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx,
-                     dw_f32, (long)rows, cols);
+#define VQ3_RB_LAUNCH(NCH)                                                                                           \
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel<NCH>, dim3((unsigned)nblk), dim3(256), cols * sizeof(float),                  \
+                     (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd,               \
+                     (const bf16_t*)dres, (bf16_t*)dx, dw_f32, (long)rows, cols)
+  if (cols <= 512) VQ3_RB_LAUNCH(1);
+  else if (cols <= 1024) VQ3_RB_LAUNCH(2);
+  else if (cols <= 2560) VQ3_RB_LAUNCH(5);
+  else if (cols <= 4096) VQ3_RB_LAUNCH(8);
+  else if (cols <= 8192) VQ3_RB_LAUNCH(16);
+  else VQ3_RB_LAUNCH(32);
+#undef VQ3_RB_LAUNCH
   VQ3_CHECK_LAUNCH("rmsnorm_bwd");
   return 0;
 }
