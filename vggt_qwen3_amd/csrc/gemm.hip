@@ -10,8 +10,12 @@
 // ds_read_b128 fragment reads). One barrier per K tile; next tile's global loads are issued before the MFMAs.
 // The MFMA is issued with W as the A operand and x as the B operand so each lane ends up with 4 consecutive
 // output columns of one output row -> 8/16-byte epilogue stores and row-wise epilogues without shuffles.
-#include "common.h"
+#include <cstdlib>
+
+#include "gemm_common.h"
 #include "vq3_hip.h"
+
+using namespace vq3gemm;
 
 namespace {
 
@@ -19,48 +23,13 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
 constexpr int SMEM_BYTES = 4 * TILE_BYTES;       // 2 stages x (A,B) = 64 KiB
 
-struct GemmParams {
-  const bf16_t* A;
-  const bf16_t* B;
-  void* C;
-  const float* bias;      // [N] or null
-  const float* colscale;  // [N] or null  (LayerScale gamma)
-  const void* R;          // residual, same dtype as C, or null
-  int M, N, K, lda, ldb, ldc, ldr;
-  long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
-  int nb2, b2divB;
-  int mtiles, ntiles;
-  int act;         // 0 none, 1 gelu(erf), 2 silu
-  int out_f32;     // C / R dtype: 0 bf16, 1 f32
-  int accumulate;  // C += result
-  int vec_ok;      // C (and R) rows are 16B (f32) / 8B (bf16) aligned for 4-wide stores
-  float alpha;
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == 1) return gelu_erf(v);
-  if (act == 2) return silu_f(v);
-  return v;
-}
-
 template <bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own
-  // 4 MiB L2), so give every XCD a contiguous run of the (n-tile major, m-tile minor) order: the m-tiles that
-  // re-read one weight tile then hit the same L2. Bijective for any grid size.
   int m0, n0;
-  {
-    const int nwg = p.mtiles * p.ntiles;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, idx = orig >> 3;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    m0 = (lin % p.mtiles) * BM;
-    n0 = (lin / p.mtiles) * BN;
-  }
+  tile_coords(p, BM, BN, m0, n0);
   const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
   const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
   const bf16_t* B = p.B + b1 * p.sB1 + (long)(b2 / p.b2divB) * p.sB2;
@@ -162,9 +131,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
   }
 
   // ---- epilogue: lane owns C[m][n..n+3], m = m0+wm*64+i*16+fr, n = n0+wn*64+j*16+4*fq ----
-  typedef typename std::conditional<OUT_F32, float, bf16_t>::type out_t;
-  out_t* C = reinterpret_cast<out_t*>(p.C) + coff;
-  const out_t* R = p.R ? reinterpret_cast<const out_t*>(p.R) + roff : nullptr;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + fr;
@@ -173,89 +139,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * fq;
       if (n >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-      const bool full = (n + 3 < p.N);
-      const int nv = full ? 4 : (p.N - n);
-      if (p.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (r < nv) v[r] += p.bias[n + r];
-      }
-      if (!OUT_F32) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-      }
-      if (p.act) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = apply_act(v[r], p.act);
-          if (!OUT_F32) v[r] = rbf(v[r]);
-        }
-      }
-      if (p.colscale) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (r < nv) {
-            v[r] *= p.colscale[n + r];
-            if (!OUT_F32) v[r] = rbf(v[r]);
-          }
-      }
-      out_t* cp = C + (long)m * p.ldc + n;
-      const out_t* rp = R ? R + (long)m * p.ldr + n : nullptr;
-      if (full && p.vec_ok) {
-        if (OUT_F32) {
-          if (rp) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rv[r];
-          }
-          if (p.accumulate) {
-            const f32x4 cv = *reinterpret_cast<const f32x4*>(cp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += cv[r];
-          }
-          *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          if (rp) {
-            const u32x2 rv = *reinterpret_cast<const u32x2*>(rp);
-            v[0] = rbf(v[0] + bf2f((bf16_t)(rv[0] & 0xffff)));
-            v[1] = rbf(v[1] + bf2f((bf16_t)(rv[0] >> 16)));
-            v[2] = rbf(v[2] + bf2f((bf16_t)(rv[1] & 0xffff)));
-            v[3] = rbf(v[3] + bf2f((bf16_t)(rv[1] >> 16)));
-          }
-          if (p.accumulate) {
-            const u32x2 cv = *reinterpret_cast<const u32x2*>(cp);
-            v[0] += bf2f((bf16_t)(cv[0] & 0xffff));
-            v[1] += bf2f((bf16_t)(cv[0] >> 16));
-            v[2] += bf2f((bf16_t)(cv[1] & 0xffff));
-            v[3] += bf2f((bf16_t)(cv[1] >> 16));
-          }
-          u32x2 o;
-          o[0] = pack2bf(v[0], v[1]);
-          o[1] = pack2bf(v[2], v[3]);
-          *reinterpret_cast<u32x2*>(cp) = o;
-        }
-      } else {
-        for (int r = 0; r < nv; ++r) {
-          float x = v[r];
-          if (OUT_F32) {
-            if (rp) x += (float)reinterpret_cast<const float*>(rp)[r];
-            if (p.accumulate) x += reinterpret_cast<const float*>(cp)[r];
-            reinterpret_cast<float*>(cp)[r] = x;
-          } else {
-            if (rp) x = rbf(x + bf2f(reinterpret_cast<const bf16_t*>(rp)[r]));
-            if (p.accumulate) x += bf2f(reinterpret_cast<const bf16_t*>(cp)[r]);
-            reinterpret_cast<bf16_t*>(cp)[r] = f2bf(x);
-          }
-        }
-      }
+      store_quad<OUT_F32>(p, coff, roff, m, n, acc[i][j]);
     }
   }
 }
 
 bool g_attr_set = false;
+
+// Kernel choice per shape. -1 = v1 (128x128, register staged, 2 workgroups/CU); 0/1/2 = v2 LDS-DMA kernels
+// (256x128, 128x256, 128x128 tiles, one workgroup per CU). VQ3_GEMM_CFG overrides (benchmarking).
+int choose_config(int M, int N, int K, int nbatch) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("VQ3_GEMM_CFG");
+    forced = e ? atoi(e) : -3;
+  }
+  if (forced >= -1) return forced;
+  (void)K;
+  // Measured on MI355X (gpurun_out/gemm_v2_*.log): with more 128x128 tiles than CUs the 2-stage kernel at two
+  // workgroups (16 waves) per CU wins; with at most one tile per CU the 3-stage ring (tile t+1 in flight across the
+  // barrier) hides more of the load latency.
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
+  return tiles <= 256 ? 3 : 7;
+}
 
 }  // namespace
 
@@ -288,6 +194,15 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   if (d->R) vec = vec && (d->ldr % 4 == 0) && (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0) && ((uintptr_t)d->R % (4 * esz) == 0);
   p.vec_ok = vec ? 1 : 0;
 
+  hipStream_t s = (hipStream_t)stream;
+  const int nbatch = d->nb1 * d->nb2;
+  const int cfg = choose_config(d->M, d->N, d->K, nbatch);
+  if (cfg >= 0) {
+    const int rc = launch_gemm_v2(p, cfg, nbatch, s);
+    if (rc) return rc;
+    VQ3_CHECK_LAUNCH("gemm_bf16_nt(v2)");
+    return 0;
+  }
   if (!g_attr_set) {
     hipError_t e1 = hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     hipError_t e2 = hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
@@ -300,8 +215,7 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   p.mtiles = (d->M + BM - 1) / BM;
   p.ntiles = (d->N + BN - 1) / BN;
   VQ3_CHECK_ARG((long)p.mtiles * p.ntiles < (1L << 31), "gemm: too many tiles");
-  dim3 grid(p.mtiles * p.ntiles, 1, d->nb1 * d->nb2);
-  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
   if (d->out_f32)
     hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), SMEM_BYTES, s, p);
   else

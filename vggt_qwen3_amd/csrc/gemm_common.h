@@ -1,0 +1,137 @@
+// Shared by the GEMM kernels: launch parameters, the XCD-aware tile order and the fused epilogue.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+namespace vq3gemm {
+
+struct GemmParams {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;      // [N] or null
+  const float* colscale;  // [N] or null  (LayerScale gamma)
+  const void* R;          // residual, same dtype as C, or null
+  int M, N, K, lda, ldb, ldc, ldr;
+  long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+  int nb2, b2divB;
+  int mtiles, ntiles;
+  int act;         // 0 none, 1 gelu(erf), 2 silu
+  int out_f32;     // C / R dtype: 0 bf16, 1 f32
+  int accumulate;  // C += result
+  int vec_ok;      // C (and R) rows are 16B (f32) / 8B (bf16) aligned for 4-wide stores
+  float alpha;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return gelu_erf(v);
+  if (act == 2) return silu_f(v);
+  return v;
+}
+
+// XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own
+// 4 MiB L2), so give every XCD a contiguous run of the (n-tile major, m-tile minor) order: the m-tiles that re-read
+// one weight tile then hit the same L2. Bijective for any grid size.
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int BM, int BN, int& m0, int& n0) {
+  const int nwg = p.mtiles * p.ntiles;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, idx = orig >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  m0 = (lin % p.mtiles) * BM;
+  n0 = (lin / p.mtiles) * BN;
+}
+
+// Epilogue for one lane-owned quad C[m][n..n+3] (m < M, n < N guaranteed by the caller):
+//   v = alpha*acc; += bias; (round to bf16 if C is bf16); act; *= colscale; += R; += C if accumulate; store.
+// The intermediate roundings reproduce the points where PyTorch materialises a bf16 tensor.
+template <bool OUT_F32>
+__device__ __forceinline__ void store_quad(const GemmParams& p, long coff, long roff, int m, int n, const f32x4& a) {
+  typedef typename std::conditional<OUT_F32, float, bf16_t>::type out_t;
+  out_t* C = reinterpret_cast<out_t*>(p.C) + coff;
+  const out_t* R = p.R ? reinterpret_cast<const out_t*>(p.R) + roff : nullptr;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
+  const bool full = (n + 3 < p.N);
+  const int nv = full ? 4 : (p.N - n);
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < nv) v[r] += p.bias[n + r];
+  }
+  if (!OUT_F32) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+  }
+  if (p.act) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = apply_act(v[r], p.act);
+      if (!OUT_F32) v[r] = rbf(v[r]);
+    }
+  }
+  if (p.colscale) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < nv) {
+        v[r] *= p.colscale[n + r];
+        if (!OUT_F32) v[r] = rbf(v[r]);
+      }
+  }
+  out_t* cp = C + (long)m * p.ldc + n;
+  const out_t* rp = R ? R + (long)m * p.ldr + n : nullptr;
+  if (full && p.vec_ok) {
+    if (OUT_F32) {
+      if (rp) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+      }
+      if (p.accumulate) {
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += cv[r];
+      }
+      *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+      if (rp) {
+        const u32x2 rv = *reinterpret_cast<const u32x2*>(rp);
+        v[0] = rbf(v[0] + bf2f((bf16_t)(rv[0] & 0xffff)));
+        v[1] = rbf(v[1] + bf2f((bf16_t)(rv[0] >> 16)));
+        v[2] = rbf(v[2] + bf2f((bf16_t)(rv[1] & 0xffff)));
+        v[3] = rbf(v[3] + bf2f((bf16_t)(rv[1] >> 16)));
+      }
+      if (p.accumulate) {
+        const u32x2 cv = *reinterpret_cast<const u32x2*>(cp);
+        v[0] += bf2f((bf16_t)(cv[0] & 0xffff));
+        v[1] += bf2f((bf16_t)(cv[0] >> 16));
+        v[2] += bf2f((bf16_t)(cv[1] & 0xffff));
+        v[3] += bf2f((bf16_t)(cv[1] >> 16));
+      }
+      u32x2 o;
+      o[0] = pack2bf(v[0], v[1]);
+      o[1] = pack2bf(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(cp) = o;
+    }
+  } else {
+    for (int r = 0; r < nv; ++r) {
+      float x = v[r];
+      if (OUT_F32) {
+        if (rp) x += reinterpret_cast<const float*>(rp)[r];
+        if (p.accumulate) x += reinterpret_cast<const float*>(cp)[r];
+        reinterpret_cast<float*>(cp)[r] = x;
+      } else {
+        if (rp) x = rbf(x + bf2f(reinterpret_cast<const bf16_t*>(rp)[r]));
+        if (p.accumulate) x += bf2f(reinterpret_cast<const bf16_t*>(cp)[r]);
+        reinterpret_cast<bf16_t*>(cp)[r] = f2bf(x);
+      }
+    }
+  }
+}
+
+// v2 (LDS-DMA pipelined) launcher, defined in gemm2.hip. cfg: 0 = 256x128 tile, 1 = 128x256, 2 = 128x128.
+int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream);
+
+}  // namespace vq3gemm
