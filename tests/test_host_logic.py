@@ -1,0 +1,113 @@
+"""CPU tests of the host-side logic around the HIP path: integer splice map and label-row selection against the
+oracle, LR schedule against transformers, bucket planning, and the N>1 gradient exchange on gloo (world_size 2)."""
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import qwen3 as oq
+from oracle import vlm as ovlm
+
+
+def test_srcmap_matches_oracle_bit_exact():
+    from vggt_qwen3_amd.vlm import build_srcmap
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 50, (5, 200), generator=g)
+    ids[ids == 7] = 8
+    for b, p in enumerate([3, 17, 40, 63, 0]):
+        ids[b, p] = 7
+    ids[4, 0] = 9                      # row without <image>
+    ids[2, 45] = 7                     # repeated <image>: the later span overwrites the earlier one
+    a = build_srcmap(ids, 7, 136)
+    b = ovlm.splice_srcmap(ids, 136, 7)
+    assert a.dtype == torch.int32 and torch.equal(a, b)
+    assert (a[4] == -1).all()
+    assert a[2, 45] == 0 and a[2, 44] == 4
+    with pytest.raises(RuntimeError):
+        build_srcmap(ids[:, :100], 7, 136)
+
+
+def test_label_rows_match_shifted_cross_entropy():
+    from vggt_qwen3_amd.qwen3 import Qwen3ForCausalLM
+    g = torch.Generator().manual_seed(1)
+    B, L, V = 3, 20, 11
+    labels = torch.full((B, L), -100)
+    labels[0, 5:9] = torch.randint(0, V, (4,), generator=g)
+    labels[1, 19] = 3
+    labels[2, 0] = 4                   # a label at position 0 is never predicted (shift)
+    idx, tgt = Qwen3ForCausalLM.label_rows(labels)
+    logits = torch.randn(B, L, V, generator=g)
+    ref = oq.causal_lm_loss(logits, labels)
+    flat = logits.reshape(-1, V)[idx.long()]
+    mine = torch.nn.functional.cross_entropy(flat, tgt.long(), reduction="mean")
+    assert torch.allclose(ref, mine, atol=1e-6)
+    assert idx.tolist() == [4, 5, 6, 7, 20 + 18]
+
+
+def test_cosine_schedule_matches_transformers():
+    from transformers import get_cosine_schedule_with_warmup
+    from vggt_qwen3_amd.trainer import cosine_with_warmup
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1.0)
+    total, warm = 1000, 30
+    sch = get_cosine_schedule_with_warmup(opt, warm, total)
+    for step in range(0, total, 37):
+        while sch.last_epoch < step:
+            opt.step(); sch.step()
+        assert math.isclose(sch.get_last_lr()[0], cosine_with_warmup(step, warm, total), rel_tol=1e-9, abs_tol=1e-12)
+
+
+def _fake_table(L=6, H=64, I=128, D=128, nqkv=256, V=50):
+    ent = [("embed", (V, H))]
+    for i in range(L):
+        ent += [(f"l{i}.qkv", (nqkv, H)), (f"l{i}.o", (H, 128)), (f"l{i}.gu", (2 * I, H)), (f"l{i}.down", (H, I)),
+                (f"l{i}.ln1", (H,)), (f"l{i}.ln2", (H,)), (f"l{i}.qn", (D,)), (f"l{i}.kn", (D,))]
+    ent.append(("norm", (H,)))
+    off, table = 0, {}
+    for n, s in ent:
+        table[n] = (off, s)
+        off += (math.prod(s) + 63) // 64 * 64
+    return table, off
+
+
+def test_bucket_plan_covers_buffer_exactly():
+    from vggt_qwen3_amd import dp
+    table, total = _fake_table()
+    for bl in (1, 2, 4, 6, 7):
+        buckets, emb = dp.plan_buckets(table, 6, bl)
+        dp.check_cover(buckets, emb, total)
+        assert len(buckets) == math.ceil(6 / bl)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vggt_qwen3_amd import dp
+        table, total = _fake_table()
+        buckets, emb = dp.plan_buckets(table, 6, 4)
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(total, generator=g)
+        mine = flat.clone()
+        dp.allreduce_in_backward_order(flat, buckets, emb)
+        others = [torch.randn(total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        ref = sum(others)
+        ret[rank] = (torch.allclose(flat, ref, atol=1e-6), float((flat - mine).abs().sum()) > 0)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r][0] and ret[r][1] for r in range(world)), dict(ret)

@@ -1,0 +1,57 @@
+"""Data-parallel gradient exchange: bucket planning over the flat gradient buffer and the all-reduce itself.
+Pure torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests); no kernels here.
+
+The path shards by samples only: every rank runs whole micro-batches, the one exchange is a SUM
+all-reduce of the gradients before the optimiser step, bucketed so that it can be issued from inside the backward
+(last layers first) and overlap the rest of it. The 1/world_size factor is applied by the AdamW kernel."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def plan_buckets(table: Dict[str, tuple], num_layers: int, bucket_layers: int) -> Tuple[Dict[int, Tuple[int, int]], Tuple[int, int]]:
+    """table: name -> (offset, shape) of the flat buffer laid out [embed | l0.* ... l{L-1}.* | norm].
+    Returns ({first_layer_of_group: (lo, hi)}, embed_span). Groups are contiguous; the final norm rides with the last
+    group; the tied embedding is its own bucket (its gradient is only complete at the very end of the backward)."""
+    def span(first: str, last: str) -> Tuple[int, int]:
+        lo = table[first][0]
+        o1, s1 = table[last]
+        return lo, round_up(o1 + math.prod(s1), 64)
+    buckets = {}
+    for g0 in range(0, num_layers, bucket_layers):
+        g1 = min(num_layers, g0 + bucket_layers) - 1
+        buckets[g0] = span(f"l{g0}.qkv", "norm" if g1 == num_layers - 1 else f"l{g1}.kn")
+    return buckets, span("embed", "embed")
+
+
+def check_cover(buckets: Dict[int, Tuple[int, int]], embed_span: Tuple[int, int], total: int) -> None:
+    """Every element of the flat buffer belongs to exactly one bucket."""
+    spans = sorted([embed_span] + list(buckets.values()))
+    pos = 0
+    for lo, hi in spans:
+        if lo != pos:
+            raise AssertionError(f"gap or overlap at {pos} -> {lo}")
+        pos = hi
+    if pos != total:
+        raise AssertionError(f"buckets end at {pos}, buffer has {total}")
+
+
+def allreduce_span(flat: torch.Tensor, lo: int, hi: int, group=None, async_op: bool = False):
+    return dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def allreduce_in_backward_order(flat: torch.Tensor, buckets: Dict[int, Tuple[int, int]], embed_span: Tuple[int, int],
+                                group=None) -> None:
+    """Reference schedule (used by the tests and as the no-overlap fallback): groups from the last layer to the
+    first, then the embedding."""
+    for g0 in sorted(buckets, reverse=True):
+        allreduce_span(flat, *buckets[g0], group=group)
+    allreduce_span(flat, *embed_span, group=group)

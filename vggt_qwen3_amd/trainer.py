@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import dp, ops
 from .ops import BF16, F32
 from .vlm import VGGTQwen3VLM
 
@@ -60,18 +60,8 @@ class Stage1Trainer:
         self._geom_has_grad = False
         # all-reduce buckets over flat_g: groups of `bucket_layers` layers (contiguous), norm with the last group,
         # the tied embedding last (its gradient is completed by the embedding backward at the very end)
-        self.buckets: Dict[int, tuple] = {}
-        L = self.tm.config.num_hidden_layers
-        tab = self.tm.table
-        def span(first, last_name):
-            o0 = tab[first][0]
-            o1, s1 = tab[last_name]
-            return o0, ops.round_up(o1 + math.prod(s1), 64)
-        for g0 in range(0, L, bucket_layers):
-            g1 = min(L, g0 + bucket_layers) - 1
-            last = "norm" if g1 == L - 1 else f"l{g1}.kn"
-            self.buckets[g0] = span(f"l{g0}.qkv", last)
-        self.embed_span = span("embed", "embed")
+        self.buckets, self.embed_span = dp.plan_buckets(self.tm.table, self.tm.config.num_hidden_layers, bucket_layers)
+        dp.check_cover(self.buckets, self.embed_span, n)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
         self._works: List = []
 
@@ -79,10 +69,9 @@ class Stage1Trainer:
     def _allreduce_span(self, lo: int, hi: int):
         if self.world == 1:
             return
-        buf = self.tm.flat_g[lo:hi]
         self.comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+            dp.allreduce_span(self.tm.flat_g, lo, hi, group=self.pg)
 
     def _layer_done(self, i: int):
         if i in self.buckets:

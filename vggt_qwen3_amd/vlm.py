@@ -44,6 +44,21 @@ class VisionLanguageConfig:
     seed: int = 0
 
 
+def build_srcmap(input_ids: torch.Tensor, image_id: int, S: int) -> torch.Tensor:
+    """Integer image of `for b, pos in nonzero(ids == image_id): emb[b, pos:pos+S] = features[b]`
+    (vggt_qwen3_vlm.py:191-195): srcmap[b,l] = feature row written at (b,l) or -1; the last writer wins for repeated
+    <image> tokens; raises RuntimeError like the reference's index assignment when a span overruns the sequence."""
+    B, L = input_ids.shape
+    pos = (input_ids == image_id).nonzero(as_tuple=False).tolist()
+    m = torch.full((B, L), -1, dtype=torch.int32)
+    for b, p in pos:
+        if p + S > L:
+            raise RuntimeError(f"The expanded size of the tensor ({L - p}) must match the existing size ({S}) at "
+                               f"non-singleton dimension 0 (visual span at position {p} overruns L={L})")
+        m[b, p:p + S] = torch.arange(S, dtype=torch.int32)
+    return m.to(input_ids.device)
+
+
 class _StubTokenizer:
     """Used only when text_model_name has no tokenizer files (synthetic benchmarks): knows `<image>`."""
 
@@ -209,17 +224,7 @@ class VGGTQwen3VLM(nn.Module):
 
     # ------------------------------------------------------------------ splice (integer work, host side)
     def _srcmap(self, input_ids: torch.Tensor, S: int) -> torch.Tensor:
-        """Integer image of `for b, pos in nonzero(ids == image_id): emb[b, pos:pos+S] = features[b]`
-        (vggt_qwen3_vlm.py:191-195), last writer wins; raises like the reference when a span overruns."""
-        B, L = input_ids.shape
-        pos = (input_ids == self.image_id).nonzero(as_tuple=False).tolist()
-        m = torch.full((B, L), -1, dtype=torch.int32)
-        for b, p in pos:
-            if p + S > L:
-                raise RuntimeError(f"The expanded size of the tensor ({L - p}) must match the existing size ({S}) at "
-                                   f"non-singleton dimension 0 (visual span at position {p} overruns L={L})")
-            m[b, p:p + S] = torch.arange(S, dtype=torch.int32)
-        return m.to(input_ids.device)
+        return build_srcmap(input_ids, self.image_id, S)
 
     # ------------------------------------------------------------------ forward / backward
     def forward_state(self, images, geom_token, input_ids, attention_mask, labels, need_grad: bool) -> dict:
