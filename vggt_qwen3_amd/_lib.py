@@ -76,6 +76,9 @@ def load() -> C.CDLL:
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). The HIP library is required; there is no CPU/PyTorch fallback."
         )
+    # torch ships its own libamdhip64; import it first so that this library binds to the SAME HIP runtime instance
+    # (device pointers and streams are shared with torch). Loading ours first gives two runtimes in one process.
+    import torch  # noqa: F401
     lib = C.CDLL(str(path))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
