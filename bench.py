@@ -204,14 +204,20 @@ def main():
         ops.GEMM_PROFILE = []
         trainer.micro_step(batch)
         torch.cuda.synchronize()
-        fl = sum(f for f, _, _ in ops.GEMM_PROFILE)
-        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in ops.GEMM_PROFILE)
+        fl = sum(f for f, _, _, _ in ops.GEMM_PROFILE)
+        by = sum(b for _, b, _, _ in ops.GEMM_PROFILE)
+        ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in ops.GEMM_PROFILE)
         nlaunch = len(ops.GEMM_PROFILE)
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12
+        traffic = None
+        tj = ROOT / "profiles" / "r1_pmc_traffic.json"
+        if tj.exists():  # PMC counters cannot be read from inside the run: this is the committed rocprofv3 --pmc result
+            traffic = round(json.loads(tj.read_text())["traffic_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (vq3_gemm_bf16_nt)", "achieved": round(ach, 1),
                 "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                "traffic": None, "launches_per_step": nlaunch, "avg_launch_us": round(ms * 1e3 / nlaunch, 2),
+                "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
+                "algorithmic_bytes_per_launch": round(by / nlaunch), "launches_per_step": nlaunch, "avg_launch_us": round(ms * 1e3 / nlaunch, 2),
                 "gemm_ms_per_step": round(ms, 2), "gemm_tflop_per_step": round(fl / 1e12, 3)}
     elif world > 1:
         trainer.micro_step(batch)  # keep collectives matched across ranks

@@ -15,7 +15,7 @@ F32 = torch.float32
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 
 # When set to a list, every GEMM launch is bracketed by HIP events on the launch stream and
-# (algorithmic FLOPs, start, end) is appended: bench.py's live roofline measurement.
+# (algorithmic FLOPs, algorithmic bytes, start, end) is appended: bench.py's live roofline measurement.
 GEMM_PROFILE = None
 
 
@@ -67,7 +67,9 @@ def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, 
         e0.record()
         check(_lib.load().vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")
         e1.record()
-        GEMM_PROFILE.append((2.0 * M * N * K * nb1 * nb2, e0, e1))
+        GEMM_PROFILE.append((2.0 * M * N * K * nb1 * nb2,
+                             float(nb1 * nb2) * (2.0 * M * K + 2.0 * N * K / b2divB + C.element_size() * M * N *
+                                                 (1 + (R is not None) + bool(accumulate))), e0, e1))
         return
     check(_lib.load().vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")
 
