@@ -7,9 +7,10 @@
 
 One step = one micro-batch of B=6 synthetic samples per GPU through the whole hot path: VGGT aggregator forward
 (frozen), Perceiver forward (no grad, as in the reference), Qwen3-4B forward + backward, gradient all-reduce over
-RCCL, fused AdamW with fp32 master weights, refresh of the transposed weight copies. grad_accum defaults to 1 so the
-optimiser and the collective run inside EVERY timed step (the reference's stage1 config uses 32; --grad-accum 32
-reproduces it). Weights are random-init at the exact Qwen3-4B / VGGT-1B / Perceiver shapes, inputs synthetic and
+RCCL, fused AdamW with fp32 master weights, refresh of the transposed weight copies. The timed window is whole
+accumulation cycles: grad_accum defaults to min(32, --steps) (the reference's stage-1 schedule is 32), so every
+window contains exactly steps/grad_accum optimiser steps + all-reduces and never zero; --grad-accum 1 puts them in
+every step. Weights are random-init at the exact Qwen3-4B / VGGT-1B / Perceiver shapes, inputs synthetic and
 already resident in HBM. Prints one JSON line on rank 0.
 """
 from __future__ import annotations
@@ -134,7 +135,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--grad-accum", type=int, default=1)
+    ap.add_argument("--grad-accum", type=int, default=0,
+                    help="micro-batches per optimiser step; 0 = min(32, --steps): the timed window is one accumulation "
+                         "cycle of the reference's stage-1 schedule (grad_accum 32) with exactly one all-reduce + AdamW")
     ap.add_argument("--batch", type=int, default=6)
     ap.add_argument("--views", type=int, default=1)
     ap.add_argument("--seq-len", type=int, default=200)
@@ -171,7 +174,11 @@ def main():
                                 device=str(dev), seed=0)
     model = VGGTQwen3VLM(vcfg)
     model.train()
-    trainer = Stage1Trainer(model, grad_accum=args.grad_accum, max_steps=30000)
+    accum = args.grad_accum if args.grad_accum > 0 else max(1, min(32, args.steps))
+    if args.steps % accum:
+        raise SystemExit(f"--steps {args.steps} must be a multiple of the accumulation length {accum}: every timed "
+                         "window must contain whole optimiser steps")
+    trainer = Stage1Trainer(model, grad_accum=accum, max_steps=30000)
     B, V, L = args.batch, args.views, args.seq_len
     batch = synthetic_batch(B, V, L, args.image_size, 151936, model.image_id, 151643, 198, 1234 + rank, dev, args.geom)
     torch.cuda.synchronize()
@@ -183,8 +190,15 @@ def main():
         torch.cuda.synchronize()
 
     loss = None
-    for _ in range(args.warmup):
+    # warm-up runs whole accumulation cycles too (so the timed region starts on a cycle boundary); the first cycle
+    # also pays the one-time costs (LDS attribute setup, allocator growth, RCCL channel setup)
+    nwarm = max(args.warmup, 1)
+    trainer.grad_accum = nwarm
+    for _ in range(nwarm):
         loss = trainer.micro_step(batch)
+    trainer.grad_accum = accum
+    assert trainer.micro % nwarm == 0
+    trainer.micro = 0
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -202,12 +216,22 @@ def main():
     roof = None
     if rank == 0:
         ops.GEMM_PROFILE = []
+        trainer.grad_accum = 1
+        trainer.micro = 0
         trainer.micro_step(batch)
         torch.cuda.synchronize()
-        fl = sum(f for f, _, _, _ in ops.GEMM_PROFILE)
-        by = sum(b for _, b, _, _ in ops.GEMM_PROFILE)
-        ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in ops.GEMM_PROFILE)
+        fl = sum(g[0] for g in ops.GEMM_PROFILE)
+        by = sum(g[1] for g in ops.GEMM_PROFILE)
+        ms = sum(g[2].elapsed_time(g[3]) for g in ops.GEMM_PROFILE)
         nlaunch = len(ops.GEMM_PROFILE)
+        if os.environ.get("VQ3_GEMM_TABLE"):
+            import collections
+            tab = collections.defaultdict(lambda: [0, 0.0, 0.0])
+            for g in ops.GEMM_PROFILE:
+                t = tab[g[4]]; t[0] += 1; t[1] += g[2].elapsed_time(g[3]); t[2] += g[0]
+            print("GEMM shapes (M,N,K,batch): calls, ms/step, TF/s", file=sys.stderr)
+            for k, (c, m_, f_) in sorted(tab.items(), key=lambda kv: -kv[1][1])[:40]:
+                print(f"  {k}: {c:4d} {m_:8.3f} ms {f_ / m_ / 1e9:8.1f} TF/s", file=sys.stderr)
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12
         traffic = None
@@ -220,6 +244,8 @@ def main():
                 "algorithmic_bytes_per_launch": round(by / nlaunch), "launches_per_step": nlaunch, "avg_launch_us": round(ms * 1e3 / nlaunch, 2),
                 "gemm_ms_per_step": round(ms, 2), "gemm_tflop_per_step": round(fl / 1e12, 3)}
     elif world > 1:
+        trainer.grad_accum = 1
+        trainer.micro = 0
         trainer.micro_step(batch)  # keep collectives matched across ranks
     if world > 1:
         dist.barrier()
@@ -234,7 +260,7 @@ def main():
                                     "Perceiver + Qwen3-4B fwd+bwd + RCCL all-reduce + AdamW(fp32 master); random-init "
                                     "weights" % (args.image_size, V)),
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": L, "views": V,
-                       "grad_accum": args.grad_accum, "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
+                       "grad_accum": accum, "optimizer_steps_timed": args.steps // accum, "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
                        "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),
             "algorithmic_tflop_per_sample": round(tf_train, 3),

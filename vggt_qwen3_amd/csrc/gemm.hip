@@ -180,6 +180,8 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   VQ3_CHECK_ARG((long)d->nb1 * d->nb2 <= 65535, "gemm: too many batches");
   VQ3_CHECK_ARG(d->act >= 0 && d->act <= 2, "gemm: bad activation %d", d->act);
   VQ3_CHECK_ARG(!(d->R) || d->ldr >= d->N, "gemm: ldr < N");
+  VQ3_CHECK_ARG((!d->bias || (uintptr_t)d->bias % 16 == 0) && (!d->colscale || (uintptr_t)d->colscale % 16 == 0),
+                "gemm: bias / colscale must be 16-byte aligned");
 
   GemmParams p;
   p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;

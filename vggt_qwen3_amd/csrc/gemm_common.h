@@ -57,9 +57,15 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, long coff, long 
   const bool full = (n + 3 < p.N);
   const int nv = full ? 4 : (p.N - n);
   if (p.bias) {
+    if (full) {  // n % 4 == 0 and the vectors are 16-byte aligned (checked on the host)
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (r < nv) v[r] += p.bias[n + r];
+      for (int r = 0; r < 4; ++r) v[r] += bv[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < nv) v[r] += p.bias[n + r];
+    }
   }
   if (!OUT_F32) {
 #pragma unroll
@@ -73,12 +79,21 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, long coff, long 
     }
   }
   if (p.colscale) {
+    if (full) {
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(p.colscale + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (r < nv) {
-        v[r] *= p.colscale[n + r];
+      for (int r = 0; r < 4; ++r) {
+        v[r] *= cv[r];
         if (!OUT_F32) v[r] = rbf(v[r]);
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < nv) {
+          v[r] *= p.colscale[n + r];
+          if (!OUT_F32) v[r] = rbf(v[r]);
+        }
+    }
   }
   out_t* cp = C + (long)m * p.ldc + n;
   const out_t* rp = R ? R + (long)m * p.ldr + n : nullptr;

@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------- RMSNorm backward
-// 16 rows per block (4 waves x 4 rows). A wave keeps its row's x / dy / w chunks in registers (one HBM read), and its
+// 4 rows per block (one per wave; 300 blocks at M = 1200 fill the chip). A wave keeps its row's x / dy / w chunks in registers (one HBM read), and its
 // dw partials in registers across its rows; partials meet in LDS once per block, then one f32 atomic per column.
-constexpr int RB_ROWS = 16;
+constexpr int RB_ROWS = 4;
 template <int NCH>  // cols <= NCH * 512
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,

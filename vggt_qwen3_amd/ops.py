@@ -69,7 +69,7 @@ def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, 
         e1.record()
         GEMM_PROFILE.append((2.0 * M * N * K * nb1 * nb2,
                              float(nb1 * nb2) * (2.0 * M * K + 2.0 * N * K / b2divB + C.element_size() * M * N *
-                                                 (1 + (R is not None) + bool(accumulate))), e0, e1))
+                                                 (1 + (R is not None) + bool(accumulate))), e0, e1, (M, N, K, nb1 * nb2)))
         return
     check(_lib.load().vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")
 
