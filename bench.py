@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--seq-len", type=int, default=200)
     ap.add_argument("--image-size", type=int, default=448)
     ap.add_argument("--geom", action="store_true", help="geometry tokens on (config C4)")
+    ap.add_argument("--trim-pad", action="store_true",
+                    help="drop the all-padding tail of the batch (exact; NOT the default: fewer FLOPs are executed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=36, help="debug only; anything but 36 marks the line invalid")
     args = ap.parse_args()
@@ -150,12 +152,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VQ3_DIST_BACKEND", "nccl") != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VQ3_DIST_BACKEND", "nccl")   # "gloo" only to rehearse N ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from vggt_qwen3_amd import ops
@@ -171,7 +179,7 @@ def main():
     pcfg = PerceiverConfig(**yaml.safe_load((ROOT / "configs" / "perceiver_small.yaml").read_text()))
     vcfg = VisionLanguageConfig(text_model_name="synthetic", vision_ckpt_dir="none", num_vis_tokens=128,
                                 geom_tokens=8 if args.geom else 0, projector_cfg=pcfg, text_config=qcfg,
-                                device=str(dev), seed=0)
+                                device=str(dev), seed=0, trim_padding=args.trim_pad)
     model = VGGTQwen3VLM(vcfg)
     model.train()
     accum = args.grad_accum if args.grad_accum > 0 else max(1, min(32, args.steps))
@@ -261,7 +269,7 @@ def main():
                                     "weights" % (args.image_size, V)),
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": L, "views": V,
                        "grad_accum": accum, "optimizer_steps_timed": args.steps // accum, "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
-                       "qwen_layers": args.layers, "valid": args.layers == 36},
+                       "trim_padding": bool(args.trim_pad), "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),
             "algorithmic_tflop_per_sample": round(tf_train, 3),
             "model_flops_utilisation": round(value * tf_train / (world * BF16_DENSE_PEAK_TFLOPS), 4),

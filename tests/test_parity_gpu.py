@@ -185,3 +185,27 @@ def test_qwen3_layer_full_width_vs_oracle():
     assert e < 1e-2, f"full-width logits rel err {e}"
     loss, _ = model.loss_head(h_last, labels.cuda(), save=False)
     assert abs(loss.item() - loss_ref.item()) < 5e-3 * abs(loss_ref.item())
+
+
+def test_trim_padding_is_exact():
+    """Dropping the all-padding tail of the batch changes neither the loss nor any gradient (beyond bf16 noise)."""
+    z = load("vlm_tiny.npz")
+    m = meta(z)
+    geom = {k: torch.from_numpy(z["geom:" + k]).cuda() for k in ("R", "t", "K", "depth_hist")}
+    images = torch.from_numpy(z["pixel_values"].astype(np.float32)).cuda()
+    ids = torch.from_numpy(z["input_ids"]).cuda()
+    mask = torch.from_numpy(z["attention_mask"]).cuda()
+    labels = torch.from_numpy(z["labels"]).cuda()
+    out = {}
+    for trim in (False, True):
+        model = _build_vlm(z, m)
+        model.trim_padding = trim
+        model.train()
+        loss = model(images=images, geom_token=geom, input_ids=ids, attention_mask=mask, labels=labels)
+        loss.backward()
+        out[trim] = (loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
+                     model._last_state["L"])
+    assert out[True][2] < out[False][2]
+    assert abs(out[True][0] - out[False][0]) < 1e-4 * abs(out[False][0])
+    for n, g in out[False][1].items():
+        assert relerr(out[True][1][n], g) < 2e-2, n

@@ -42,6 +42,7 @@ class VisionLanguageConfig:
     vision_module: Optional[nn.Module] = None    # inject any module exposing .aggregator(images) and .embed_dim
     device: str = "cuda"
     seed: int = 0
+    trim_padding: bool = False
 
 
 def build_srcmap(input_ids: torch.Tensor, image_id: int, S: int) -> torch.Tensor:
@@ -151,6 +152,9 @@ class VGGTQwen3VLM(nn.Module):
         self.geom_head.to(dev)
         self.num_vis_tokens = config.num_vis_tokens
         self.geom_tokens = config.geom_tokens
+        # False = compute all L positions like the reference; True = drop the all-padding tail of the batch (same
+        # loss and gradients, fewer rows). Off by default so the dense figure stays comparable with the reference's.
+        self.trim_padding = bool(config.trim_padding)
         self._text_param_names = [n for n, _ in self.text_model.named_parameters()]
 
     # ------------------------------------------------------------------ loaders
@@ -245,7 +249,19 @@ class VGGTQwen3VLM(nn.Module):
             feats = vis
         S = feats.shape[1]
         feats16 = ops.cast(feats.contiguous(), BF16)
-        srcmap = self._srcmap(input_ids, S)
+        srcmap = self._srcmap(input_ids, S)          # on the full L: overruns raise exactly like the reference
+        if self.trim_padding:
+            # Exact shortcut: columns after the last attended / labelled position of the whole batch are padding for
+            # every row - masked as keys, never read as queries, no label - so they cannot change loss or gradients.
+            used = ((attention_mask != 0) | (labels != -100)).any(dim=0).nonzero()
+            L_eff = int(used.max().item()) + 1 if used.numel() else 1
+            L_eff = min(L, max(8, (L_eff + 7) // 8 * 8))
+            if L_eff < L:
+                input_ids = input_ids[:, :L_eff].contiguous()
+                attention_mask = attention_mask[:, :L_eff].contiguous()
+                labels = labels[:, :L_eff].contiguous()
+                srcmap = srcmap[:, :L_eff].contiguous()
+                L = L_eff
         emb = ops.embed_splice_fwd(input_ids.contiguous(), tm._w["embed"], feats16, srcmap, B, L, H, S)
         h_last, saved = tm.forward_hidden(emb, attention_mask, save=need_grad)
         loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad)
