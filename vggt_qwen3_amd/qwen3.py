@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import json
 import math
+import os
 from dataclasses import dataclass, field
 from pathlib import Path
 from typing import Dict, List, Optional, Tuple
@@ -96,6 +97,9 @@ class Qwen3ForCausalLM(nn.Module):
         self.nqkv = (self.Hq + 2 * self.Hkv) * D
         self.device_ = torch.device(device)
         self._rope_cache: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._wgrad_stream = None
+        if self.device_.type == "cuda" and os.environ.get("VQ3_WGRAD_STREAM", "1") != "0":
+            self._wgrad_stream = torch.cuda.Stream(device=self.device_)
         self._alloc(c.vocab_size, seed)
 
     # ------------------------------------------------------------------ storage
@@ -371,13 +375,30 @@ class Qwen3ForCausalLM(nn.Module):
     # ------------------------------------------------------------------ backward
     def _wgrad(self, name: str, dY: torch.Tensor, X: torch.Tensor, accumulate: bool):
         """dW[N,K] (+)= dY^T[N,M] . X[M,K]: both operands are transposed (zero-padded M) to make M the contiguous
-        contraction dim of the NT GEMM."""
-        M = dY.shape[0]
+        contraction dim of the NT GEMM. Weight gradients have no consumer inside the backward, so they are enqueued
+        on a second HIP stream: their transposes (HBM-bound) and GEMM tails overlap the dgrad chain on the main one."""
+        side = self._wgrad_stream
+        if side is None:
+            self._wgrad_now(name, dY, X, accumulate)
+            return
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._wgrad_now(name, dY, X, accumulate)
+        dY.record_stream(side)
+        X.record_stream(side)
+
+    def _wgrad_now(self, name: str, dY: torch.Tensor, X: torch.Tensor, accumulate: bool):
         dYt = ops.transpose2d(dY, 64)
         Xt = ops.transpose2d(X, 64)
         g = self._g[name]
         ops.gemm_raw(dYt, Xt, g, g.shape[0], g.shape[1], dYt.shape[1], dYt.shape[1], Xt.shape[1], g.shape[1],
                      accumulate=accumulate)
+
+    def join_wgrad_stream(self):
+        """Make the current stream wait for every weight-gradient kernel enqueued so far."""
+        if self._wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._wgrad_stream)
 
     def _norm_wgrad(self, name: str, dw_f32: torch.Tensor, accumulate: bool):
         ops.f32_to_bf16_acc(dw_f32, self._g[name], accumulate)
@@ -456,7 +477,9 @@ class Qwen3ForCausalLM(nn.Module):
             dh = ops.rmsnorm_bwd(d_xn1, ctx["h_in"], self._w[f"l{i}.ln1"], ctx["r1"], dh_mid, dw1)
             self._norm_wgrad(f"l{i}.ln1", dw1, accumulate)
             if layer_done is not None:
+                self.join_wgrad_stream()
                 layer_done(i)
+        self.join_wgrad_stream()
         return dh
 
     def backward_loss_head(self, head_ctx, rows: int, gscale: float, accumulate: bool) -> torch.Tensor:
