@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void vit_qkprep_kernel(const bf16_t* __restric
                                                          bf16_t* __restrict__ K, bf16_t* __restrict__ V, int N, int NH,
                                                          int P, int patch_start, int Wp, int use_norm, int use_rope,
                                                          float eps) {
+  // A wave handles two heads per pass (lanes 0-31 / 32-63), a lane two adjacent features (one 4-byte access):
+  // the LayerNorm sums stay inside a 32-lane half, the rotate-half partner of feature e is e^16 = lane^8.
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
   const long t = blockIdx.x;
   const long g = t / N;
   const int n = (int)(t - g * N);
@@ -59,33 +62,45 @@ __global__ __launch_bounds__(256) void vit_qkprep_kernel(const bf16_t* __restric
       px = (tp - patch_start) % Wp + 1;
     }
   }
-  const int pos = lane < 32 ? py : px;
-  const int f = lane & 31;
-  float c = 1.f, s = 0.f;
+  const int e0 = 2 * l32;                       // features e0, e0+1 of the head
+  const int pos = l32 < 16 ? py : px;
+  const int f0 = e0 & 31;
+  float c0 = 1.f, c1 = 1.f, s0 = 0.f, s1 = 0.f;
   if (use_rope) {
-    c = bf2f(cs[pos * 32 + f]);
-    s = bf2f(sn[pos * 32 + f]);
+    c0 = bf2f(cs[pos * 32 + f0]); c1 = bf2f(cs[pos * 32 + f0 + 1]);
+    s0 = bf2f(sn[pos * 32 + f0]); s1 = bf2f(sn[pos * 32 + f0 + 1]);
   }
-  for (int hh = wid; hh < 3 * NH; hh += 4) {
+  const bool neg = (l32 & 8) == 0;              // (e & 16) == 0 -> rotate-half takes -x[e+16]
+  for (int hp = wid; hp < (3 * NH) / 2; hp += 4) {
+    const int hh = 2 * hp + half;
     const int which = hh / NH, h = hh - which * NH;
-    float x = bf2f(row[which * C + h * 64 + lane]);
-    bf16_t* dst = (which == 0 ? Q : (which == 1 ? K : V)) + ((g * NH + h) * (long)N + n) * 64;
+    const uint32_t raw = *reinterpret_cast<const uint32_t*>(row + which * C + h * 64 + e0);
+    float x0 = bf2f((bf16_t)(raw & 0xffff)), x1 = bf2f((bf16_t)(raw >> 16));
+    bf16_t* dst = (which == 0 ? Q : (which == 1 ? K : V)) + ((g * NH + h) * (long)N + n) * 64 + e0;
     if (which < 2) {
       if (use_norm) {
-        const float mean = wave_sum(x) * (1.f / 64.f);
-        const float d = x - mean;
-        const float rs = rsqrtf(wave_sum(d * d) * (1.f / 64.f) + eps);
+        float sum = x0 + x1;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum * (1.f / 64.f);
+        const float d0 = x0 - mean, d1 = x1 - mean;
+        float sq = d0 * d0 + d1 * d1;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rs = rsqrtf(sq * (1.f / 64.f) + eps);
         const float* w = which == 0 ? qn_w : kn_w;
         const float* b = which == 0 ? qn_b : kn_b;
-        x = rbf(d * rs * w[lane] + b[lane]);
+        x0 = rbf(d0 * rs * w[e0] + b[e0]);
+        x1 = rbf(d1 * rs * w[e0 + 1] + b[e0 + 1]);
       }
       if (use_rope) {
-        const float partner = __shfl_xor(x, 16, 64);
-        const float rot = (f < 16) ? -partner : partner;
-        x = rbf(rbf(x * c) + rbf(rot * s));
+        const float p0 = __shfl_xor(x0, 8, 64), p1 = __shfl_xor(x1, 8, 64);
+        const float r0 = neg ? -p0 : p0, r1 = neg ? -p1 : p1;
+        x0 = rbf(rbf(x0 * c0) + rbf(r0 * s0));
+        x1 = rbf(rbf(x1 * c1) + rbf(r1 * s1));
       }
     }
-    dst[lane] = f2bf(x);
+    *reinterpret_cast<uint32_t*>(dst) = pack2bf(x0, x1);
   }
 }
 
@@ -101,9 +116,8 @@ __device__ __forceinline__ int fa_swz(int row, int chunk) { return row * 128 + (
 __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                               int N, int Np, int NH, long ldo, float scale_log2e) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * FA_KV * 128];
-  char* Ks = smem;
-  char* Vs = smem + FA_KV * 128;
+  // two stages of (K tile | V^T tile): tile t+1 is written while tile t is read -> one barrier per tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * FA_KV * 128];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const long nb = blockIdx.y;
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
   f32x16 o0, o1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;   // running max in the scaled (log2) domain
 
   // staging: 512 16-byte chunks per tile, 2 per thread: chunk id c = tid + 256*i -> row c>>3, chunk c&7
   const int srow0 = tid >> 3, sch = tid & 7;
@@ -139,7 +153,9 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
       vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (long)row * Np + t * FA_KV + sch * 8);
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    char* Ks = smem + buf * (2 * FA_KV * 128);
+    char* Vs = Ks + FA_KV * 128;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = srow0 + 32 * i;
@@ -147,12 +163,31 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
       *reinterpret_cast<u32x4*>(Vs + fa_swz(row, sch)) = vreg[i];
     }
   };
+  // lane-constant LDS offsets of the fragment reads (relative to the stage base)
+  int koff0[4], koff1[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    koff0[s] = fa_swz(r, 2 * s + h);
+    koff1[s] = fa_swz(32 + r, 2 * s + h);
+  }
+  int voffa[4][2], voffb[4][2];   // [sub*2+sp][run]
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int kb = 16 * u + 4 * h;
+#pragma unroll
+    for (int run = 0; run < 2; ++run) {
+      voffa[u][run] = FA_KV * 128 + fa_swz(r, (kb + 8 * run) >> 3) + ((kb & 7) << 1);
+      voffb[u][run] = FA_KV * 128 + fa_swz(32 + r, (kb + 8 * run) >> 3) + ((kb & 7) << 1);
+    }
+  }
+
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
     const bool more = t + 1 < nt;
+    const char* sb = smem + (t & 1) * (2 * FA_KV * 128);
     if (more) load_tile(t + 1);
     // ---- S^T = K . Q^T for the two 32-key sub-tiles
     f32x16 s0, s1;
@@ -160,29 +195,32 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
     for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Ks + fa_swz(r, 2 * s + h));
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Ks + fa_swz(32 + r, 2 * s + h));
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sb + koff0[s]);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sb + koff1[s]);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
     }
-    // ---- online softmax (per query column = per lane pair (lane, lane^32))
+    // ---- online softmax (per query column = per lane pair (lane, lane^32)); masking only on the last tile
     const int kbase = t * FA_KV;
-    float mx = -INFINITY;
+    if (kbase + FA_KV > N) {   // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int key0 = kbase + (i & 3) + 8 * (i >> 2) + 4 * h;
-      s0[i] = (key0 < N) ? s0[i] * scale_log2e : -INFINITY;
-      s1[i] = (key0 + 32 < N) ? s1[i] * scale_log2e : -INFINITY;
-      mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+      for (int i = 0; i < 16; ++i) {
+        const int key0 = kbase + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (key0 >= N) s0[i] = -INFINITY;
+        if (key0 + 32 >= N) s1[i] = -INFINITY;
+      }
     }
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx * scale_log2e);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float ps = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      s0[i] = exp2f(s0[i] - m_new);
-      s1[i] = exp2f(s1[i] - m_new);
+      s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], scale_log2e, -m_new));
+      s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], scale_log2e, -m_new));
       ps += s0[i] + s1[i];
     }
     ps += __shfl_xor(ps, 32, 64);
@@ -192,31 +230,20 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
     for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
     // ---- O^T += V^T . P^T : B operand = packed S^T registers 8s'..8s'+7 (k order: 16s' + 8(j>>2) + 4h + (j&3))
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int u = 0; u < 4; ++u) {   // u = sub*2 + sp
+      bf16x8 pf;
 #pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        bf16x8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(sub == 0 ? s0[8 * sp + j] : s1[8 * sp + j]);
-        // A operand = V^T fragment: lane (d = r [+32], h), element j <-> key 32*sub + 16*sp + 8*(j>>2) + 4h + (j&3)
-        const int kb = 32 * sub + 16 * sp + 4 * h;  // first run of 4 keys; second run at +8
-        bf16x8 va, vb;
-        {
-          const u32x2 a0 = *reinterpret_cast<const u32x2*>(Vs + fa_swz(r, kb >> 3) + ((kb & 7) << 1));
-          const u32x2 a1 = *reinterpret_cast<const u32x2*>(Vs + fa_swz(r, (kb + 8) >> 3) + ((kb & 7) << 1));
-          const u32x2 b0 = *reinterpret_cast<const u32x2*>(Vs + fa_swz(32 + r, kb >> 3) + ((kb & 7) << 1));
-          const u32x2 b1 = *reinterpret_cast<const u32x2*>(Vs + fa_swz(32 + r, (kb + 8) >> 3) + ((kb & 7) << 1));
-          u32x4 ta = {a0[0], a0[1], a1[0], a1[1]};
-          u32x4 tb = {b0[0], b0[1], b1[0], b1[1]};
-          va = __builtin_bit_cast(bf16x8, ta);
-          vb = __builtin_bit_cast(bf16x8, tb);
-        }
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf, o1, 0, 0, 0);
-      }
+      for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(u < 2 ? s0[8 * (u & 1) + j] : s1[8 * (u & 1) + j]);
+      const u32x2 a0 = *reinterpret_cast<const u32x2*>(sb + voffa[u][0]);
+      const u32x2 a1 = *reinterpret_cast<const u32x2*>(sb + voffa[u][1]);
+      const u32x2 b0 = *reinterpret_cast<const u32x2*>(sb + voffb[u][0]);
+      const u32x2 b1 = *reinterpret_cast<const u32x2*>(sb + voffb[u][1]);
+      const u32x4 ta = {a0[0], a0[1], a1[0], a1[1]};
+      const u32x4 tb = {b0[0], b0[1], b1[0], b1[1]};
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), pf, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1, 0, 0, 0);
     }
-    __syncthreads();
-    if (more) store_tile();
+    if (more) store_tile((t + 1) & 1);
     __syncthreads();
   }
 
@@ -261,7 +288,7 @@ extern "C" int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* q
                               int32_t Wp, int32_t use_norm, int32_t use_rope, float eps, void* stream) {
   VQ3_CHECK_ARG(qkv && Q && K && V, "vit_qkprep: null pointer");
   VQ3_CHECK_ARG(head_dim == 64, "vit_qkprep: head_dim must be 64, got %d", head_dim);
-  VQ3_CHECK_ARG(T > 0 && N > 0 && T % N == 0 && NH > 0, "vit_qkprep: bad shape");
+  VQ3_CHECK_ARG(T > 0 && N > 0 && T % N == 0 && NH > 0 && NH % 2 == 0, "vit_qkprep: bad shape (NH must be even)");
   VQ3_CHECK_ARG(!use_norm || (qn_w && qn_b && kn_w && kn_b), "vit_qkprep: norm weights missing");
   VQ3_CHECK_ARG(!use_rope || (cos && sin && tokens_per_frame > 0 && Wp > 0), "vit_qkprep: rope tables missing");
   hipLaunchKernelGGL(vit_qkprep_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, qn_w,
