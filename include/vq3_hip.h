@@ -66,9 +66,13 @@ int vq3_gemm_bf16_nt(const vq3_gemm_desc* desc, void* stream);
 int vq3_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int32_t cols, int64_t ldx,
                     int64_t ldy, float eps, void* stream);
 /* Backward of the above: dx = [dres +] rstd * (g - xhat * mean(g * xhat)), g = dy*w, xhat = x*rstd;
- * dw_f32[cols] += sum_rows dy * xhat (f32 atomics; caller zeroes dw_f32). dres may be NULL; dx may alias dres. */
+ * dw_part f32 [ceil(rows/4), cols] receives one partial row of sum(dy * xhat) per workgroup (plain stores, every row
+ * written); reduce it with vq3_colsum_f32_to_bf16. dres may be NULL; dx may alias dres. */
 int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
-                    float* dw_f32, int64_t rows, int32_t cols, float eps, void* stream);
+                    float* dw_part, int64_t rows, int32_t cols, float eps, void* stream);
+/* out_bf16[c] (+)= sum_{r < nrows} part[r*cols + c]: column sum of a partial slab into a (bf16) gradient vector. */
+int vq3_colsum_f32_to_bf16(const float* part, int32_t nrows, int32_t cols, void* out_bf16, int32_t accumulate,
+                           void* stream);
 
 /* torch.nn.LayerNorm (projector_perceiver.py:39-40; VGGT Block.norm1/norm2, q_norm/k_norm).
  * x: bf16 (x_f32=0) or f32 (x_f32=1) [rows, cols]; w,b f32 [cols]; y_bf16 and/or y_f32 may be NULL.
@@ -106,10 +110,10 @@ int vq3_qwen_qkprep_fwd(const void* qkv, const void* q_w, const void* k_w, const
                         void* K, void* V, float* q_rstd, float* k_rstd, int32_t B, int32_t L, int32_t Hq, int32_t Hkv,
                         int32_t D, float eps, void* stream);
 /* Backward: dQ,dK,dV (layouts as above) + saved qkv, rstd -> dqkv bf16 [B*L,(Hq+2Hkv)*D];
- * dq_w_f32[D], dk_w_f32[D] += (f32 atomics, caller zeroes). */
+ * dq_w_part, dk_w_part f32 [B*L, D]: one partial row per token (plain stores); reduce with vq3_colsum_f32_to_bf16. */
 int vq3_qwen_qkprep_bwd(const void* dQ, const void* dK, const void* dV, const void* qkv, const void* q_w,
                         const void* k_w, const void* cos, const void* sin, const float* q_rstd, const float* k_rstd,
-                        void* dqkv, float* dq_w_f32, float* dk_w_f32, int32_t B, int32_t L, int32_t Hq, int32_t Hkv,
+                        void* dqkv, float* dq_w_part, float* dk_w_part, int32_t B, int32_t L, int32_t Hq, int32_t Hkv,
                         int32_t D, void* stream);
 
 /* Masked softmax over the last dim. S f32 [nb, Lq, ldS] -> P bf16 [nb, Lq, ldP]; columns >= Lk (up to ldP) zeroed.

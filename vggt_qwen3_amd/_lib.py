@@ -36,6 +36,7 @@ SIGNATURES = {
     "vq3_gemm_bf16_nt": [C.POINTER(GemmDesc), c_p],
     "vq3_rmsnorm_fwd": [c_p, c_p, c_p, c_p, i64, i32, i64, i64, f32, c_p],
     "vq3_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
+    "vq3_colsum_f32_to_bf16": [c_p, i32, i32, c_p, i32, c_p],
     "vq3_layernorm_fwd": [c_p, c_p, i32, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "vq3_silu_mul_fwd": [c_p, c_p, i64, i32, c_p],
     "vq3_silu_mul_bwd": [c_p, c_p, c_p, i64, i32, c_p],

@@ -42,17 +42,18 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------- RMSNorm backward
-// 4 rows per block (one per wave; 300 blocks at M = 1200 fill the chip). A wave keeps its row's x / dy / w chunks in registers (one HBM read), and its
-// dw partials in registers across its rows; partials meet in LDS once per block, then one f32 atomic per column.
+// 4 rows per block (one per wave; 300 blocks at M = 1200 fill the chip). A wave keeps its row's x / dy / w chunks in
+// registers (one HBM read); the four waves' dw contributions meet in LDS and leave as ONE plain-store row of the
+// partial slab dw_part[blockIdx][cols] - no global atomics (300 blocks hammering one 10-KB row ran ~14x below the
+// atomic rate); vq3_colsum_f32_to_bf16 sums the slab straight into the bf16 gradient.
 constexpr int RB_ROWS = 4;
 template <int NCH>  // cols <= NCH * 512
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* dres, bf16_t* dx, float* __restrict__ dw,
                                                           long rows, int cols) {
-  extern __shared__ float dw_s[];
+  extern __shared__ __attribute__((aligned(16))) float dw_s[];   // [4 waves][cols]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < cols; c += 256) dw_s[c] = 0.f;
   float dwacc[NCH][8];
   bf16x8 wv[NCH];
 #pragma unroll
@@ -107,19 +108,46 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
       }
     }
   }
-  __syncthreads();
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const int c = lane * 8 + ch * 512;
     if (c < cols) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(&dw_s[c + j], dwacc[ch][j]);
+      *reinterpret_cast<f32x4*>(&dw_s[wid * cols + c]) = f32x4{dwacc[ch][0], dwacc[ch][1], dwacc[ch][2], dwacc[ch][3]};
+      *reinterpret_cast<f32x4*>(&dw_s[wid * cols + c + 4]) = f32x4{dwacc[ch][4], dwacc[ch][5], dwacc[ch][6], dwacc[ch][7]};
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < cols; c += 256) {
-    const float v = dw_s[c];
-    if (v != 0.f) atomicAdd(&dw[c], v);
+  float* out = dw + (long)blockIdx.x * cols;
+  for (int c = threadIdx.x; c < cols; c += 256)
+    out[c] = dw_s[c] + dw_s[cols + c] + dw_s[2 * cols + c] + dw_s[3 * cols + c];
+}
+
+// out_bf16[c] (+)= sum_r part[r][c]: 64 columns per block, 16 waves stride over the rows (4 independent loads in
+// flight per lane), LDS combine.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int nrows, int cols,
+                                                      bf16_t* __restrict__ out, int accumulate) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    int r = rg;
+    for (; r + 48 < nrows; r += 64) {
+      a0 += part[(long)r * cols + c];
+      a1 += part[(long)(r + 16) * cols + c];
+      a2 += part[(long)(r + 32) * cols + c];
+      a3 += part[(long)(r + 48) * cols + c];
+    }
+    for (; r < nrows; r += 16) a0 += part[(long)r * cols + c];
+  }
+  red[rg][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[i][lane];
+    if (accumulate) v += bf2f(out[c]);
+    out[c] = f2bf(v);
   }
 }
 
@@ -209,19 +237,17 @@ extern "C" int vq3_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
 extern "C" int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                                void* dx, float* dw_f32, int64_t rows, int32_t cols, float eps, void* stream) {
   (void)eps;
-  VQ3_CHECK_ARG(dy && x && w && rstd && dx && dw_f32, "rmsnorm_bwd: null pointer");
-  VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 16384, "rmsnorm_bwd: bad cols=%d", cols);
+  VQ3_CHECK_ARG(dy && x && w && rstd && dx && dw_f32, "rmsnorm_bwd: null pointer (dw_part must hold ceil(rows/4)*cols floats)");
+  VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "rmsnorm_bwd: bad cols=%d (<= 4096)", cols);
   const long nblk = (rows + RB_ROWS - 1) / RB_ROWS;
 #define VQ3_RB_LAUNCH(NCH)                                                                                           \
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel<NCH>, dim3((unsigned)nblk), dim3(256), cols * sizeof(float),                  \
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel<NCH>, dim3((unsigned)nblk), dim3(256), 4 * cols * sizeof(float),              \
                      (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd,               \
                      (const bf16_t*)dres, (bf16_t*)dx, dw_f32, (long)rows, cols)
   if (cols <= 512) VQ3_RB_LAUNCH(1);
   else if (cols <= 1024) VQ3_RB_LAUNCH(2);
   else if (cols <= 2560) VQ3_RB_LAUNCH(5);
-  else if (cols <= 4096) VQ3_RB_LAUNCH(8);
-  else if (cols <= 8192) VQ3_RB_LAUNCH(16);
-  else VQ3_RB_LAUNCH(32);
+  else VQ3_RB_LAUNCH(8);
 #undef VQ3_RB_LAUNCH
   VQ3_CHECK_LAUNCH("rmsnorm_bwd");
   return 0;
@@ -239,5 +265,14 @@ extern "C" int vq3_layernorm_fwd(const void* x, const void* res, int32_t x_f32, 
     hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, res, w,
                        b, (bf16_t*)y_bf16, y_f32, (long)rows, cols, eps);
   VQ3_CHECK_LAUNCH("layernorm_fwd");
+  return 0;
+}
+
+extern "C" int vq3_colsum_f32_to_bf16(const float* part, int32_t nrows, int32_t cols, void* out_bf16, int32_t accumulate,
+                                      void* stream) {
+  VQ3_CHECK_ARG(part && out_bf16 && nrows > 0 && cols > 0, "colsum: bad args");
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, nrows, cols,
+                     (bf16_t*)out_bf16, accumulate);
+  VQ3_CHECK_LAUNCH("colsum_f32_to_bf16");
   return 0;
 }

@@ -102,10 +102,11 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
   atomicAdd(&dw_s[1][lane], ak1);
   atomicAdd(&dw_s[1][lane + 64], ak2);
   __syncthreads();
+  // plain-store partial rows [token][D] (summed by vq3_colsum_f32_to_bf16): no contended global atomics
   if (threadIdx.x < D) {
-    atomicAdd(&dq_w[threadIdx.x], dw_s[0][threadIdx.x]);
+    dq_w[t * D + threadIdx.x] = dw_s[0][threadIdx.x];
   } else {
-    atomicAdd(&dk_w[threadIdx.x - D], dw_s[1][threadIdx.x - D]);
+    dk_w[t * D + threadIdx.x - D] = dw_s[1][threadIdx.x - D];
   }
 }
 

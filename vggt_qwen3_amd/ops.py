@@ -107,14 +107,19 @@ def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, want_rstd: bool = 
     return (y, rstd) if want_rstd else y
 
 
-def rmsnorm_bwd(dy, x, w, rstd, dres, dw_f32, eps: float = 0.0):
-    """Returns dx (bf16) = [dres +] d/dx; accumulates into dw_f32 (caller zeroes)."""
-    _req(dy, BF16, "rmsnorm_bwd dy"); _req(x, BF16, "rmsnorm_bwd x"); _req(dw_f32, F32, "rmsnorm_bwd dw")
+def rmsnorm_bwd(dy, x, w, rstd, dres, dw_out: torch.Tensor, accumulate: bool, eps: float = 0.0):
+    """Returns dx (bf16) = [dres +] d/dx; dw_out (bf16 [cols]) (+)= the weight gradient (partial slab + column sum)."""
+    _req(dy, BF16, "rmsnorm_bwd dy"); _req(x, BF16, "rmsnorm_bwd x"); _req(dw_out, BF16, "rmsnorm_bwd dw")
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
     rows, cols = x.shape
     dx = torch.empty_like(x)
-    check(_lib.load().vq3_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres),
-                                      dx.data_ptr(), dw_f32.data_ptr(), rows, cols, eps, _stream()), "vq3_rmsnorm_bwd")
+    nblk = (rows + 3) // 4
+    part = torch.empty((nblk, cols), device=x.device, dtype=F32)
+    lib = _lib.load()
+    check(lib.vq3_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres), dx.data_ptr(),
+                              part.data_ptr(), rows, cols, eps, _stream()), "vq3_rmsnorm_bwd")
+    check(lib.vq3_colsum_f32_to_bf16(part.data_ptr(), nblk, cols, dw_out.data_ptr(), 1 if accumulate else 0,
+                                     _stream()), "vq3_colsum_f32_to_bf16")
     return dx
 
 
@@ -226,14 +231,20 @@ def qwen_qkprep_fwd(qkv, q_w, k_w, cos, sin, B, L, Hq, Hkv, D, eps, want_rstd=Tr
     return Q, K, V, qr, kr
 
 
-def qwen_qkprep_bwd(dQ, dK, dV, qkv, q_w, k_w, cos, sin, qr, kr, dq_w_f32, dk_w_f32, B, L, Hq, Hkv, D):
+def qwen_qkprep_bwd(dQ, dK, dV, qkv, q_w, k_w, cos, sin, qr, kr, dq_w_out, dk_w_out, accumulate, B, L, Hq, Hkv, D):
+    """dq_w_out / dk_w_out: bf16 [D] gradient vectors, (+)= per `accumulate`."""
     for t in (dQ, dK, dV, qkv):
         _req(t, BF16, "qkprep_bwd"); assert t.is_contiguous()
     dqkv = torch.empty_like(qkv)
-    check(_lib.load().vq3_qwen_qkprep_bwd(dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), qkv.data_ptr(), q_w.data_ptr(),
-                                          k_w.data_ptr(), cos.data_ptr(), sin.data_ptr(), qr.data_ptr(), kr.data_ptr(),
-                                          dqkv.data_ptr(), dq_w_f32.data_ptr(), dk_w_f32.data_ptr(), B, L, Hq, Hkv, D,
-                                          _stream()), "vq3_qwen_qkprep_bwd")
+    part = torch.empty((2, B * L, D), device=qkv.device, dtype=F32)
+    lib = _lib.load()
+    check(lib.vq3_qwen_qkprep_bwd(dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), qkv.data_ptr(), q_w.data_ptr(),
+                                  k_w.data_ptr(), cos.data_ptr(), sin.data_ptr(), qr.data_ptr(), kr.data_ptr(),
+                                  dqkv.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), B, L, Hq, Hkv, D,
+                                  _stream()), "vq3_qwen_qkprep_bwd")
+    acc = 1 if accumulate else 0
+    check(lib.vq3_colsum_f32_to_bf16(part[0].data_ptr(), B * L, D, dq_w_out.data_ptr(), acc, _stream()), "colsum dq_w")
+    check(lib.vq3_colsum_f32_to_bf16(part[1].data_ptr(), B * L, D, dk_w_out.data_ptr(), acc, _stream()), "colsum dk_w")
     return dqkv
 
 

@@ -458,24 +458,19 @@ class Qwen3ForCausalLM(nn.Module):
             dgu = ops.silu_mul_bwd(d_act, ctx["gu"])
             d_xn2 = ops.linear(dgu, self._wt[f"l{i}.gu"])
             self._wgrad(f"l{i}.gu", dgu, ctx["xn2"], accumulate)
-            dw = torch.zeros(H, device=dev, dtype=F32)
-            dh_mid = ops.rmsnorm_bwd(d_xn2, ctx["h_mid"], self._w[f"l{i}.ln2"], ctx["r2"], dh, dw)
-            self._norm_wgrad(f"l{i}.ln2", dw, accumulate)
+            dh_mid = ops.rmsnorm_bwd(d_xn2, ctx["h_mid"], self._w[f"l{i}.ln2"], ctx["r2"], dh, self._g[f"l{i}.ln2"],
+                                     accumulate)
             # o_proj
             d_ao = ops.linear(dh_mid, self._wt[f"l{i}.o"])
             self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
             dQ, dK, dV = self._attention_bwd(i, ctx, d_ao, B, L)
-            dqw = torch.zeros(D, device=dev, dtype=F32)
-            dkw = torch.zeros(D, device=dev, dtype=F32)
             dqkv = ops.qwen_qkprep_bwd(dQ, dK, dV, ctx["qkv"], self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin,
-                                       ctx["qr"], ctx["kr"], dqw, dkw, B, L, self.Hq, self.Hkv, D)
-            self._norm_wgrad(f"l{i}.qn", dqw, accumulate)
-            self._norm_wgrad(f"l{i}.kn", dkw, accumulate)
+                                       ctx["qr"], ctx["kr"], self._g[f"l{i}.qn"], self._g[f"l{i}.kn"], accumulate, B, L,
+                                       self.Hq, self.Hkv, D)
             d_xn1 = ops.linear(dqkv, self._wt[f"l{i}.qkv"])
             self._wgrad(f"l{i}.qkv", dqkv, ctx["xn1"], accumulate)
-            dw1 = torch.zeros(H, device=dev, dtype=F32)
-            dh = ops.rmsnorm_bwd(d_xn1, ctx["h_in"], self._w[f"l{i}.ln1"], ctx["r1"], dh_mid, dw1)
-            self._norm_wgrad(f"l{i}.ln1", dw1, accumulate)
+            dh = ops.rmsnorm_bwd(d_xn1, ctx["h_in"], self._w[f"l{i}.ln1"], ctx["r1"], dh_mid, self._g[f"l{i}.ln1"],
+                                 accumulate)
             if layer_done is not None:
                 self.join_wgrad_stream()
                 layer_done(i)
@@ -497,9 +492,7 @@ class Qwen3ForCausalLM(nn.Module):
         hnt = ops.transpose2d(head_ctx["hn"], 64)
         ops.gemm_raw(dlt, hnt, self._g["embed"], self.vocab, H, dlt.shape[1], dlt.shape[1], hnt.shape[1], H,
                      accumulate=accumulate, alpha=gscale)
-        dw = torch.zeros(H, device=dev, dtype=F32)
-        d_hs = ops.rmsnorm_bwd(d_hn, head_ctx["hs"], self._w["norm"], head_ctx["rstd"], None, dw)
-        self._norm_wgrad("norm", dw, accumulate)
+        d_hs = ops.rmsnorm_bwd(d_hn, head_ctx["hs"], self._w["norm"], head_ctx["rstd"], None, self._g["norm"], accumulate)
         dh = torch.zeros((rows, H), device=dev, dtype=BF16)
         ops.scatter_rows(d_hs, head_ctx["idx"], dh, n, False)
         return dh
