@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--geom", action="store_true", help="geometry tokens on (config C4)")
     ap.add_argument("--trim-pad", action="store_true",
                     help="drop the all-padding tail of the batch (exact; NOT the default: fewer FLOPs are executed)")
+    ap.add_argument("--vision-prefetch", action="store_true",
+                    help="run the (frozen) vision tower one micro-batch ahead on a second stream (measured: no gain "
+                         "on a saturated GPU; off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=36, help="debug only; anything but 36 marks the line invalid")
     args = ap.parse_args()
@@ -156,8 +159,11 @@ def main():
         local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = bool(os.environ.get("VQ3_FORCE_DIST"))   # exercise the RCCL path even with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("VQ3_DIST_BACKEND", "nccl")   # "gloo" only to rehearse N ranks on one GPU
         if backend == "nccl":
@@ -192,8 +198,10 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
+    use_dist = world > 1 or force_dist
+
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -202,18 +210,19 @@ def main():
     # also pays the one-time costs (LDS attribute setup, allocator growth, RCCL channel setup)
     nwarm = max(args.warmup, 1)
     trainer.grad_accum = nwarm
+    nxt = batch if args.vision_prefetch else None   # next micro-batch's (frozen) vision forward overlaps this one
     for _ in range(nwarm):
-        loss = trainer.micro_step(batch)
+        loss = trainer.micro_step(batch, nxt)
     trainer.grad_accum = accum
     assert trainer.micro % nwarm == 0
     trainer.micro = 0
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.micro_step(batch)
+        loss = trainer.micro_step(batch, nxt)   # K vision forwards + K text fwd/bwd inside the window
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -255,7 +264,7 @@ def main():
         trainer.grad_accum = 1
         trainer.micro = 0
         trainer.micro_step(batch)  # keep collectives matched across ranks
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     if rank == 0:
@@ -269,7 +278,7 @@ def main():
                                     "weights" % (args.image_size, V)),
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": L, "views": V,
                        "grad_accum": accum, "optimizer_steps_timed": args.steps // accum, "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
-                       "trim_padding": bool(args.trim_pad), "qwen_layers": args.layers, "valid": args.layers == 36},
+                       "trim_padding": bool(args.trim_pad), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),
             "algorithmic_tflop_per_sample": round(tf_train, 3),
             "model_flops_utilisation": round(value * tf_train / (world * BF16_DENSE_PEAK_TFLOPS), 4),
@@ -282,7 +291,7 @@ def main():
             except Exception as e:  # the baseline is reported-only; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

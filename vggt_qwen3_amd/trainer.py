@@ -41,7 +41,8 @@ class Stage1Trainer:
         self.max_steps = max_steps
         self.warmup = int(warmup_ratio * max_steps)
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.dist_on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.dist_on else 1
         self.micro = 0       # micro-batches seen (the reference's `step`)
         self.opt_step = 0    # optimiser / scheduler steps
         dev = self.tm.flat_w.device
@@ -62,12 +63,12 @@ class Stage1Trainer:
         # the tied embedding last (its gradient is completed by the embedding backward at the very end)
         self.buckets, self.embed_span = dp.plan_buckets(self.tm.table, self.tm.config.num_hidden_layers, bucket_layers)
         dp.check_cover(self.buckets, self.embed_span, n)
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.dist_on else None
         self._works: List = []
 
     # ------------------------------------------------------------------ communication
     def _allreduce_span(self, lo: int, hi: int):
-        if self.world == 1:
+        if not self.dist_on:
             return
         self.comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
@@ -78,15 +79,19 @@ class Stage1Trainer:
             self._allreduce_span(*self.buckets[i])
 
     # ------------------------------------------------------------------ one micro-batch
-    def micro_step(self, batch: dict) -> torch.Tensor:
-        """forward + backward (+ gradient all-reduce, AdamW, schedule on accumulation boundaries). Returns the loss."""
+    def micro_step(self, batch: dict, next_batch: Optional[dict] = None) -> torch.Tensor:
+        """forward + backward (+ gradient all-reduce, AdamW, schedule on accumulation boundaries). Returns the loss.
+        next_batch (optional): its frozen vision-tower forward is enqueued on a second stream now, overlapping this
+        micro-batch's text forward/backward; pass the same dict to the next call."""
         model, tm = self.model, self.tm
+        if next_batch is not None:
+            model.prefetch_images(next_batch["pixel_values"])
         k = self.micro % self.grad_accum
         boundary = (k == self.grad_accum - 1)
         accumulate = k != 0
         st = model.forward_state(batch["pixel_values"], batch.get("geom_token"), batch["input_ids"],
                                  batch["attention_mask"], batch["labels"], need_grad=True)
-        hook = self._layer_done if (boundary and self.world > 1) else None
+        hook = self._layer_done if (boundary and self.dist_on) else None
         d_geom = model._backward_text(st, 1.0 / self.grad_accum, accumulate, layer_done=hook)
         if d_geom is not None:
             g = model.geom_head_backward(st, d_geom)
@@ -104,7 +109,7 @@ class Stage1Trainer:
 
     def _optimizer_step(self):
         tm = self.tm
-        if self.world > 1:
+        if self.dist_on:
             self._allreduce_span(*self.embed_span)
             if self._geom_has_grad:
                 dist.all_reduce(self.geom_grad, op=dist.ReduceOp.SUM, group=self.pg)

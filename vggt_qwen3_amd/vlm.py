@@ -155,6 +155,8 @@ class VGGTQwen3VLM(nn.Module):
         # False = compute all L positions like the reference; True = drop the all-padding tail of the batch (same
         # loss and gradients, fewer rows). Off by default so the dense figure stays comparable with the reference's.
         self.trim_padding = bool(config.trim_padding)
+        self._vis_stream = None
+        self._prefetched = None
         self._text_param_names = [n for n, _ in self.text_model.named_parameters()]
 
     # ------------------------------------------------------------------ loaders
@@ -198,6 +200,28 @@ class VGGTQwen3VLM(nn.Module):
             agg = agg.reshape(B, -1, agg.shape[-1])[:, : self.num_vis_tokens, :]
         return self.projector(agg.contiguous())
 
+    def prefetch_images(self, images: torch.Tensor) -> None:
+        """Run encode_images for a FUTURE batch on a second HIP stream: the vision tower is frozen and under no_grad
+        in the reference (vggt_qwen3_vlm.py:44-45,128), so its forward for micro-batch t+1 is independent of the text
+        model's forward/backward of micro-batch t and can fill the CUs those GEMMs leave idle. The result is picked up
+        by forward_state() when it is called with the same tensor object."""
+        if self._vis_stream is None:
+            self._vis_stream = torch.cuda.Stream(device=self.device_)
+        images = images.to(self.device_)
+        self._vis_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._vis_stream):
+            vis = self.encode_images(images)
+        self._prefetched = (images, vis)
+
+    def _take_prefetched(self, images: torch.Tensor) -> Optional[torch.Tensor]:
+        pf = self._prefetched
+        if pf is None or pf[0] is not images:
+            return None
+        self._prefetched = None
+        torch.cuda.current_stream().wait_stream(self._vis_stream)
+        pf[1].record_stream(torch.cuda.current_stream())
+        return pf[1]
+
     def _geom_inputs(self, geom_token) -> Optional[torch.Tensor]:
         if not geom_token or self.geom_tokens == 0:
             return None
@@ -239,7 +263,10 @@ class VGGTQwen3VLM(nn.Module):
         attention_mask = attention_mask.to(self.device_)
         labels = labels.to(self.device_)
         B, L = input_ids.shape
-        vis = self.encode_images(images.to(self.device_))                                     # [B, Nv, H] fp32
+        images = images.to(self.device_)
+        vis = self._take_prefetched(images)
+        if vis is None:
+            vis = self.encode_images(images)                                                  # [B, Nv, H] fp32
         gfeat = self._geom_inputs(geom_token)
         geom_ctx, gy = None, None
         if gfeat is not None:
