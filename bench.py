@@ -233,6 +233,7 @@ def main():
     roof = None
     if rank == 0:
         ops.GEMM_PROFILE = []
+        model.text_model._wgrad_stream = None   # serial launches: per-launch event times are not inflated by overlap
         trainer.grad_accum = 1
         trainer.micro = 0
         trainer.micro_step(batch)

@@ -38,7 +38,10 @@ const char* vq3_target_arch(void);
  * Epilogue order: v = alpha*acc; v += bias[n]; (round to bf16 if C is bf16); v = act(v); v *= colscale[n];
  *                 v += R[m,n]; v += C[m,n] if accumulate; store.
  * Batches: blockIdx.z = b1*nb2 + b2; A += b1*sA1 + b2*sA2; B += b1*sB1 + (b2/b2divB)*sB2; C,R alike (no div).
- * Requirements: K % 64 == 0, lda/ldb % 8 == 0, A/B 16-byte aligned.
+ * General form: C[m,n] = epilogue(alpha * sum_k opA(A)[m,k] * opB(B)[n,k]); transA/transB select k-major operands, so
+ * dgrad (dX = dY . W), wgrad (dW = dY^T . X) and P.V products need no transposed copies.
+ * Requirements: K % 8 == 0 (K % 64 == 0 takes the fastest path), lda/ldb % 8 == 0, A/B 16-byte aligned, and the
+ * M (resp. N) extent of a k-major A (resp. B) a multiple of 8.
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct vq3_gemm_desc {
   const void* A;        /* bf16 [M, lda] */
@@ -54,6 +57,8 @@ typedef struct vq3_gemm_desc {
   int32_t out_f32;    /* 0: C/R bf16, 1: C/R f32 */
   int32_t accumulate; /* C += */
   float alpha;
+  int32_t transA;     /* 0: A is [M, lda] (contraction contiguous); 1: A is [K, lda] ("k-major", element (m,k) at k*lda+m) */
+  int32_t transB;     /* 0: B is [N, ldb]; 1: B is [K, ldb] */
 } vq3_gemm_desc;
 
 int vq3_gemm_bf16_nt(const vq3_gemm_desc* desc, void* stream);

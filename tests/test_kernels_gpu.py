@@ -103,7 +103,7 @@ def test_gemm_rejects_bad_args(ops):
     from vggt_qwen3_amd._lib import Vq3Error
     A = _rand((16, 100), seed=1); W = _rand((16, 100), seed=2)
     with pytest.raises(Vq3Error):
-        ops.linear(A, W)  # K % 64 != 0
+        ops.linear(A, W)  # K % 8 != 0
 
 
 # ------------------------------------------------------------------------------------------ norms
@@ -322,3 +322,57 @@ def test_adamw(ops):
         ops.adamw_step(p, m, v, g, w, 1e-3, 0.9, 0.999, 1e-8, 0.1, step)
     assert _maxerr(p, ref_p.data) < 1e-5, _maxerr(p, ref_p.data)
     assert torch.equal(w, p.to(BF16))
+
+
+# ------------------------------------------------------------------------------------------ GEMM v3: operand layouts, K tails
+@pytest.mark.parametrize("tA,tB", [(False, True), (True, False), (True, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1200, 2560, 1200), (200, 128, 200), (2560, 9728, 1200),
+                                   (136, 264, 72), (6144, 2560, 1208)])
+def test_gemm_layouts_and_k_tail(ops, tA, tB, M, N, K):
+    if K % 64 == 0 and not (tA or tB):
+        pytest.skip("plain NT with full K tiles is covered by test_gemm_shapes")
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(BF16).cuda()
+    Bm = torch.randn(N, K, generator=g).to(BF16).cuda()
+    ref = A.float() @ Bm.float().t()
+    a_op = A.t().contiguous() if tA else A            # k-major: [K, M]
+    b_op = Bm.t().contiguous() if tB else Bm
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=F32)
+    ops.gemm_raw(a_op, b_op, out, M, N, K, a_op.stride(0), b_op.stride(0), N, transA=tA, transB=tB)
+    e = _relerr(out, ref)
+    assert e < 2e-6 * math.sqrt(K) + 1e-6, f"tA={tA} tB={tB} rel err {e}"
+
+
+def test_gemm_kmajor_identity_asymmetric(ops):
+    """Exact-integer check of the transposed-read fragment maps (k order, row/col) for both k-major operands."""
+    K, M, N = 128, 128, 256
+    A = torch.eye(K, dtype=F32)[:M].to(BF16).cuda()                      # [M, K] = I
+    Bm = (torch.arange(N * K, dtype=F32).reshape(N, K) % 251 - 125).to(BF16).cuda()
+    ref = A.float() @ Bm.float().t()
+    for tA, tB in ((True, True), (True, False), (False, True)):
+        a_op = A.t().contiguous() if tA else A
+        b_op = Bm.t().contiguous() if tB else Bm
+        out = torch.empty((M, N), device="cuda", dtype=F32)
+        ops.gemm_raw(a_op, b_op, out, M, N, K, a_op.stride(0), b_op.stride(0), N, transA=tA, transB=tB)
+        assert torch.equal(out, ref), (tA, tB, _maxerr(out, ref))
+
+
+def test_gemm_kmajor_batched_attention_shapes(ops):
+    """dK = sum_g dS^T Q with the (group, query) pair as the contraction and P.V with V as stored (no transposes)."""
+    Bz, Hq, Hkv, L, D, Lp = 2, 8, 2, 200, 128, 256
+    G = Hq // Hkv
+    dS = _rand((Bz, Hq, L, Lp), 0.2, seed=31); dS[..., L:] = 0
+    Q = _rand((Bz, Hq, L, D), 1.0, seed=32)
+    dK = torch.empty((Bz, Hkv, L, D), device="cuda", dtype=F32)
+    # A = dS[b, kv*G:(kv+1)*G] viewed as k-major [G*L, Lp] (M = L keys), B = Q[b, kv*G..] as k-major [G*L, D]
+    ops.gemm_raw(dS, Q, dK, L, D, G * L, Lp, D, D, nb1=Bz, nb2=Hkv, sA=(Hq * L * Lp, G * L * Lp),
+                 sB=(Hq * L * D, G * L * D), sC=(Hkv * L * D, L * D), transA=True, transB=True)
+    ref = torch.einsum("bkgqj,bkgqd->bkjd", dS.float().view(Bz, Hkv, G, L, Lp)[..., :L], Q.float().view(Bz, Hkv, G, L, D))
+    assert _relerr(dK, ref) < 1e-5
+    P = _rand((Bz, Hq, L, Lp), 0.1, seed=33); P[..., L:] = 0
+    V = _rand((Bz, Hkv, L, D), 1.0, seed=34)
+    O = torch.zeros((Bz, L, Hq * D), device="cuda", dtype=F32)
+    ops.gemm_raw(P, V, O, L, D, L, Lp, D, Hq * D, nb1=Bz, nb2=Hq, b2divB=G, sA=(Hq * L * Lp, L * Lp),
+                 sB=(Hkv * L * D, L * D), sC=(L * Hq * D, D), transB=True)
+    ref = torch.einsum("bhlm,bhmd->blhd", P.float()[..., :L], V.float().repeat_interleave(G, 1)).reshape(Bz, L, Hq * D)
+    assert _relerr(O, ref) < 1e-5

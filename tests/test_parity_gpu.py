@@ -45,7 +45,7 @@ def test_qwen3_tiny_forward_backward_vs_hf_golden():
     # first layer output
     e = relerr(saved["layers"][1]["h_in"].view(B, L, H)[valid], bf16(z["hidden_1"])[valid.cpu()])
     assert e < 1e-2, f"layer-0 output rel err {e}"
-    loss, head = model.loss_head(h_last, labels, save=True)
+    loss, head = model.loss_head(h_last, labels, save=True, L=saved["L"])
     assert abs(loss.item() - float(z["loss"])) < 5e-3 * abs(float(z["loss"])), (loss.item(), float(z["loss"]))
     dh = model.backward_loss_head(head, B * L, 1.0, accumulate=False)
     d_emb = model.backward_hidden(saved, dh, accumulate=False)

@@ -169,9 +169,12 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   VQ3_CHECK_ARG(d != nullptr, "gemm: null descriptor");
   VQ3_CHECK_ARG(d->A && d->B && d->C, "gemm: null operand pointer");
   VQ3_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
-  VQ3_CHECK_ARG(d->K % BK == 0, "gemm: K=%d must be a multiple of %d (pad operands with zeros)", d->K, BK);
+  VQ3_CHECK_ARG(d->K % 8 == 0 && d->K >= 8, "gemm: K=%d must be a positive multiple of 8", d->K);
   VQ3_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm: lda=%d / ldb=%d must be multiples of 8", d->lda, d->ldb);
-  VQ3_CHECK_ARG(d->lda >= d->K && d->ldb >= d->K, "gemm: leading dims smaller than K");
+  VQ3_CHECK_ARG(d->lda >= (d->transA ? d->M : d->K) && d->ldb >= (d->transB ? d->N : d->K),
+                "gemm: leading dims smaller than the operand's inner extent");
+  VQ3_CHECK_ARG(!d->transA || (d->M % 8 == 0), "gemm: a k-major A needs M %% 8 == 0 (M=%d)", d->M);
+  VQ3_CHECK_ARG(!d->transB || (d->N % 8 == 0), "gemm: a k-major B needs N %% 8 == 0 (N=%d)", d->N);
   VQ3_CHECK_ARG(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0), "gemm: A/B must be 16-byte aligned");
   VQ3_CHECK_ARG(d->sA1 % 8 == 0 && d->sA2 % 8 == 0 && d->sB1 % 8 == 0 && d->sB2 % 8 == 0,
                 "gemm: batch strides of A/B must be multiples of 8 elements");
@@ -198,6 +201,13 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
 
   hipStream_t s = (hipStream_t)stream;
   const int nbatch = d->nb1 * d->nb2;
+  if (d->transA || d->transB || d->K % BK != 0) {
+    const long tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * nbatch;
+    const int rc = launch_gemm_v3(p, d->transA, d->transB, tiles <= 256 ? 3 : 2, nbatch, s);
+    if (rc) return rc;
+    VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3)");
+    return 0;
+  }
   const int cfg = choose_config(d->M, d->N, d->K, nbatch);
   if (cfg >= 0) {
     const int rc = launch_gemm_v2(p, cfg, nbatch, s);

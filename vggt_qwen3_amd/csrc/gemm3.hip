@@ -1,0 +1,294 @@
+// GEMM v3 for gfx950: the v2 LDS-DMA pipeline (gemm2.hip) generalised to every operand layout, so that no dgrad,
+// wgrad or attention product needs a transposed copy in HBM:
+//     C[M,N] = epilogue(alpha * sum_k opA(A)[m,k] * opB(B)[n,k])
+//     transA = 0: A[m*lda + k]  (contraction contiguous)      transA = 1: A[k*lda + m]  ("k-major")
+//     transB = 0: B[n*ldb + k]                                  transB = 1: B[k*ldb + n]
+// and K only has to be a multiple of 8 (the tail of the last 64-deep tile is zero-filled in LDS on the A side and
+// read from clamped, finite addresses on the B side).
+//
+// A k-major 64(k) x 128 tile is DMA'd as 16 pieces of 4 k-rows x 256 B. MFMA fragments need 8 consecutive k for one
+// m (a COLUMN of that image): they come from ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of a
+// 4-row x 16-column block - two of them per fragment, no transposed copy anywhere. Bank conflicts: a 32-lane half
+// reads 2 groups x 4 rows at one column offset; the 32-byte segment index is XORed with (k&3) | ((k>>3)&1)<<2 (again
+// on the DMA SOURCE address, the LDS image being lane-linear), which spreads those 8 (row, group) pairs over all
+// eight 32-byte segments of the 256-byte bank row: conflict-free.
+// Tile 128x128x64, 8 waves (4x2, 32x64 per wave), 2 stages x 2 workgroups/CU or 3-stage ring x 1 workgroup/CU.
+#include "gemm_common.h"
+
+namespace vq3gemm {
+namespace {
+
+constexpr int BK = 64, BM = 128, BN = 128;
+constexpr int OPB = BM * BK * 2;  // bytes per operand tile (16 KiB)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ds_read_b64_tr_b16 through inline asm, NOT through __builtin_amdgcn_ds_read_tr16_b64: with the builtin hipcc
+// (ROCm 7.2) orders the read behind every in-flight LDS-DMA and emits s_waitcnt vmcnt(0) in front of it in each K step
+// (it does not do that for plain ds_read_b128), which drains the prefetch pipeline (measured: -35 % on the dgrad
+// shapes). The asm read is invisible to the waitcnt pass, so its completion is waited for by hand: one
+// s_waitcnt lgkmcnt(0) + sched_barrier(0) in front of the MFMAs that consume the fragments (LDS returns in order, so
+// mixing with compiler-counted ds_read_b128 is only ever conservative).
+template <int OFF>
+__device__ __forceinline__ u32x2 ds_tr(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ void tr_frag(unsigned addr, u32x2& lo, u32x2& hi) {
+  lo = ds_tr<OFF>(addr);
+  hi = ds_tr<OFF + 4 * 256>(addr);
+}
+__device__ __forceinline__ bf16x8 join(const u32x2& lo, const u32x2& hi) {
+  const u32x4 t = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, t);
+}
+
+template <int WM, int WN, int NSTAGE, bool AKM, bool BKM, bool OUT_F32>
+__global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) void gemm_v3_kernel(GemmParams p) {
+  constexpr int NW = WM * WN, NT = 64 * NW;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr int STAGE = 2 * OPB;
+  constexpr int PPW = 32 / NW;  // 16 A pieces + 16 B pieces per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  int m0, n0;
+  tile_coords(p, BM, BN, m0, n0);
+  const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
+  const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
+  const bf16_t* B = p.B + b1 * p.sB1 + (long)(b2 / p.b2divB) * p.sB2;
+  const long coff = b1 * p.sC1 + b2 * p.sC2;
+  const long roff = b1 * p.sR1 + b2 * p.sR2;
+  const int K = p.K;
+  const int nt = (K + BK - 1) / BK, last = nt - 1;
+  const int krem = K & (BK - 1);  // 0 or a multiple of 8: valid depth of the last tile
+
+  // ---- DMA sources. piece index within an operand: po = (wid + NW*j) & 15; j < PPW/2 -> A, else B.
+  // tile_ptr(op, piece, tile): per-lane source address of that piece.
+  auto src_ptr = [&](bool isA, int po, int tile) -> const bf16_t* {
+    const bf16_t* base = isA ? A : B;
+    const long ld = isA ? p.lda : p.ldb;
+    const int ext = isA ? p.M : p.N, x0 = isA ? m0 : n0;
+    const bool km = isA ? AKM : BKM;
+    if (!km) {
+      const int prow = lane >> 3;
+      int r = x0 + po * 8 + prow; r = r < ext ? r : ext - 1;
+      int k = tile * BK + (((lane & 7) ^ prow) << 3);
+      k = k <= K - 8 ? k : K - 8;                       // tail: clamp to the last valid 16-byte chunk (finite data)
+      return base + (long)r * ld + k;
+    } else {
+      const int krow = po * 4 + (lane >> 4);            // 0..63
+      const int pc = lane & 15;
+      const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int lchunk = (((pc >> 1) ^ f) << 1) | (pc & 1);
+      int col = x0 + lchunk * 8; col = col <= ext - 8 ? col : ext - 8;
+      int k = tile * BK + krow; k = k < K ? k : K - 1;  // tail rows: re-read the last valid row
+      return base + (long)k * ld + col;
+    }
+  };
+  auto issue = [&](int tile, int stage) {
+    char* sb = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const bool isA = j < PPW / 2;
+      const int po = (wid + NW * j) & 15;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_ptr(isA, po, tile),
+                                       (__attribute__((address_space(3))) void*)(sb + (isA ? 0 : OPB) + po * 1024), 16,
+                                       0, 0);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment read offsets
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[TM], b_off[TN];
+  {
+    // k-major: addr = (32ks + 4r + 8q + (li>>2)) * 256 + ((seg ^ fl) << 5) + lane_part
+    const int li = fr;
+    const int fl = (li >> 2) | ((fq & 1) << 2);
+    const int lane_part = (((li >> 1) & 1) << 4) | ((li & 1) << 3);
+    const int krow_base = 8 * fq + (li >> 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (BM / WM) + i * 16;
+      if (AKM) a_off[i] = krow_base * 256 + ((((row >> 4)) ^ fl) << 5) + lane_part;
+      else { const int rr = row + fr; a_off[i] = rr * 128 + ((fq ^ (rr & 7)) << 4); }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * (BN / WN) + j * 16;
+      if (BKM) b_off[j] = OPB + krow_base * 256 + ((((row >> 4)) ^ fl) << 5) + lane_part;
+      else { const int rr = row + fr; b_off[j] = OPB + rr * 128 + ((fq ^ (rr & 7)) << 4); }
+    }
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto compute = [&](int stage) {
+    const char* sb = smem + stage * STAGE;
+    const unsigned sa = lds0 + stage * STAGE;
+    // all fragment reads of both k-steps first (k-major operands by asm, the others by the compiler), one wait, MFMAs
+    u32x2 alo[2][TM], ahi[2][TM], blo[2][TN], bhi[2][TN];
+    bf16x8 xa[2][TM], wb[2][TN];
+    if (AKM) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        tr_frag<0>(sa + a_off[i], alo[0][i], ahi[0][i]);
+        tr_frag<32 * 256>(sa + a_off[i], alo[1][i], ahi[1][i]);
+      }
+    }
+    if (BKM) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        tr_frag<0>(sa + b_off[j], blo[0][j], bhi[0][j]);
+        tr_frag<32 * 256>(sa + b_off[j], blo[1][j], bhi[1][j]);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (!AKM) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[ks][i] = *reinterpret_cast<const bf16x8*>(sb + (a_off[i] ^ (ks << 6)));
+      }
+      if (!BKM) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wb[ks][j] = *reinterpret_cast<const bf16x8*>(sb + (b_off[j] ^ (ks << 6)));
+      }
+    }
+    if (AKM || BKM) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (AKM) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[ks][i] = join(alo[ks][i], ahi[ks][i]);
+      }
+      if (BKM) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wb[ks][j] = join(blo[ks][j], bhi[ks][j]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks][j], xa[ks][i], acc[i][j], 0, 0, 0);
+    }
+  };
+  // zero the k >= krem part of the A tile of the LAST stage (B's tail holds finite duplicates: 0 * finite = 0)
+  auto zero_tail = [&](int stage) {
+    char* sa = smem + stage * STAGE;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (AKM) {
+      const int n16 = (BK - krem) * 16;
+      for (int idx = tid; idx < n16; idx += NT) *reinterpret_cast<u32x4*>(sa + krem * 256 + idx * 16) = z;
+    } else {
+      const int c0 = krem >> 3, nch = 8 - c0;
+      for (int idx = tid; idx < BM * nch; idx += NT) {
+        const int row = idx & (BM - 1), kc = c0 + idx / BM;
+        *reinterpret_cast<u32x4*>(sa + row * 128 + ((kc ^ (row & 7)) << 4)) = z;
+      }
+    }
+    __syncthreads();
+  };
+
+  // The last K tile is peeled out of the loop: its zero-fill does LDS stores, and with LDS stores inside the loop
+  // hipcc orders every fragment read behind the in-flight LDS-DMA (s_waitcnt vmcnt(0) per K step), which drains the
+  // prefetch pipeline. The steady-state loop touches LDS by DMA and ds_read only.
+  if (NSTAGE == 3) {
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    int stage = 0;
+    for (int t = 0; t < last; ++t) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 <= last) {
+        int s2 = stage + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
+        issue(t + 2, s2);
+      }
+      compute(stage);
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (krem) zero_tail(stage);
+    compute(stage);
+  } else {
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < last; ++t) {
+      issue(t + 1, (t + 1) & 1);
+      compute(t & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (krem) zero_tail(last & 1);
+    compute(last & 1);
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / WM) + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / WN) + j * 16 + 4 * fq;
+      if (n >= p.N) continue;
+      store_quad<OUT_F32>(p, coff, roff, m, n, acc[i][j]);
+    }
+  }
+}
+
+template <int NSTAGE, bool AKM, bool BKM>
+int launch_v3(GemmParams& p, int nbatch, hipStream_t stream) {
+  constexpr int SMEM = NSTAGE * 2 * OPB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v3_kernel<4, 2, NSTAGE, AKM, BKM, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v3_kernel<4, 2, NSTAGE, AKM, BKM, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      vq3_set_error("gemm v3: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      return 2;
+    }
+    attr_done = true;
+  }
+  p.mtiles = (p.M + BM - 1) / BM;
+  p.ntiles = (p.N + BN - 1) / BN;
+  dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
+  if (p.out_f32)
+    hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, AKM, BKM, true>), grid, dim3(512), SMEM, stream, p);
+  else
+    hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, AKM, BKM, false>), grid, dim3(512), SMEM, stream, p);
+  return 0;
+}
+
+}  // namespace
+
+int launch_gemm_v3(GemmParams& p, int transA, int transB, int nstage, int nbatch, hipStream_t stream) {
+  const int sel = (nstage == 3 ? 4 : 0) | (transA ? 2 : 0) | (transB ? 1 : 0);
+  switch (sel) {
+    case 0: return launch_v3<2, false, false>(p, nbatch, stream);
+    case 1: return launch_v3<2, false, true>(p, nbatch, stream);
+    case 2: return launch_v3<2, true, false>(p, nbatch, stream);
+    case 3: return launch_v3<2, true, true>(p, nbatch, stream);
+    case 4: return launch_v3<3, false, false>(p, nbatch, stream);
+    case 5: return launch_v3<3, false, true>(p, nbatch, stream);
+    case 6: return launch_v3<3, true, false>(p, nbatch, stream);
+    default: return launch_v3<3, true, true>(p, nbatch, stream);
+  }
+}
+
+}  // namespace vq3gemm

@@ -148,5 +148,7 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, long coff, long 
 
 // v2 (LDS-DMA pipelined) launcher, defined in gemm2.hip. cfg: 0 = 256x128 tile, 1 = 128x256, 2 = 128x128.
 int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream);
+// v3 (any operand layout, K % 8 == 0), defined in gemm3.hip. nstage: 2 or 3.
+int launch_gemm_v3(GemmParams& p, int transA, int transB, int nstage, int nbatch, hipStream_t stream);
 
 }  // namespace vq3gemm

@@ -21,10 +21,15 @@ def plan_buckets(table: Dict[str, tuple], num_layers: int, bucket_layers: int) -
     """table: name -> (offset, shape) of the flat buffer laid out [embed | l0.* ... l{L-1}.* | norm].
     Returns ({first_layer_of_group: (lo, hi)}, embed_span). Groups are contiguous; the final norm rides with the last
     group; the tied embedding is its own bucket (its gradient is only complete at the very end of the backward)."""
+    offs = sorted(o for o, _ in table.values())
+    o_last, s_last = max(table.values(), key=lambda v: v[0])
+    total = round_up(o_last + math.prod(s_last), 64)
+
     def span(first: str, last: str) -> Tuple[int, int]:
+        """[offset of `first`, offset of the entry that follows `last`) - entries may carry alignment / zero-row padding."""
         lo = table[first][0]
-        o1, s1 = table[last]
-        return lo, round_up(o1 + math.prod(s1), 64)
+        nxt = [o for o in offs if o > table[last][0]]
+        return lo, (nxt[0] if nxt else total)
     buckets = {}
     for g0 in range(0, num_layers, bucket_layers):
         g1 = min(num_layers, g0 + bucket_layers) - 1

@@ -140,12 +140,17 @@ class PerceiverProjector(nn.Module):
             ops.gemm_raw(q, kv, S, N, T, hd, D, 2 * D, Tp, nb1=B, nb2=Hh, sA=(N * D, hd), sB=(T * 2 * D, hd),
                          sC=(Hh * N * Tp, N * Tp), alpha=hd ** -0.5)
             P = ops.softmax_fwd(S, None, 1, T, Tp, False)
-            Vt = torch.empty((B, Hh, hd, Tp), device=dev, dtype=BF16)
-            ops.transpose_raw(kv, Vt, T, hd, Tp, 2 * D, Tp, n=(1, B, Hh), s=(0, T * 2 * D, hd),
-                              d=(0, Hh * hd * Tp, hd * Tp), src_off=D)
             o = torch.empty((B * N, D), device=dev, dtype=BF16)
-            ops.gemm_raw(P, Vt, o, N, hd, Tp, Tp, Tp, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp),
-                         sB=(Hh * hd * Tp, hd * Tp), sC=(N * D, hd))
+            if T % 8 == 0:
+                # O[b,h] = P[b,h] . V[b,h]: V (columns D + h*hd .. of kv) is read in place as the k-major B operand
+                ops.gemm_raw(P, kv, o, N, hd, T, Tp, 2 * D, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp),
+                             sB=(T * 2 * D, hd), sC=(N * D, hd), b_off=D, transB=True)
+            else:
+                Vt = torch.empty((B, Hh, hd, Tp), device=dev, dtype=BF16)
+                ops.transpose_raw(kv, Vt, T, hd, Tp, 2 * D, Tp, n=(1, B, Hh), s=(0, T * 2 * D, hd),
+                                  d=(0, Hh * hd * Tp, hd * Tp), src_off=D)
+                ops.gemm_raw(P, Vt, o, N, hd, Tp, Tp, Tp, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp),
+                             sB=(Hh * hd * Tp, hd * Tp), sC=(N * D, hd))
             x1 = ops.linear(o, w["o"], bias=l.self_attn.out_proj.bias, residual=lat32, out_dtype=F32)
             lat16, lat32 = ops.layernorm_fwd(x1, l.norm1.weight, l.norm1.bias, 1e-5, want_bf16=True, want_f32=True)
             h = ops.linear(lat16, w["f1"], bias=l.mlp[0].bias, act=ops.ACT_GELU)

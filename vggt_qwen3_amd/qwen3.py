@@ -8,8 +8,9 @@ Memory layout (sized for 288 GB HBM3E: everything replicated, nothing sharded):
   flat_w   bf16  every parameter, one buffer; per layer [qkv | o | gate_up | down | 4 norm vectors] so the fused
                  QKV and gate|up GEMMs read one contiguous weight and a layer is one contiguous all-reduce bucket
   flat_g   bf16  gradients, same layout (parameters' .grad are views)
-  flat_wt  bf16  transposed copies [K, N] of the matrix weights for the dgrad GEMMs (the GEMM kernel is NT-only);
-                 refreshed by `refresh_transposed()` after every optimiser step
+No transposed weight or activation copies exist: dgrad (dX = dY . W) reads W as the k-major B operand, wgrad
+(dW = dY^T . X) reads dY and X as k-major A / B operands, and the attention products read K, V, Q, dO as stored
+(vq3_gemm_bf16_nt transA / transB; ds_read_b64_tr_b16 fragment reads).
 """
 from __future__ import annotations
 
@@ -116,6 +117,8 @@ class Qwen3ForCausalLM(nn.Module):
         for name, shape in ent:
             n = math.prod(shape)
             table[name] = (off, shape)
+            if name == "embed":  # zero rows up to a multiple of 64: the vocabulary is a GEMM contraction / k-major extent
+                n = round_up(shape[0], 64) * shape[1]
             off += round_up(n, 64)  # keep every tensor 128-byte aligned
         return table, off
 
@@ -128,16 +131,7 @@ class Qwen3ForCausalLM(nn.Module):
         self.flat_g = torch.zeros(total, device=dev, dtype=BF16)
         self._w = {n: self.flat_w[o:o + math.prod(s)].view(s) for n, (o, s) in self.table.items()}
         self._g = {n: self.flat_g[o:o + math.prod(s)].view(s) for n, (o, s) in self.table.items()}
-        # transposed copies for dgrad: Wt[K, round_up(N, 64)]
         self.vocab_p = round_up(vocab, 64)
-        tt, toff = {}, 0
-        for n, (o, s) in self.table.items():
-            if len(s) == 2:
-                Np = round_up(s[0], 64)
-                tt[n] = (toff, (s[1], Np))
-                toff += s[1] * Np
-        self.flat_wt = torch.zeros(toff, device=dev, dtype=BF16)
-        self._wt = {n: self.flat_wt[o:o + math.prod(s)].view(s) for n, (o, s) in tt.items()}
         if seed is not None:
             g = torch.Generator(device="cpu").manual_seed(seed)
             for n, w in self._w.items():
@@ -160,7 +154,6 @@ class Qwen3ForCausalLM(nn.Module):
                 else:
                     self._w[n].copy_(t)
         self._build_modules()
-        self.refresh_transposed()
 
     def _build_modules(self):
         c = self.config
@@ -226,12 +219,6 @@ class Qwen3ForCausalLM(nn.Module):
     def zero_grad_flat(self):
         self.flat_g.zero_()
 
-    def refresh_transposed(self):
-        """Re-derive the [K, N] copies after the weights changed (load / optimiser step)."""
-        for n, wt in self._wt.items():
-            w = self._w[n]
-            ops.transpose_raw(w, wt, w.shape[0], w.shape[1], wt.shape[1], w.shape[1], wt.shape[1])
-
     # ------------------------------------------------------------------ HF-compatible surface
     def get_input_embeddings(self):
         return self.model.embed_tokens
@@ -257,7 +244,6 @@ class Qwen3ForCausalLM(nn.Module):
                     missing.append(n)
         if strict and missing:
             raise KeyError(f"missing keys: {missing[:5]}...")
-        self.refresh_transposed()
         return missing
 
     @classmethod
@@ -288,30 +274,35 @@ class Qwen3ForCausalLM(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _attention_fwd(self, i, xn, B, L, keymask, ctx):
+        """L is a multiple of 8 here (forward_hidden pads). Scores are materialised per (b, head) - at L = 200 the
+        attention is < 1 % of the FLOPs - as batched GEMMs that read Q, K, V exactly as the prep kernel wrote them."""
         c = self.config
         Hq, Hkv, D, G = self.Hq, self.Hkv, self.D, self.Hq // self.Hkv
-        Lp = round_up(L, 64)
         cos, sin = self.rope(L)
         qkv = ops.linear(xn, self._w[f"l{i}.qkv"])
         Q, K, V, qr, kr = ops.qwen_qkprep_fwd(qkv, self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin, B, L, Hq, Hkv,
                                               D, c.rms_norm_eps, want_rstd=ctx is not None)
-        S = torch.empty((B * Hq, L, Lp), device=xn.device, dtype=F32)
-        ops.gemm_raw(Q, K, S, L, L, D, D, D, Lp, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * D, L * D),
-                     sB=(Hkv * L * D, L * D), sC=(Hq * L * Lp, L * Lp), alpha=D ** -0.5)
-        P = ops.softmax_fwd(S, keymask, Hq, L, Lp, True)
-        Vt = torch.empty((B, Hkv, D, Lp), device=xn.device, dtype=BF16)
-        ops.transpose_raw(V, Vt, L, D, Lp, D, Lp, n=(1, B, Hkv), s=(0, Hkv * L * D, L * D), d=(0, Hkv * D * Lp, D * Lp))
+        S = torch.empty((B * Hq, L, L), device=xn.device, dtype=F32)
+        ops.gemm_raw(Q, K, S, L, L, D, D, D, L, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * D, L * D),
+                     sB=(Hkv * L * D, L * D), sC=(Hq * L * L, L * L), alpha=D ** -0.5)
+        P = ops.softmax_fwd(S, keymask, Hq, L, L, True)
         ao = torch.empty((B * L, Hq * D), device=xn.device, dtype=BF16)
-        ops.gemm_raw(P, Vt, ao, L, D, Lp, Lp, Lp, Hq * D, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * Lp, L * Lp),
-                     sB=(Hkv * D * Lp, D * Lp), sC=(L * Hq * D, D))
+        # O[b,h] = P[b,h] . V[b,h/G]  (V [L, D] is the k-major B operand)
+        ops.gemm_raw(P, V, ao, L, D, L, L, D, Hq * D, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * L, L * L),
+                     sB=(Hkv * L * D, L * D), sC=(L * Hq * D, D), transB=True)
         if ctx is not None:
             ctx.update(qkv=qkv, Q=Q, K=K, V=V, qr=qr, kr=kr, P=P, ao=ao)
         return ao
 
     def forward_hidden(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, save: bool):
         """36x decoder layer (modeling_qwen3.py:294-323, 367-427). Returns (h_last [B*L,H] pre-final-norm, saved)."""
-        B, L, H = inputs_embeds.shape
+        B, L0, H = inputs_embeds.shape
         c = self.config
+        L = round_up(L0, 8)
+        if L != L0:
+            # exact: the extra positions are masked as keys and carry no label (k-major GEMM operands want L % 8 == 0)
+            inputs_embeds = torch.cat([inputs_embeds, inputs_embeds.new_zeros((B, L - L0, H))], dim=1)
+            attention_mask = torch.cat([attention_mask, attention_mask.new_zeros((B, L - L0))], dim=1)
         keymask = (attention_mask != 0).to(torch.uint8).contiguous()
         h = inputs_embeds.reshape(B * L, H)
         saved: List[dict] = []
@@ -328,7 +319,7 @@ class Qwen3ForCausalLM(nn.Module):
                 ctx.update(h_in=h, r1=r1, xn1=xn1, h_mid=h_mid, r2=r2, xn2=xn2, gu=gu, act=act)
                 saved.append(ctx)
             h = h_out
-        return h, {"layers": saved, "B": B, "L": L, "keymask": keymask}
+        return h, {"layers": saved, "B": B, "L": L, "L0": L0, "keymask": keymask}
 
     @staticmethod
     def label_rows(labels: torch.Tensor):
@@ -342,25 +333,28 @@ class Qwen3ForCausalLM(nn.Module):
         idx = (flat != -100).nonzero(as_tuple=False).squeeze(1)
         return idx.to(torch.int32), flat[idx].to(torch.int32)
 
-    def loss_head(self, h_last: torch.Tensor, labels: torch.Tensor, save: bool):
+    def loss_head(self, h_last: torch.Tensor, labels: torch.Tensor, save: bool, L: Optional[int] = None):
         """Final RMSNorm + tied lm_head + shifted mean cross-entropy, evaluated only on the rows that carry a label
         (the other rows of the reference's [B,L,V] logits never reach the loss). Also leaves d(loss)/d(logits) in
         place for the backward."""
         c = self.config
         H = c.hidden_size
+        if L is not None and labels.shape[1] < L:   # h_last rows follow the padded length of forward_hidden
+            labels = torch.cat([labels, labels.new_full((labels.shape[0], L - labels.shape[1]), -100)], dim=1)
         idx, tgt = self.label_rows(labels)
         n = int(idx.numel())
         if n == 0:
             return torch.full((), float("nan"), device=h_last.device, dtype=F32), None
-        hs = ops.gather_rows(h_last, idx, n, n)
+        n8 = round_up(n, 8)                                  # zero rows: contribute nothing, keep K % 8 == 0 in backward
+        hs = ops.gather_rows(h_last, idx, n, n8)
         hn, rstd = ops.rmsnorm_fwd(hs, self._w["norm"], c.rms_norm_eps, want_rstd=True)
         ldl = self.vocab_p
-        logits = torch.empty((n, ldl), device=h_last.device, dtype=BF16)
+        logits = torch.zeros((n8, ldl), device=h_last.device, dtype=BF16)
         ops.gemm_raw(hn, self._w["embed"], logits, n, self.vocab, H, H, H, ldl)
         loss_sum = torch.zeros(1, device=h_last.device, dtype=F32)
         ops.cross_entropy_fwd_bwd(logits, tgt, loss_sum, n, self.vocab, 1.0 / n)
         loss = (loss_sum / n).reshape(())
-        ctx = dict(idx=idx, n=n, hs=hs, hn=hn, rstd=rstd, dlogits=logits) if save else None
+        ctx = dict(idx=idx, n=n, n8=n8, hs=hs, hn=hn, rstd=rstd, dlogits=logits) if save else None
         return loss, ctx
 
     def logits_all(self, h_last: torch.Tensor) -> torch.Tensor:
@@ -374,9 +368,9 @@ class Qwen3ForCausalLM(nn.Module):
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, name: str, dY: torch.Tensor, X: torch.Tensor, accumulate: bool):
-        """dW[N,K] (+)= dY^T[N,M] . X[M,K]: both operands are transposed (zero-padded M) to make M the contiguous
-        contraction dim of the NT GEMM. Weight gradients have no consumer inside the backward, so they are enqueued
-        on a second HIP stream: their transposes (HBM-bound) and GEMM tails overlap the dgrad chain on the main one."""
+        """dW[N,K] (+)= dY^T[N,M] . X[M,K]: dY and X are read as stored (k-major A and B operands, contraction = token
+        rows). Weight gradients have no consumer inside the backward, so they are enqueued on a second HIP stream:
+        their GEMM tails overlap the dgrad chain on the main one."""
         side = self._wgrad_stream
         if side is None:
             self._wgrad_now(name, dY, X, accumulate)
@@ -389,56 +383,49 @@ class Qwen3ForCausalLM(nn.Module):
         X.record_stream(side)
 
     def _wgrad_now(self, name: str, dY: torch.Tensor, X: torch.Tensor, accumulate: bool):
-        dYt = ops.transpose2d(dY, 64)
-        Xt = ops.transpose2d(X, 64)
+        M, N = dY.shape
+        K = X.shape[1]
         g = self._g[name]
-        ops.gemm_raw(dYt, Xt, g, g.shape[0], g.shape[1], dYt.shape[1], dYt.shape[1], Xt.shape[1], g.shape[1],
-                     accumulate=accumulate)
+        ops.gemm_raw(dY, X, g, N, K, M, dY.stride(0), X.stride(0), g.shape[1], accumulate=accumulate, transA=True,
+                     transB=True)
 
     def join_wgrad_stream(self):
         """Make the current stream wait for every weight-gradient kernel enqueued so far."""
         if self._wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self._wgrad_stream)
 
+    def _dgrad(self, dY: torch.Tensor, name: str) -> torch.Tensor:
+        """dX[M,K] = dY[M,N] . W[N,K]: W as stored is the k-major B operand (contraction = its rows)."""
+        W = self._w[name]
+        M, N = dY.shape
+        dX = torch.empty((M, W.shape[1]), device=dY.device, dtype=BF16)
+        ops.gemm_raw(dY, W, dX, M, W.shape[1], N, dY.stride(0), W.shape[1], W.shape[1], transB=True)
+        return dX
+
     def _norm_wgrad(self, name: str, dw_f32: torch.Tensor, accumulate: bool):
         ops.f32_to_bf16_acc(dw_f32, self._g[name], accumulate)
 
     def _attention_bwd(self, i, ctx, d_ao, B, L):
+        """d_ao: d(loss)/d(attention output), head-major [B, Hq, L, D]. No operand is transposed in memory."""
         Hq, Hkv, D, G = self.Hq, self.Hkv, self.D, self.Hq // self.Hkv
-        Lp = round_up(L, 64)
         dev = d_ao.device
         Q, K, V, P = ctx["Q"], ctx["K"], ctx["V"], ctx["P"]
         # dP[b,h] = dAO[b,h] . V[b,h/G]^T
-        dP = torch.empty((B * Hq, L, Lp), device=dev, dtype=F32)
-        ops.gemm_raw(d_ao, V, dP, L, L, D, Hq * D, D, Lp, nb1=B, nb2=Hq, b2divB=G, sA=(L * Hq * D, D),
-                     sB=(Hkv * L * D, L * D), sC=(Hq * L * Lp, L * Lp))
+        dP = torch.empty((B * Hq, L, L), device=dev, dtype=F32)
+        ops.gemm_raw(d_ao, V, dP, L, L, D, D, D, L, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * D, L * D),
+                     sB=(Hkv * L * D, L * D), sC=(Hq * L * L, L * L))
         dS = ops.softmax_bwd(P, dP, L, D ** -0.5)
-        # dQ[b,h] = dS[b,h] . K[b,h/G]   (needs K^T as the NT B operand)
-        Kt = torch.empty((B, Hkv, D, Lp), device=dev, dtype=BF16)
-        ops.transpose_raw(K, Kt, L, D, Lp, D, Lp, n=(1, B, Hkv), s=(0, Hkv * L * D, L * D), d=(0, Hkv * D * Lp, D * Lp))
+        # dQ[b,h] = dS[b,h] . K[b,h/G]            (K [L, D]: k-major B)
         dQ = torch.empty((B, Hq, L, D), device=dev, dtype=BF16)
-        ops.gemm_raw(dS, Kt, dQ, L, D, Lp, Lp, Lp, D, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * Lp, L * Lp),
-                     sB=(Hkv * D * Lp, D * Lp), sC=(Hq * L * D, L * D))
-        # dK[b,kv] = sum_g dS[b,h]^T . Q[b,h] ; dV[b,kv] = sum_g P[b,h]^T . dAO[b,h]: the (g, query) pair is the
-        # contraction dim -> transposed, zero-padded copies [.., G*Lp]
-        GL = G * Lp
-        dSt = torch.empty((B, Hkv, L, GL), device=dev, dtype=BF16)
-        Pt = torch.empty((B, Hkv, L, GL), device=dev, dtype=BF16)
-        for src, dst in ((dS, dSt), (P, Pt)):
-            ops.transpose_raw(src, dst, L, L, Lp, Lp, GL, n=(B, Hkv, G), s=(Hq * L * Lp, G * L * Lp, L * Lp),
-                              d=(Hkv * L * GL, L * GL, Lp))
-        Qt = torch.empty((B, Hkv, D, GL), device=dev, dtype=BF16)
-        ops.transpose_raw(Q, Qt, L, D, Lp, D, GL, n=(B, Hkv, G), s=(Hq * L * D, G * L * D, L * D),
-                          d=(Hkv * D * GL, D * GL, Lp))
-        dAOt = torch.empty((B, Hkv, D, GL), device=dev, dtype=BF16)
-        ops.transpose_raw(d_ao, dAOt, L, D, Lp, Hq * D, GL, n=(B, Hkv, G), s=(L * Hq * D, G * D, D),
-                          d=(Hkv * D * GL, D * GL, Lp))
+        ops.gemm_raw(dS, K, dQ, L, D, L, L, D, D, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * L, L * L),
+                     sB=(Hkv * L * D, L * D), sC=(Hq * L * D, L * D), transB=True)
+        # dK[b,kv] = sum_g dS[b,h]^T . Q[b,h] ; dV[b,kv] = sum_g P[b,h]^T . dAO[b,h]: the G heads of a kv group are
+        # contiguous, so (g, query) is one contraction of length G*L over k-major operands [G*L, L] and [G*L, D]
         dK = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
         dV = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
-        ops.gemm_raw(dSt, Qt, dK, L, D, GL, GL, GL, D, nb1=B, nb2=Hkv, sA=(Hkv * L * GL, L * GL),
-                     sB=(Hkv * D * GL, D * GL), sC=(Hkv * L * D, L * D))
-        ops.gemm_raw(Pt, dAOt, dV, L, D, GL, GL, GL, D, nb1=B, nb2=Hkv, sA=(Hkv * L * GL, L * GL),
-                     sB=(Hkv * D * GL, D * GL), sC=(Hkv * L * D, L * D))
+        for A_, B_, C_ in ((dS, Q, dK), (P, d_ao, dV)):
+            ops.gemm_raw(A_, B_, C_, L, D, G * L, L, D, D, nb1=B, nb2=Hkv, sA=(Hq * L * L, G * L * L),
+                         sB=(Hq * L * D, G * L * D), sC=(Hkv * L * D, L * D), transA=True, transB=True)
         return dQ, dK, dV
 
     def backward_hidden(self, saved, dh: torch.Tensor, accumulate: bool, gscale_hook=None, layer_done=None):
@@ -453,21 +440,25 @@ class Qwen3ForCausalLM(nn.Module):
         for i in reversed(range(c.num_hidden_layers)):
             ctx = saved["layers"][i]
             # down_proj
-            d_act = ops.linear(dh, self._wt[f"l{i}.down"])
+            d_act = self._dgrad(dh, f"l{i}.down")
             self._wgrad(f"l{i}.down", dh, ctx["act"], accumulate)
             dgu = ops.silu_mul_bwd(d_act, ctx["gu"])
-            d_xn2 = ops.linear(dgu, self._wt[f"l{i}.gu"])
+            d_xn2 = self._dgrad(dgu, f"l{i}.gu")
             self._wgrad(f"l{i}.gu", dgu, ctx["xn2"], accumulate)
             dh_mid = ops.rmsnorm_bwd(d_xn2, ctx["h_mid"], self._w[f"l{i}.ln2"], ctx["r2"], dh, self._g[f"l{i}.ln2"],
                                      accumulate)
             # o_proj
-            d_ao = ops.linear(dh_mid, self._wt[f"l{i}.o"])
+            # d(attention out) head-major [B, Hq, L, D]: one batch per (b, head) over the column block of W_o
+            Wo = self._w[f"l{i}.o"]
+            d_ao = torch.empty((B, self.Hq, L, D), device=dev, dtype=BF16)
+            ops.gemm_raw(dh_mid, Wo, d_ao, L, D, H, H, self.Hq * D, D, nb1=B, nb2=self.Hq, sA=(L * H, 0), sB=(0, D),
+                         sC=(self.Hq * L * D, L * D), transB=True)
             self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
             dQ, dK, dV = self._attention_bwd(i, ctx, d_ao, B, L)
             dqkv = ops.qwen_qkprep_bwd(dQ, dK, dV, ctx["qkv"], self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin,
                                        ctx["qr"], ctx["kr"], self._g[f"l{i}.qn"], self._g[f"l{i}.kn"], accumulate, B, L,
                                        self.Hq, self.Hkv, D)
-            d_xn1 = ops.linear(dqkv, self._wt[f"l{i}.qkv"])
+            d_xn1 = self._dgrad(dqkv, f"l{i}.qkv")
             self._wgrad(f"l{i}.qkv", dqkv, ctx["xn1"], accumulate)
             dh = ops.rmsnorm_bwd(d_xn1, ctx["h_in"], self._w[f"l{i}.ln1"], ctx["r1"], dh_mid, self._g[f"l{i}.ln1"],
                                  accumulate)
@@ -483,15 +474,16 @@ class Qwen3ForCausalLM(nn.Module):
         c = self.config
         H = c.hidden_size
         dev = head_ctx["hn"].device
-        n, dlog = head_ctx["n"], head_ctx["dlogits"]
-        # d(hn) = dlogits[n, Vp] . E[V, H]  via E^T [H, Vp]
-        d_hn = torch.empty((n, H), device=dev, dtype=BF16)
-        ops.gemm_raw(dlog, self._wt["embed"], d_hn, n, H, self.vocab_p, self.vocab_p, self.vocab_p, H, alpha=gscale)
-        # dE[V, H] (+)= dlogits^T[V, n] . hn[n, H]
-        dlt = ops.transpose2d(dlog[:, : self.vocab], 64)
-        hnt = ops.transpose2d(head_ctx["hn"], 64)
-        ops.gemm_raw(dlt, hnt, self._g["embed"], self.vocab, H, dlt.shape[1], dlt.shape[1], hnt.shape[1], H,
-                     accumulate=accumulate, alpha=gscale)
+        n, n8, dlog = head_ctx["n"], head_ctx["n8"], head_ctx["dlogits"]
+        Vp = self.vocab_p
+        E = self.flat_w[self.table["embed"][0]: self.table["embed"][0] + Vp * H].view(Vp, H)      # incl. the zero pad rows
+        dE = self.flat_g[self.table["embed"][0]: self.table["embed"][0] + Vp * H].view(Vp, H)
+        # d(hn)[n8, H] = dlogits[n8, Vp] . E[Vp, H]       (E: k-major B; pad rows/cols are zero on both sides)
+        d_hn = torch.empty((n8, H), device=dev, dtype=BF16)
+        ops.gemm_raw(dlog, E, d_hn, n8, H, Vp, Vp, H, H, alpha=gscale, transB=True)
+        # dE[Vp, H] (+)= dlogits^T[Vp, n8] . hn[n8, H]    (both k-major; contraction = the n8 selected rows)
+        ops.gemm_raw(dlog, head_ctx["hn"], dE, Vp, H, n8, Vp, H, H, accumulate=accumulate, alpha=gscale, transA=True,
+                     transB=True)
         d_hs = ops.rmsnorm_bwd(d_hn, head_ctx["hs"], self._w["norm"], head_ctx["rstd"], None, self._g["norm"], accumulate)
         dh = torch.zeros((rows, H), device=dev, dtype=BF16)
         ops.scatter_rows(d_hs, head_ctx["idx"], dh, n, False)

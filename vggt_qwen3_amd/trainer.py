@@ -1,8 +1,8 @@
 """Data-parallel Stage-1 step around VGGTQwen3VLM: the MI355X-native replacement for the reference's
 Accelerate/DeepSpeed loop body (src/train/train_sft.py:138-163 optimiser + schedule, :208-220 step).
 
-One process per GPU. Every rank holds the full model (288 GB HBM3E: bf16 weights + bf16 grads + transposed copies +
-fp32 master/Adam state of the 4 B trainable parameters is ~72 GB, so nothing is sharded - no ZeRO). The only exchange
+One process per GPU. Every rank holds the full model (288 GB HBM3E: bf16 weights + bf16 grads +
+fp32 master/Adam state of the 4 B trainable parameters is ~64 GB, so nothing is sharded - no ZeRO). The only exchange
 is a SUM all-reduce of the flat bf16 gradient buffer over RCCL/xGMI, issued bucket by bucket from inside the
 hand-written backward (layers 35 -> 0) on a side stream so it overlaps the remaining backward; the 1/world factor is
 folded into the fused AdamW kernel. Semantics kept from the reference: two LR groups selected by parameter NAME
@@ -119,7 +119,6 @@ class Stage1Trainer:
         gscale = 1.0 / self.world
         ops.adamw_step(self.master, self.m, self.v, tm.flat_g, tm.flat_w, self.lr * mult, self.betas[0], self.betas[1],
                        self.eps, self.wd, self.opt_step, gscale)
-        tm.refresh_transposed()
         if self._geom_has_grad:
             ops.adamw_step(self.geom_master, self.geom_m, self.geom_v, ops.cast(self.geom_grad, BF16), self.geom_w16,
                            self.proj_lr * mult, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step, gscale)

@@ -291,7 +291,7 @@ class VGGTQwen3VLM(nn.Module):
                 L = L_eff
         emb = ops.embed_splice_fwd(input_ids.contiguous(), tm._w["embed"], feats16, srcmap, B, L, H, S)
         h_last, saved = tm.forward_hidden(emb, attention_mask, save=need_grad)
-        loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad)
+        loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad, L=saved["L"])
         return dict(loss=loss, saved=saved, head=head_ctx, srcmap=srcmap, input_ids=input_ids, B=B, L=L, S=S,
                     geom_ctx=geom_ctx, geom_y=gy, emb=emb, h_last=h_last)
 
@@ -303,8 +303,11 @@ class VGGTQwen3VLM(nn.Module):
         B, L, S = st["B"], st["L"], st["S"]
         if st["head"] is None:
             return None
-        dh = tm.backward_loss_head(st["head"], B * L, gscale, accumulate)
+        Lp = st["saved"]["L"]                                   # forward_hidden pads L to a multiple of 8
+        dh = tm.backward_loss_head(st["head"], B * Lp, gscale, accumulate)
         d_emb = tm.backward_hidden(st["saved"], dh, accumulate, layer_done=layer_done)
+        if Lp != L:
+            d_emb = d_emb.view(B, Lp, H)[:, :L].contiguous()
         ids = st["input_ids"].reshape(-1)
         sorted_ids, order = torch.sort(ids, stable=True)
         dfeat = None
