@@ -189,9 +189,9 @@ def main():
     model = VGGTQwen3VLM(vcfg)
     model.train()
     accum = args.grad_accum if args.grad_accum > 0 else max(1, min(32, args.steps))
-    if args.steps % accum:
-        raise SystemExit(f"--steps {args.steps} must be a multiple of the accumulation length {accum}: every timed "
-                         "window must contain whole optimiser steps")
+    # the timed window is cut into whole accumulation cycles (the last one shorter if --steps is not a multiple): every
+    # timed micro-batch belongs to a cycle that ends with its all-reduce + optimiser step inside the window
+    cycles = [accum] * (args.steps // accum) + ([args.steps % accum] if args.steps % accum else [])
     trainer = Stage1Trainer(model, grad_accum=accum, max_steps=30000)
     B, V, L = args.batch, args.views, args.seq_len
     batch = synthetic_batch(B, V, L, args.image_size, 151936, model.image_id, 151643, 198, 1234 + rank, dev, args.geom)
@@ -218,8 +218,10 @@ def main():
     trainer.micro = 0
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.micro_step(batch, nxt)   # K vision forwards + K text fwd/bwd inside the window
+    for clen in cycles:
+        trainer.grad_accum, trainer.micro = clen, 0
+        for _ in range(clen):
+            loss = trainer.micro_step(batch, nxt)   # K vision forwards + K text fwd/bwd inside the window
     sync()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -278,7 +280,7 @@ def main():
                                     "Perceiver + Qwen3-4B fwd+bwd + RCCL all-reduce + AdamW(fp32 master); random-init "
                                     "weights" % (args.image_size, V)),
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": L, "views": V,
-                       "grad_accum": accum, "optimizer_steps_timed": args.steps // accum, "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
+                       "grad_accum": accum, "optimizer_steps_timed": len(cycles), "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
                        "trim_padding": bool(args.trim_pad), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),
             "algorithmic_tflop_per_sample": round(tf_train, 3),
