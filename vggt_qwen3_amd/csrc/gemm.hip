@@ -146,8 +146,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
 
 bool g_attr_set = false;
 
-// Kernel choice per shape. -1 = v1 (128x128, register staged, 2 workgroups/CU); 0/1/2 = v2 LDS-DMA kernels
-// (256x128, 128x256, 128x128 tiles, one workgroup per CU). VQ3_GEMM_CFG overrides (benchmarking).
+// Kernel choice per shape, from measurements on MI355X (tools/bench_gemm.py, tools/bench_gemm_layouts.py,
+// tools/diag/run_stamps.py). Candidates:
+//   cfg 7  : 128x128 tile, 8 waves, 2 stages, two workgroups per CU (512 tile slots)  - best for short K (<= 1536)
+//   cfg 13 : 128x128 tile, 8 compute + 2 DMA-loader waves, 4-stage ring, one workgroup per CU (256 slots)
+//   cfg 11 : 256x128 tile, 8 compute + 2 DMA-loader waves, 3-stage ring, one workgroup per CU (256 slots)
+// score = (measured relative speed of the schedule) x (fraction of tile slots busy over all rounds).
+// VQ3_GEMM_CFG overrides (benchmarking; -1 = v1 register-staged kernel).
+double fill(long tiles, long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); }
+
 int choose_config(int M, int N, int K, int nbatch) {
   static int forced = -2;
   if (forced == -2) {
@@ -155,12 +162,24 @@ int choose_config(int M, int N, int K, int nbatch) {
     forced = e ? atoi(e) : -3;
   }
   if (forced >= -1) return forced;
-  (void)K;
-  // Measured on MI355X (gpurun_out/gemm_v2_*.log): with more 128x128 tiles than CUs the 2-stage kernel at two
-  // workgroups (16 waves) per CU wins; with at most one tile per CU the 3-stage ring (tile t+1 in flight across the
-  // barrier) hides more of the load latency.
-  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
-  return tiles <= 256 ? 3 : 7;
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
+  const long t256 = (long)((M + 255) / 256) * ((N + 127) / 128) * nbatch;
+  const bool shortk = K <= 1536;
+  const double s7 = (shortk ? 1.00 : 0.93) * fill(t128, 512);
+  const double s12 = (shortk ? 0.85 : 0.95) * fill(t128, 256);
+  const double s11 = (shortk ? 0.90 : 1.00) * fill(t256, 256) * ((double)M / (double)(((M + 255) / 256) * 256)) /
+                     ((double)M / (double)(((M + 127) / 128) * 128));
+  if (s11 >= s12 && s11 >= s7) return 11;
+  return s12 >= s7 ? 13 : 7;
+}
+
+// v3 (k-major operands / K tails) has 128x128 tiles only: 3-stage ring + loader waves vs 2 stages x 2 workgroups.
+int choose_v3_stages(int M, int N, int K, int nbatch) {
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
+  const bool shortk = K <= 1536;
+  const double s2 = (shortk ? 1.00 : 0.93) * fill(t128, 512);
+  const double s3 = (shortk ? 0.85 : 0.95) * fill(t128, 256);
+  return s3 >= s2 ? 3 : 2;
 }
 
 }  // namespace
@@ -202,8 +221,7 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int nbatch = d->nb1 * d->nb2;
   if (d->transA || d->transB || d->K % BK != 0) {
-    const long tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * nbatch;
-    const int rc = launch_gemm_v3(p, d->transA, d->transB, tiles <= 256 ? 3 : 2, nbatch, s);
+    const int rc = launch_gemm_v3(p, d->transA, d->transB, choose_v3_stages(d->M, d->N, d->K, nbatch), nbatch, s);
     if (rc) return rc;
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3)");
     return 0;

@@ -18,18 +18,22 @@ namespace {
 
 constexpr int BK = 64;
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool OUT_F32>
-__global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) void gemm_v2_kernel(GemmParams p) {
+template <int BM, int BN, int WM, int WN, int NSTAGE, int NLOAD, bool OUT_F32>
+__global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((WM * WN + NLOAD + 3) / 4)) void gemm_v2_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;   // 16x16 MFMA tiles per wave
   constexpr int STAGE = (BM + BN) * 128;                 // bytes per stage
   constexpr int NPIECE = (BM + BN) / 8;                  // 1-KiB pieces per stage
-  constexpr int PPW = NPIECE / NW;                       // pieces per wave per stage
-  static_assert(NPIECE % NW == 0, "pieces must divide evenly over the waves");
+  // NLOAD > 0: dedicated DMA waves (wid >= NW) issue every piece; the compute waves never leave the MFMA/ds_read stream
+  constexpr int NISS = NLOAD > 0 ? NLOAD : NW;            // waves that issue DMA
+  constexpr int PPW = NPIECE / NISS;                     // pieces per issuing wave per stage
+  static_assert(NPIECE % NISS == 0, "pieces must divide evenly over the issuing waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid % WN;
+  const bool loader = NLOAD > 0 && wid >= NW;
+  const int iw = NLOAD > 0 ? (wid >= NW ? wid - NW : 0) : wid;   // index among the issuing waves
+  const int wm = (wid % NW) / WN, wn = wid % WN;
   int m0, n0;
   tile_coords(p, BM, BN, m0, n0);
   const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) 
   const bf16_t* gsrc[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    const int pi = wid + NW * j;
+    const int pi = iw + NISS * j;
     const int trow = pi * 8 + prow;                 // row in the stacked [A|B] tile
     if (trow < BM) {
       int r = m0 + trow; r = r < p.M ? r : p.M - 1;
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) 
     char* sb = smem + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-      const int pi = wid + NW * j;
+      const int pi = iw + NISS * j;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + (long)tile * BK),
                                        (__attribute__((address_space(3))) void*)(sb + pi * 1024), 16, 0, 0);
     }
@@ -101,7 +105,39 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) 
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     }
   };
-  if (NSTAGE == 3) {
+  if (NSTAGE >= 3 && NLOAD > 0) {
+    // producer / consumer split inside the workgroup (one s_barrier per K step for everybody):
+    //   loader waves:  wait until their pieces of tile t landed -> barrier -> issue tile t+2
+    //   compute waves: barrier -> fragments of tile t -> MFMAs
+    if (loader) {
+      // the ring runs NSTAGE-1 tiles ahead: cold (HBM-resident) weights need more than two tiles of latency cover
+#pragma unroll
+      for (int i = 0; i < NSTAGE - 1; ++i)
+        if (i < nt) issue(i, i);
+      int stage = 0;
+      for (int t = 0; t < nt; ++t) {
+        const int newer = (last - t) < (NSTAGE - 2) ? (last - t) : (NSTAGE - 2);   // tiles allowed to stay in flight
+        if (newer >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 <= last) {
+          int s2 = stage + NSTAGE - 1; s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
+          issue(t + NSTAGE - 1, s2);
+        }
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+      }
+      return;
+    }
+    int stage = 0;
+    for (int t = 0; t < nt; ++t) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      compute(stage);
+      stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    }
+  } else if (NSTAGE == 3) {
     issue(0, 0);
     if (nt > 1) issue(1, 1);
     int stage = 0;
@@ -149,14 +185,14 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int NLOAD = 0>
 int launch_cfg(GemmParams& p, int nbatch, hipStream_t stream) {
   constexpr int SMEM = NSTAGE * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v2_kernel<BM, BN, WM, WN, NSTAGE, true>,
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v2_kernel<BM, BN, WM, WN, NSTAGE, NLOAD, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v2_kernel<BM, BN, WM, WN, NSTAGE, false>,
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v2_kernel<BM, BN, WM, WN, NSTAGE, NLOAD, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       vq3_set_error("gemm v2: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -168,9 +204,9 @@ int launch_cfg(GemmParams& p, int nbatch, hipStream_t stream) {
   p.ntiles = (p.N + BN - 1) / BN;
   dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
   if (p.out_f32)
-    hipLaunchKernelGGL((gemm_v2_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(64 * WM * WN), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_v2_kernel<BM, BN, WM, WN, NSTAGE, NLOAD, true>), grid, dim3(64 * (WM * WN + NLOAD)), SMEM, stream, p);
   else
-    hipLaunchKernelGGL((gemm_v2_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(64 * WM * WN), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_v2_kernel<BM, BN, WM, WN, NSTAGE, NLOAD, false>), grid, dim3(64 * (WM * WN + NLOAD)), SMEM, stream, p);
   return 0;
 }
 
@@ -185,7 +221,14 @@ int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream) {
     case 4: return launch_cfg<128, 64, 4, 2, 3>(p, nbatch, stream);
     case 5: return launch_cfg<64, 128, 2, 4, 3>(p, nbatch, stream);
     case 6: return launch_cfg<128, 128, 2, 2, 2>(p, nbatch, stream);
-    default: return launch_cfg<128, 128, 4, 2, 2>(p, nbatch, stream);
+    case 7: return launch_cfg<128, 128, 4, 2, 2>(p, nbatch, stream);
+    case 8: return launch_cfg<256, 128, 4, 2, 3, 4>(p, nbatch, stream);
+    case 9: return launch_cfg<128, 128, 4, 2, 3, 4>(p, nbatch, stream);
+    case 10: return launch_cfg<128, 128, 2, 2, 3, 4>(p, nbatch, stream);
+    case 11: return launch_cfg<256, 128, 4, 2, 3, 2>(p, nbatch, stream);
+    case 12: return launch_cfg<128, 128, 4, 2, 3, 2>(p, nbatch, stream);
+    case 13: return launch_cfg<128, 128, 4, 2, 4, 2>(p, nbatch, stream);
+    default: return launch_cfg<128, 128, 4, 2, 5, 2>(p, nbatch, stream);
   }
 }
 

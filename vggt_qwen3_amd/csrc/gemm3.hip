@@ -12,7 +12,8 @@
 // reads 2 groups x 4 rows at one column offset; the 32-byte segment index is XORed with (k&3) | ((k>>3)&1)<<2 (again
 // on the DMA SOURCE address, the LDS image being lane-linear), which spreads those 8 (row, group) pairs over all
 // eight 32-byte segments of the 256-byte bank row: conflict-free.
-// Tile 128x128x64, 8 waves (4x2, 32x64 per wave), 2 stages x 2 workgroups/CU or 3-stage ring x 1 workgroup/CU.
+// Tile 128x128x64, 8 compute waves (4x2, 32x64 per wave); either 2 stages x 2 workgroups/CU, or a 4-stage ring fed
+// by 2 dedicated DMA-loader waves x 1 workgroup/CU.
 #include "gemm_common.h"
 
 namespace vq3gemm {
@@ -44,16 +45,20 @@ __device__ __forceinline__ bf16x8 join(const u32x2& lo, const u32x2& hi) {
   return __builtin_bit_cast(bf16x8, t);
 }
 
-template <int WM, int WN, int NSTAGE, bool AKM, bool BKM, bool OUT_F32>
-__global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) void gemm_v3_kernel(GemmParams p) {
-  constexpr int NW = WM * WN, NT = 64 * NW;
+template <int WM, int WN, int NSTAGE, int NLOAD, bool AKM, bool BKM, bool OUT_F32>
+__global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((WM * WN + NLOAD + 3) / 4)) void gemm_v3_kernel(GemmParams p) {
+  constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   constexpr int STAGE = 2 * OPB;
-  constexpr int PPW = 32 / NW;  // 16 A pieces + 16 B pieces per stage
+  // NLOAD > 0: dedicated DMA waves (wid >= NW) issue every piece (see gemm2.hip)
+  constexpr int NISS = NLOAD > 0 ? NLOAD : NW;
+  constexpr int PPW = 32 / NISS;  // 16 A pieces + 16 B pieces per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid % WN;
+  const bool loader = NLOAD > 0 && wid >= NW;
+  const int iw = NLOAD > 0 ? (wid >= NW ? wid - NW : 0) : wid;
+  const int wm = (wid % NW) / WN, wn = wid % WN;
   int m0, n0;
   tile_coords(p, BM, BN, m0, n0);
   const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) 
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       const bool isA = j < PPW / 2;
-      const int po = (wid + NW * j) & 15;
+      const int po = (iw + NISS * j) & 15;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_ptr(isA, po, tile),
                                        (__attribute__((address_space(3))) void*)(sb + (isA ? 0 : OPB) + po * 1024), 16,
                                        0, 0);
@@ -187,10 +192,10 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) 
     const u32x4 z = {0u, 0u, 0u, 0u};
     if (AKM) {
       const int n16 = (BK - krem) * 16;
-      for (int idx = tid; idx < n16; idx += NT) *reinterpret_cast<u32x4*>(sa + krem * 256 + idx * 16) = z;
+      for (int idx = tid; idx < n16; idx += 64 * NW) *reinterpret_cast<u32x4*>(sa + krem * 256 + idx * 16) = z;
     } else {
       const int c0 = krem >> 3, nch = 8 - c0;
-      for (int idx = tid; idx < BM * nch; idx += NT) {
+      for (int idx = tid; idx < BM * nch; idx += 64 * NW) {
         const int row = idx & (BM - 1), kc = c0 + idx / BM;
         *reinterpret_cast<u32x4*>(sa + row * 128 + ((kc ^ (row & 7)) << 4)) = z;
       }
@@ -201,7 +206,44 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) 
   // The last K tile is peeled out of the loop: its zero-fill does LDS stores, and with LDS stores inside the loop
   // hipcc orders every fragment read behind the in-flight LDS-DMA (s_waitcnt vmcnt(0) per K step), which drains the
   // prefetch pipeline. The steady-state loop touches LDS by DMA and ds_read only.
-  if (NSTAGE == 3) {
+  if (NSTAGE >= 3 && NLOAD > 0) {
+    // producer / consumer split (gemm2.hip): loader waves own the DMA, compute waves only ds_read + MFMA.
+    if (loader) {
+      // the ring runs NSTAGE-1 tiles ahead (cold, HBM-resident weights need more than two tiles of latency cover)
+#pragma unroll
+      for (int i = 0; i < NSTAGE - 1; ++i)
+        if (i < nt) issue(i, i);
+      int stage = 0;
+      for (int t = 0; t < nt; ++t) {
+        const int newer = (last - t) < (NSTAGE - 2) ? (last - t) : (NSTAGE - 2);
+        if (newer >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (newer == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 <= last) {
+          int s2 = stage + NSTAGE - 1; s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
+          issue(t + NSTAGE - 1, s2);
+        }
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+      }
+      if (krem) {            // take part in the zero-fill barrier of the last tile
+        __syncthreads();
+      }
+      return;
+    }
+    int stage = 0;
+    for (int t = 0; t < last; ++t) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      compute(stage);
+      stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (krem) zero_tail(stage);
+    compute(stage);
+  } else if (NSTAGE == 3) {
     issue(0, 0);
     if (nt > 1) issue(1, 1);
     int stage = 0;
@@ -250,14 +292,14 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 2 ? 2 : 1) * WM * WN / 4) 
   }
 }
 
-template <int NSTAGE, bool AKM, bool BKM>
+template <int NSTAGE, int NLOAD, bool AKM, bool BKM>
 int launch_v3(GemmParams& p, int nbatch, hipStream_t stream) {
   constexpr int SMEM = NSTAGE * 2 * OPB;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v3_kernel<4, 2, NSTAGE, AKM, BKM, true>,
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v3_kernel<4, 2, NSTAGE, AKM, BKM, false>,
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       vq3_set_error("gemm v3: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -269,9 +311,9 @@ int launch_v3(GemmParams& p, int nbatch, hipStream_t stream) {
   p.ntiles = (p.N + BN - 1) / BN;
   dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
   if (p.out_f32)
-    hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, AKM, BKM, true>), grid, dim3(512), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, true>), grid, dim3(64 * (8 + NLOAD)), SMEM, stream, p);
   else
-    hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, AKM, BKM, false>), grid, dim3(512), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, false>), grid, dim3(64 * (8 + NLOAD)), SMEM, stream, p);
   return 0;
 }
 
@@ -280,14 +322,14 @@ int launch_v3(GemmParams& p, int nbatch, hipStream_t stream) {
 int launch_gemm_v3(GemmParams& p, int transA, int transB, int nstage, int nbatch, hipStream_t stream) {
   const int sel = (nstage == 3 ? 4 : 0) | (transA ? 2 : 0) | (transB ? 1 : 0);
   switch (sel) {
-    case 0: return launch_v3<2, false, false>(p, nbatch, stream);
-    case 1: return launch_v3<2, false, true>(p, nbatch, stream);
-    case 2: return launch_v3<2, true, false>(p, nbatch, stream);
-    case 3: return launch_v3<2, true, true>(p, nbatch, stream);
-    case 4: return launch_v3<3, false, false>(p, nbatch, stream);
-    case 5: return launch_v3<3, false, true>(p, nbatch, stream);
-    case 6: return launch_v3<3, true, false>(p, nbatch, stream);
-    default: return launch_v3<3, true, true>(p, nbatch, stream);
+    case 0: return launch_v3<2, 0, false, false>(p, nbatch, stream);
+    case 1: return launch_v3<2, 0, false, true>(p, nbatch, stream);
+    case 2: return launch_v3<2, 0, true, false>(p, nbatch, stream);
+    case 3: return launch_v3<2, 0, true, true>(p, nbatch, stream);
+    case 4: return launch_v3<4, 2, false, false>(p, nbatch, stream);
+    case 5: return launch_v3<4, 2, false, true>(p, nbatch, stream);
+    case 6: return launch_v3<4, 2, true, false>(p, nbatch, stream);
+    default: return launch_v3<4, 2, true, true>(p, nbatch, stream);
   }
 }
 
