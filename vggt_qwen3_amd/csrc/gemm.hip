@@ -244,6 +244,7 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   }
   p.mtiles = (d->M + BM - 1) / BM;
   p.ntiles = (d->N + BN - 1) / BN;
+  p.xm = choose_xm(p.mtiles, p.ntiles);
   VQ3_CHECK_ARG((long)p.mtiles * p.ntiles < (1L << 31), "gemm: too many tiles");
   dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
   if (d->out_f32)

@@ -309,6 +309,7 @@ int launch_v3(GemmParams& p, int nbatch, hipStream_t stream) {
   }
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = (p.N + BN - 1) / BN;
+  p.xm = choose_xm(p.mtiles, p.ntiles);
   dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
   if (p.out_f32)
     hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, true>), grid, dim3(64 * (8 + NLOAD)), SMEM, stream, p);

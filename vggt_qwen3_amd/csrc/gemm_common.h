@@ -17,6 +17,7 @@ struct GemmParams {
   long sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
   int nb2, b2divB;
   int mtiles, ntiles;
+  int xm;          // XCD blocking of the tile grid along M (1, 2, 4 or 8)
   int act;         // 0 none, 1 gelu(erf), 2 silu
   int out_f32;     // C / R dtype: 0 bf16, 1 f32
   int accumulate;  // C += result
@@ -30,17 +31,34 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-// XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own
-// 4 MiB L2), so give every XCD a contiguous run of the (n-tile major, m-tile minor) order: the m-tiles that re-read
-// one weight tile then hit the same L2. Bijective for any grid size.
+// XCD-aware tile order. Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own 4 MiB
+// L2), so workgroup b runs on XCD b % 8 as its (b / 8)-th tile. Each XCD is given one rectangle of an xm x (8/xm)
+// blocking of the tile grid (walked m-fastest): the tiles sharing an L2 then re-read only mtiles/xm row panels of A
+// and ntiles/xn panels of B. The host picks xm in {1,2,4,8} minimising mtiles/xm + ntiles/xn (xm = 1 is "n-tile
+// major" order). Bijective for any grid size; placement only ever affects speed.
 __device__ __forceinline__ void tile_coords(const GemmParams& p, int BM, int BN, int& m0, int& n0) {
   const int nwg = p.mtiles * p.ntiles;
   const int orig = blockIdx.x;
   const int xcd = orig & 7, idx = orig >> 3;
   const int q = nwg >> 3, r = nwg & 7;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  m0 = (lin % p.mtiles) * BM;
-  n0 = (lin / p.mtiles) * BN;
+  int s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // position in the region-major sequence
+  const int xm = p.xm, xn = 8 / p.xm;
+  const int mc = (p.mtiles + xm - 1) / xm, nc = (p.ntiles + xn - 1) / xn;
+  int mt = 0, ntl = 0;
+  for (int reg = 0; reg < 8; ++reg) {
+    const int xi = reg % xm, xj = reg / xm;
+    int mcnt = p.mtiles - xi * mc; mcnt = mcnt < 0 ? 0 : (mcnt > mc ? mc : mcnt);
+    int ncnt = p.ntiles - xj * nc; ncnt = ncnt < 0 ? 0 : (ncnt > nc ? nc : ncnt);
+    const int sz = mcnt * ncnt;
+    if (s < sz) {
+      mt = xi * mc + s % mcnt;
+      ntl = xj * nc + s / mcnt;
+      break;
+    }
+    s -= sz;
+  }
+  m0 = mt * BM;
+  n0 = ntl * BN;
 }
 
 // Epilogue for one lane-owned quad C[m][n..n+3] (m < M, n < N guaranteed by the caller):
@@ -144,6 +162,17 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, long coff, long 
       }
     }
   }
+}
+
+// host: pick the XCD blocking for a tile grid
+inline int choose_xm(int mtiles, int ntiles) {
+  int best = 1;
+  double bc = 1e30;
+  for (int xm = 1; xm <= 8; xm *= 2) {
+    const double c = (double)mtiles / xm + (double)ntiles / (8 / xm);
+    if (c < bc - 1e-9) { bc = c; best = xm; }
+  }
+  return best;
 }
 
 // v2 (LDS-DMA pipelined) launcher, defined in gemm2.hip. cfg: 0 = 256x128 tile, 1 = 128x256, 2 = 128x128.
