@@ -59,6 +59,8 @@ typedef struct vq3_gemm_desc {
   float alpha;
   int32_t transA;     /* 0: A is [M, lda] (contraction contiguous); 1: A is [K, lda] ("k-major", element (m,k) at k*lda+m) */
   int32_t transB;     /* 0: B is [N, ldb]; 1: B is [K, ldb] */
+  int32_t ksplit;     /* > 1: split the contraction over this many workgroup slices; C must be f32, zero-initialised,
+                         no epilogue (partials meet by f32 atomics) - for tiny-M / huge-K shapes (lm_head dgrad) */
 } vq3_gemm_desc;
 
 int vq3_gemm_bf16_nt(const vq3_gemm_desc* desc, void* stream);

@@ -376,3 +376,12 @@ def test_gemm_kmajor_batched_attention_shapes(ops):
                  sB=(Hkv * L * D, L * D), sC=(L * Hq * D, D), transB=True)
     ref = torch.einsum("bhlm,bhmd->blhd", P.float()[..., :L], V.float().repeat_interleave(G, 1)).reshape(Bz, L, Hq * D)
     assert _relerr(O, ref) < 1e-5
+
+
+def test_gemm_split_k(ops):
+    M, N, K = 16, 2560, 152000
+    A = _rand((M, K), 0.1, seed=71); Bk = _rand((K, N), 0.1, seed=72)   # B k-major
+    ref = A.float() @ Bk.float()
+    out = torch.zeros((M, N), device="cuda", dtype=F32)
+    ops.gemm_raw(A, Bk, out, M, N, K, K, N, N, transB=True, ksplit=12, alpha=0.5)
+    assert _relerr(out, 0.5 * ref) < 1e-4

@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
         ("nb1", i32), ("nb2", i32), ("b2divB", i32),
         ("act", i32), ("out_f32", i32), ("accumulate", i32),
         ("alpha", f32),
-        ("transA", i32), ("transB", i32),
+        ("transA", i32), ("transB", i32), ("ksplit", i32),
     ]
 
 

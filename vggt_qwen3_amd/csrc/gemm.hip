@@ -213,6 +213,7 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   p.sC1 = d->sC1; p.sC2 = d->sC2; p.sR1 = d->sR1; p.sR2 = d->sR2;
   p.nb2 = d->nb2; p.b2divB = d->b2divB;
   p.act = d->act; p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.alpha = d->alpha;
+  p.kper = d->K; p.nsplit = 1;
   const int esz = d->out_f32 ? 4 : 2;
   bool vec = (d->ldc % 4 == 0) && (d->sC1 % 4 == 0) && (d->sC2 % 4 == 0) && ((uintptr_t)d->C % (4 * esz) == 0);
   if (d->R) vec = vec && (d->ldr % 4 == 0) && (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0) && ((uintptr_t)d->R % (4 * esz) == 0);
@@ -220,6 +221,18 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
 
   hipStream_t s = (hipStream_t)stream;
   const int nbatch = d->nb1 * d->nb2;
+  if (d->ksplit > 1) {
+    VQ3_CHECK_ARG(d->out_f32 && !d->bias && !d->colscale && !d->R && d->act == 0 && !d->accumulate,
+                  "gemm: split-K needs a zero-initialised f32 C and no epilogue");
+    int kper = ((d->K + d->ksplit - 1) / d->ksplit + 63) / 64 * 64;
+    p.kper = kper;
+    p.nsplit = (d->K + kper - 1) / kper;
+    VQ3_CHECK_ARG(p.nsplit <= 65535, "gemm: too many K slices");
+    const int rc = launch_gemm_v3(p, d->transA, d->transB, 2, nbatch, s);
+    if (rc) return rc;
+    VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3 split-K)");
+    return 0;
+  }
   if (d->transA || d->transB || d->K % BK != 0) {
     const int rc = launch_gemm_v3(p, d->transA, d->transB, choose_v3_stages(d->M, d->N, d->K, nbatch), nbatch, s);
     if (rc) return rc;

@@ -66,7 +66,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
   const bf16_t* B = p.B + b1 * p.sB1 + (long)(b2 / p.b2divB) * p.sB2;
   const long coff = b1 * p.sC1 + b2 * p.sC2;
   const long roff = b1 * p.sR1 + b2 * p.sR2;
-  const int K = p.K;
+  // split-K: this workgroup contracts k in [kbeg, kbeg + K)
+  const int kbeg = blockIdx.y * p.kper;
+  const int K = (p.K - kbeg) < p.kper ? (p.K - kbeg) : p.kper;
+  A += AKM ? (long)kbeg * p.lda : (long)kbeg;
+  B += BKM ? (long)kbeg * p.ldb : (long)kbeg;
   const int nt = (K + BK - 1) / BK, last = nt - 1;
   const int krem = K & (BK - 1);  // 0 or a multiple of 8: valid depth of the last tile
 
@@ -310,7 +314,7 @@ int launch_v3(GemmParams& p, int nbatch, hipStream_t stream) {
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = (p.N + BN - 1) / BN;
   p.xm = choose_xm(p.mtiles, p.ntiles);
-  dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
+  dim3 grid(p.mtiles * p.ntiles, p.nsplit, nbatch);
   if (p.out_f32)
     hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, true>), grid, dim3(64 * (8 + NLOAD)), SMEM, stream, p);
   else

@@ -18,6 +18,8 @@ struct GemmParams {
   int nb2, b2divB;
   int mtiles, ntiles;
   int xm;          // XCD blocking of the tile grid along M (1, 2, 4 or 8)
+  int kper;        // split-K: K range per blockIdx.y slice (multiple of 64); == K when not split
+  int nsplit;      // number of K slices (gridDim.y); > 1 => f32 output combined with atomics
   int act;         // 0 none, 1 gelu(erf), 2 silu
   int out_f32;     // C / R dtype: 0 bf16, 1 f32
   int accumulate;  // C += result
@@ -115,6 +117,10 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, long coff, long 
   }
   out_t* cp = C + (long)m * p.ldc + n;
   const out_t* rp = R ? R + (long)m * p.ldr + n : nullptr;
+  if (OUT_F32 && p.nsplit > 1) {   // split-K partial: C was zeroed by the caller, slices meet by f32 atomics
+    for (int r = 0; r < nv; ++r) atomicAdd(reinterpret_cast<float*>(cp) + r, v[r]);
+    return;
+  }
   if (full && p.vec_ok) {
     if (OUT_F32) {
       if (rp) {

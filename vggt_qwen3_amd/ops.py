@@ -43,7 +43,7 @@ def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, 
              *, bias=None, colscale=None, R=None, ldr: int = 0, nb1: int = 1, nb2: int = 1, b2divB: int = 1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), act: int = 0, accumulate: bool = False, alpha: float = 1.0,
              a_off: int = 0, b_off: int = 0, c_off: int = 0, r_off: int = 0, transA: bool = False,
-             transB: bool = False) -> None:
+             transB: bool = False, ksplit: int = 1) -> None:
     """Raw descriptor launch. A/B bf16; C bf16 or f32 (decides out_f32). Offsets are in elements.
     transA / transB: the operand is stored k-major ([K, ld]) instead of [M or N, ld]."""
     _req(A, BF16, "gemm A"); _req(B, BF16, "gemm B")
@@ -64,7 +64,7 @@ def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, 
     d.nb1, d.nb2, d.b2divB = nb1, nb2, b2divB
     d.act = act; d.out_f32 = 1 if C.dtype == F32 else 0; d.accumulate = 1 if accumulate else 0
     d.alpha = alpha
-    d.transA = 1 if transA else 0; d.transB = 1 if transB else 0
+    d.transA = 1 if transA else 0; d.transB = 1 if transB else 0; d.ksplit = ksplit
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

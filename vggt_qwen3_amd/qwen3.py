@@ -479,8 +479,11 @@ class Qwen3ForCausalLM(nn.Module):
         E = self.flat_w[self.table["embed"][0]: self.table["embed"][0] + Vp * H].view(Vp, H)      # incl. the zero pad rows
         dE = self.flat_g[self.table["embed"][0]: self.table["embed"][0] + Vp * H].view(Vp, H)
         # d(hn)[n8, H] = dlogits[n8, Vp] . E[Vp, H]       (E: k-major B; pad rows/cols are zero on both sides)
-        d_hn = torch.empty((n8, H), device=dev, dtype=BF16)
-        ops.gemm_raw(dlog, E, d_hn, n8, H, Vp, Vp, H, H, alpha=gscale, transB=True)
+        # n8 is a handful of rows and K = 152 000: split the contraction over ~one workgroup per CU
+        d_hn32 = torch.zeros((n8, H), device=dev, dtype=F32)
+        ntile = ((n8 + 127) // 128) * ((H + 127) // 128)
+        ops.gemm_raw(dlog, E, d_hn32, n8, H, Vp, Vp, H, H, alpha=gscale, transB=True, ksplit=max(2, 256 // ntile))
+        d_hn = ops.cast(d_hn32, BF16)
         # dE[Vp, H] (+)= dlogits^T[Vp, n8] . hn[n8, H]    (both k-major; contraction = the n8 selected rows)
         ops.gemm_raw(dlog, head_ctx["hn"], dE, Vp, H, n8, Vp, H, H, accumulate=accumulate, alpha=gscale, transA=True,
                      transB=True)
