@@ -4,6 +4,8 @@
 //   S^T = K . Q^T        (A = K tile rows, B = Q fragment held in VGPRs for the whole kernel)
 //   O^T += V^T . P^T     (the S^T accumulator, exponentiated and packed to bf16, IS the B operand: no LDS round trip)
 // so every softmax statistic of a query row lives on the lane that owns that query column.
+#include <cstdlib>
+
 #include "common.h"
 #include "vq3_hip.h"
 
@@ -109,10 +111,12 @@ __global__ __launch_bounds__(256) void vit_qkprep_kernel(const bf16_t* __restric
 // O[(g*N + q) * ldo + h*64 + d] with NB = G*NH, g = nb / NH, h = nb % NH.
 // Block = 4 waves x 32 query rows; KV tile = 64 keys. LDS: K tile [64][64] and V^T tile [64][64], 16-byte chunks
 // XOR-swizzled with (row >> 1) & 7 so the fragment reads (lane = row) are conflict-free / 2-way.
-constexpr int FA_Q = 128, FA_KV = 64;
+constexpr int FA_KV = 64;
 
 __device__ __forceinline__ int fa_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// QB = 32-row query blocks per wave (1 or 2): with 2, every K / V^T fragment read from LDS feeds two MFMAs.
+template <int QB>
 __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                               int N, int Np, int NH, long ldo, float scale_log2e) {
@@ -121,23 +125,28 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const long nb = blockIdx.y;
-  const int q0 = blockIdx.x * FA_Q + wid * 32;
+  const int q0 = blockIdx.x * (128 * QB) + wid * (32 * QB);
   const bf16_t* Qb = Q + nb * (long)N * 64;
   const bf16_t* Kb = K + nb * (long)N * 64;
   const bf16_t* Vb = Vt + nb * 64L * Np;
 
-  // Q fragments: B operand, lane (r,h) holds Q[q0+r][16s + 8h .. +8]
-  bf16x8 qf[4];
-  {
-    int qr = q0 + r;
+  // Q fragments: B operand, lane (r,h) holds Q[q0 + 32*qb + r][16s + 8h .. +8]
+  bf16x8 qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    int qr = q0 + 32 * qb + r;
     qr = qr < N ? qr : N - 1;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 16 * s + 8 * h);
+    for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 16 * s + 8 * h);
   }
-  f32x16 o0, o1;
+  f32x16 o0[QB], o1[QB];
+  float m_run[QB], l_run[QB];   // running max in the scaled (log2) domain
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;   // running max in the scaled (log2) domain
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[qb][i] = 0.f; o1[qb][i] = 0.f; }
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+  }
 
   // staging: 512 16-byte chunks per tile, 2 per thread: chunk id c = tid + 256*i -> row c>>3, chunk c&7
   const int srow0 = tid >> 3, sch = tid & 7;
@@ -189,81 +198,95 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
     const bool more = t + 1 < nt;
     const char* sb = smem + (t & 1) * (2 * FA_KV * 128);
     if (more) load_tile(t + 1);
-    // ---- S^T = K . Q^T for the two 32-key sub-tiles
-    f32x16 s0, s1;
+    // ---- S^T = K . Q^T for the two 32-key sub-tiles (each K fragment feeds QB query blocks)
+    f32x16 s0[QB], s1[QB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s0[qb][i] = 0.f; s1[qb][i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sb + koff0[s]);
       const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sb + koff1[s]);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        s0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[qb][s], s0[qb], 0, 0, 0);
+        s1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[qb][s], s1[qb], 0, 0, 0);
+      }
     }
     // ---- online softmax (per query column = per lane pair (lane, lane^32)); masking only on the last tile
     const int kbase = t * FA_KV;
-    if (kbase + FA_KV > N) {   // wave-uniform
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      if (kbase + FA_KV > N) {   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key0 = kbase + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key0 >= N) s0[qb][i] = -INFINITY;
+          if (key0 + 32 >= N) s1[qb][i] = -INFINITY;
+        }
+      }
+      float mx = fmaxf(s0[qb][0], s1[qb][0]);
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[qb][i], s1[qb][i]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qb], mx * scale_log2e);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+      float ps = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int key0 = kbase + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (key0 >= N) s0[i] = -INFINITY;
-        if (key0 + 32 >= N) s1[i] = -INFINITY;
+        s0[qb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[qb][i], scale_log2e, -m_new));
+        s1[qb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[qb][i], scale_log2e, -m_new));
+        ps += s0[qb][i] + s1[qb][i];
       }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run[qb] = l_run[qb] * alpha + ps;
+      m_run[qb] = m_new;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; }
     }
-    float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale_log2e);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float ps = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], scale_log2e, -m_new));
-      s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], scale_log2e, -m_new));
-      ps += s0[i] + s1[i];
-    }
-    ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
     // ---- O^T += V^T . P^T : B operand = packed S^T registers 8s'..8s'+7 (k order: 16s' + 8(j>>2) + 4h + (j&3))
 #pragma unroll
     for (int u = 0; u < 4; ++u) {   // u = sub*2 + sp
-      bf16x8 pf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(u < 2 ? s0[8 * (u & 1) + j] : s1[8 * (u & 1) + j]);
       const u32x2 a0 = *reinterpret_cast<const u32x2*>(sb + voffa[u][0]);
       const u32x2 a1 = *reinterpret_cast<const u32x2*>(sb + voffa[u][1]);
       const u32x2 b0 = *reinterpret_cast<const u32x2*>(sb + voffb[u][0]);
       const u32x2 b1 = *reinterpret_cast<const u32x2*>(sb + voffb[u][1]);
       const u32x4 ta = {a0[0], a0[1], a1[0], a1[1]};
       const u32x4 tb = {b0[0], b0[1], b1[0], b1[1]};
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), pf, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1, 0, 0, 0);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(u < 2 ? s0[qb][8 * (u & 1) + j] : s1[qb][8 * (u & 1) + j]);
+        o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), pf, o0[qb], 0, 0, 0);
+        o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1[qb], 0, 0, 0);
+      }
     }
     if (more) store_tile((t + 1) & 1);
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns query q0+r, d = 32*db + (i&3) + 8*(i>>2) + 4h
-  const int q = q0 + r;
-  if (q < N) {
-    const float inv = 1.f / l_run;
-    const long g = nb / NH;
-    const int hd = (int)(nb % NH);
-    bf16_t* orow = O + (g * N + q) * ldo + hd * 64;
+  // ---- epilogue: lane owns query q0 + 32*qb + r, d = 32*db + (i&3) + 8*(i>>2) + 4h
 #pragma unroll
-    for (int i4 = 0; i4 < 4; ++i4) {
-      const int d = 8 * i4 + 4 * h;
-      u32x2 w0, w1;
-      w0[0] = pack2bf(o0[4 * i4 + 0] * inv, o0[4 * i4 + 1] * inv);
-      w0[1] = pack2bf(o0[4 * i4 + 2] * inv, o0[4 * i4 + 3] * inv);
-      w1[0] = pack2bf(o1[4 * i4 + 0] * inv, o1[4 * i4 + 1] * inv);
-      w1[1] = pack2bf(o1[4 * i4 + 2] * inv, o1[4 * i4 + 3] * inv);
-      *reinterpret_cast<u32x2*>(orow + d) = w0;
-      *reinterpret_cast<u32x2*>(orow + 32 + d) = w1;
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q0 + 32 * qb + r;
+    if (q < N) {
+      const float inv = 1.f / l_run[qb];
+      const long g = nb / NH;
+      const int hd = (int)(nb % NH);
+      bf16_t* orow = O + (g * N + q) * ldo + hd * 64;
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int d = 8 * i4 + 4 * h;
+        u32x2 w0, w1;
+        w0[0] = pack2bf(o0[qb][4 * i4 + 0] * inv, o0[qb][4 * i4 + 1] * inv);
+        w0[1] = pack2bf(o0[qb][4 * i4 + 2] * inv, o0[qb][4 * i4 + 3] * inv);
+        w1[0] = pack2bf(o1[qb][4 * i4 + 0] * inv, o1[qb][4 * i4 + 1] * inv);
+        w1[1] = pack2bf(o1[qb][4 * i4 + 2] * inv, o1[qb][4 * i4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(orow + d) = w0;
+        *reinterpret_cast<u32x2*>(orow + 32 + d) = w1;
+      }
     }
   }
 }
@@ -305,10 +328,19 @@ extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* Vt, 
   VQ3_CHECK_ARG(G > 0 && NH > 0 && N > 0 && Np >= N && Np % 64 == 0, "flash_attn_fwd: bad shape (Np %% 64)");
   VQ3_CHECK_ARG((long)G * NH <= 65535, "flash_attn_fwd: too many (group, head) pairs");
   VQ3_CHECK_ARG(ldo >= (long)NH * 64 && ldo % 4 == 0, "flash_attn_fwd: bad ldo");
-  dim3 grid((N + FA_Q - 1) / FA_Q, G * NH);
-  hipLaunchKernelGGL(flash_attn_hd64_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                     (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, N, Np, NH, (long)ldo,
-                     scale * 1.44269504088896340736f);
+    static int qb_forced = -1;
+  if (qb_forced < 0) { const char* e = getenv("VQ3_FLASH_QB"); qb_forced = e ? atoi(e) : 0; }
+  // measured (tools/bench_flash.py): QB=2 +3 % at N = 1029 (fewer, fuller workgroups), -11 % at N = 8232 (occupancy 2 vs 3)
+  const int qb = qb_forced ? qb_forced : ((N >= 512 && N < 4096) ? 2 : 1);
+  dim3 grid((N + 128 * qb - 1) / (128 * qb), G * NH);
+  if (qb == 2)
+    hipLaunchKernelGGL(flash_attn_hd64_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, N, Np, NH, (long)ldo,
+                       scale * 1.44269504088896340736f);
+  else
+    hipLaunchKernelGGL(flash_attn_hd64_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, N, Np, NH, (long)ldo,
+                       scale * 1.44269504088896340736f);
   VQ3_CHECK_LAUNCH("flash_attn_fwd");
   return 0;
 }
