@@ -233,6 +233,30 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3 split-K)");
     return 0;
   }
+  static int v4mode = -1, ncu = 0;
+  if (v4mode < 0) {
+    const char* e = getenv("VQ3_GEMM_V4");
+    v4mode = e ? atoi(e) : 0;  // opt-in: measured slower than the per-tile loader kernels
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  {
+    // persistent producer/consumer kernel (gemm4.hip): mode 1 = wherever the 4-stage loader ring would be chosen,
+    // mode 2 = every 128x128-tile GEMM, 0 = never
+    const bool v3case = d->transA || d->transB || d->K % BK != 0;
+    bool use4 = false;
+    if (v4mode == 2) use4 = true;
+    else if (v4mode == 1) use4 = v3case ? choose_v3_stages(d->M, d->N, d->K, nbatch) == 3
+                                        : (getenv("VQ3_GEMM_CFG") == nullptr && choose_config(d->M, d->N, d->K, nbatch) == 13);
+    if (use4) {
+      const int rc = launch_gemm_v4(p, d->transA, d->transB, nbatch, ncu, s);
+      if (rc) return rc;
+      VQ3_CHECK_LAUNCH("gemm_bf16_nt(v4)");
+      return 0;
+    }
+  }
   if (d->transA || d->transB || d->K % BK != 0) {
     const int rc = launch_gemm_v3(p, d->transA, d->transB, choose_v3_stages(d->M, d->N, d->K, nbatch), nbatch, s);
     if (rc) return rc;

@@ -38,9 +38,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // blocking of the tile grid (walked m-fastest): the tiles sharing an L2 then re-read only mtiles/xm row panels of A
 // and ntiles/xn panels of B. The host picks xm in {1,2,4,8} minimising mtiles/xm + ntiles/xn (xm = 1 is "n-tile
 // major" order). Bijective for any grid size; placement only ever affects speed.
-__device__ __forceinline__ void tile_coords(const GemmParams& p, int BM, int BN, int& m0, int& n0) {
+__device__ __forceinline__ void tile_coords_id(const GemmParams& p, int orig, int BM, int BN, int& m0, int& n0) {
   const int nwg = p.mtiles * p.ntiles;
-  const int orig = blockIdx.x;
   const int xcd = orig & 7, idx = orig >> 3;
   const int q = nwg >> 3, r = nwg & 7;
   int s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // position in the region-major sequence
@@ -61,6 +60,9 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int BM, int BN,
   }
   m0 = mt * BM;
   n0 = ntl * BN;
+}
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int BM, int BN, int& m0, int& n0) {
+  tile_coords_id(p, blockIdx.x, BM, BN, m0, n0);
 }
 
 // Epilogue for one lane-owned quad C[m][n..n+3] (m < M, n < N guaranteed by the caller):
@@ -183,6 +185,8 @@ inline int choose_xm(int mtiles, int ntiles) {
 
 // v2 (LDS-DMA pipelined) launcher, defined in gemm2.hip. cfg: 0 = 256x128 tile, 1 = 128x256, 2 = 128x128.
 int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream);
+// v4 (persistent producer/consumer, any layout), defined in gemm4.hip. ncu = workgroups to launch (one per CU).
+int launch_gemm_v4(GemmParams& p, int transA, int transB, int nbatch, int ncu, hipStream_t stream);
 // v3 (any operand layout, K % 8 == 0), defined in gemm3.hip. nstage: 2 or 3.
 int launch_gemm_v3(GemmParams& p, int transA, int transB, int nstage, int nbatch, hipStream_t stream);
 
