@@ -187,6 +187,42 @@ int vq3_flash_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, in
 int vq3_adamw_step(float* master, float* m, float* v, const void* grad_bf16, void* w_bf16, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int32_t step, float gscale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Batch builder: the collator step right before the model (src/dataio/collate_multiview.py)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* One source image of a vq3_resize_crop_u8 batch. `src` is a DEVICE pointer to uint8 RGB, row-major HWC with `pitch`
+ * bytes per row. The *_off fields index the shared `coefs` / `bounds` device arrays (int32 elements) where this
+ * image's horizontal (kh, bh) and vertical (kv, bv) resampling plans start; crop_x / crop_y locate the S x S centre
+ * crop inside the resized image (torchvision center_crop: int(round((size - S) / 2.0)), round-half-even). */
+typedef struct vq3_image_desc {
+  const uint8_t* src;
+  int32_t h, w, pitch;
+  int32_t ksize_h, ksize_v;
+  int32_t kh_off, kv_off;
+  int32_t bh_off, bv_off;
+  int32_t crop_x, crop_y;
+} vq3_image_desc;
+
+/* Pillow's bicubic resampling plan for one axis (PIL.Image.resize(..., BICUBIC) as called by
+ * torchvision.transforms.Resize, collate_multiview.py:15): taps per output index. HOST function, needs no GPU.
+ * vq3_resample_ksize returns the row stride of `coefs` (taps per output, -1 on bad sizes); vq3_resample_plan fills
+ * bounds[out_size*2] = {first source index, tap count} and coefs[out_size*ksize] (22-bit fixed point). */
+int vq3_resample_ksize(int32_t in_size, int32_t out_size);
+int vq3_resample_plan(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* coefs);
+/* Resize(S, BICUBIC) -> CenterCrop(S) -> ToTensor() (collate_multiview.py:12-19) for n_images uint8 images in one
+ * launch: out f32 [n_images, 3, S, S] in [0,1], bit-identical to the PIL/torchvision pipeline. tile_rows output rows
+ * per workgroup; max_src_rows = the largest number of source rows any such tile touches (LDS: max_src_rows*256 B). */
+int vq3_resize_crop_u8(const vq3_image_desc* descs_dev, int32_t n_images, const int32_t* coefs_dev,
+                       const int32_t* bounds_dev, float* out, int32_t S, int32_t tile_rows, int32_t max_src_rows,
+                       void* stream);
+/* Token layout of MultiViewCollator.__call__ (collate_multiview.py:56-79): row b = (prompt_b + answer_b)[:max_length]
+ * padded with pad_id to L; labels = -100 on the prompt and the padding, the answer ids elsewhere; attention_mask =
+ * (input_ids != pad_id). prompt_ids / answer_ids are the concatenated ragged lists (int32), *_off [B+1] their row
+ * starts; outputs int64 [B, L]. L (>= every truncated row) is chosen by the caller (:69 max(longest, floor)). */
+int vq3_pack_tokens(const int32_t* prompt_ids, const int32_t* prompt_off, const int32_t* answer_ids,
+                    const int32_t* answer_off, int32_t B, int32_t L, int32_t max_length, int64_t pad_id,
+                    int64_t* input_ids, int64_t* labels, int64_t* attention_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

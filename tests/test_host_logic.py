@@ -111,3 +111,60 @@ def test_bucketed_allreduce_world2_gloo():
     ret = mgr.dict()
     mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r][0] and ret[r][1] for r in range(world)), dict(ret)
+
+
+def test_checkpoint_layout_and_search_order(tmp_path):
+    """File layout / index / search order of vggt_qwen3_amd.checkpoint (reference: qa_inference.py:51-105), on a small
+    stand-in module (no GPU): sharded dir wins over flat files, legacy dir name accepted, first flat file otherwise."""
+    import json
+    from vggt_qwen3_amd import checkpoint as ck
+
+    def make(seed):
+        torch.manual_seed(seed)
+        m = torch.nn.Module()
+        m.text_model = torch.nn.Module()
+        m.text_model.lm_head = torch.nn.Linear(8, 16, bias=False)
+        m.text_model.model = torch.nn.Module()
+        m.text_model.model.embed_tokens = torch.nn.Embedding(16, 8)
+        m.text_model.lm_head.weight = m.text_model.model.embed_tokens.weight
+        m.projector = torch.nn.Linear(8, 8)
+        m.vision_model = torch.nn.Linear(4, 4)
+        return m
+
+    a = make(1)
+    wm = ck.save_model(a, tmp_path / "run", max_shard_bytes=300)
+    root = tmp_path / "run" / ck.MERGED_DIR
+    idx = json.loads((root / ck.INDEX_NAME).read_text())
+    assert idx["weight_map"] == wm
+    assert sorted(wm) == ["projector.bias", "projector.weight", "text_model.model.embed_tokens.weight"]
+    assert len(set(wm.values())) >= 2 and all((root / f).exists() for f in wm.values())
+    assert idx["metadata"]["total_size"] == 4 * (8 + 64 + 128)
+    # a decoy flat file next to the sharded dir must be ignored
+    torch.save({"projector.bias": torch.full((8,), 9.0)}, tmp_path / "run" / "zzz.bin")
+    b = make(2)
+    rep = ck.load_checkpoint_if_available(b, str(tmp_path / "run"), verbose=False)
+    assert sorted(rep["matched"]) == sorted(wm)
+    assert [k for k in rep["missing"] if not k.startswith("vision_model")] == []
+    for k in wm:
+        assert torch.equal(a.state_dict()[k], b.state_dict()[k])
+    assert torch.equal(b.text_model.lm_head.weight, a.text_model.model.embed_tokens.weight)
+    # legacy directory name
+    (tmp_path / "legacy").mkdir()
+    root.rename(tmp_path / "legacy" / ck.LEGACY_MERGED_DIR)
+    c = make(3)
+    assert ck.load_checkpoint_if_available(c, str(tmp_path / "legacy"), verbose=False) is not None
+    assert torch.equal(c.projector.weight, a.projector.weight)
+    # flat file: only the first one is read; unknown keys are reported, not fatal
+    (tmp_path / "flat").mkdir()
+    torch.save({"projector.bias": torch.full((8,), 3.0), "nope": torch.zeros(1)}, tmp_path / "flat" / "a.bin")
+    d = make(4)
+    rep = ck.load_checkpoint_if_available(d, str(tmp_path / "flat"), verbose=False)
+    assert rep["unexpected"] == ["nope"] and torch.all(d.projector.bias == 3.0)
+    # shape mismatch raises, missing directory / empty directory keep the base weights
+    torch.save({"projector.bias": torch.zeros(3)}, tmp_path / "flat" / "a.bin")
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        ck.load_checkpoint_if_available(make(5), str(tmp_path / "flat"), verbose=False)
+    assert ck.load_checkpoint_if_available(make(6), str(tmp_path / "absent"), verbose=False) is None
+    (tmp_path / "empty").mkdir()
+    assert ck.load_checkpoint_if_available(make(7), str(tmp_path / "empty"), verbose=False) is None
+    assert ck.load_checkpoint_if_available(make(8), None) is None

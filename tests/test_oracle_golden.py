@@ -95,3 +95,41 @@ def test_splice_overrun_raises_like_reference():
         ovlm.splice(torch.zeros(1, 4, 8), ids, torch.ones(1, 3, 8), image_id=7)
     with pytest.raises(RuntimeError):
         ovlm.splice_srcmap(ids, 3, 7)
+
+
+def test_preprocess_oracle_matches_pillow_golden_and_live():
+    """oracle.preprocess (restated Pillow resample + torchvision size/crop rules) against the committed Pillow outputs
+    and, when Pillow is importable, against Pillow itself on fresh random sizes. uint8 / float32: bit-exact."""
+    from oracle import preprocess as opre
+    z = load("preprocess_tiny.npz")
+    for i, (h, w, S) in enumerate(meta(z)["cases"]):
+        img = z[f"in{i}"]
+        nh, nw = opre.resized_size(h, w, S)
+        assert (nh, nw) == z[f"resized{i}"].shape[:2]
+        assert np.array_equal(opre.pil_resize_bicubic(img, nh, nw), z[f"resized{i}"]), i
+        got = opre.transform(img, S)
+        assert got.dtype == np.float32 and np.array_equal(got, z[f"out{i}"]), i
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(7)
+    for _ in range(6):
+        h, w, S = int(rng.integers(9, 120)), int(rng.integers(9, 120)), int(rng.integers(8, 64))
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        nh, nw = opre.resized_size(h, w, S)
+        ref = np.asarray(Image.fromarray(a, "RGB").resize((nw, nh), Image.BICUBIC))
+        assert np.array_equal(opre.pil_resize_bicubic(a, nh, nw), ref), (h, w, S)
+
+
+def test_library_resample_plan_matches_oracle():
+    """vq3_resample_plan is a host routine (no GPU): its taps and bounds equal the restated Pillow plan bit for bit."""
+    from oracle import preprocess as opre
+    from vggt_qwen3_amd import _lib
+    lib = _lib.load()
+    for i, o in [(53, 16), (600, 448), (33, 40), (1000, 448), (448, 448), (4032, 448), (7, 300)]:
+        ks = lib.vq3_resample_ksize(i, o)
+        b = np.empty((o, 2), np.int32)
+        c = np.empty((o, ks), np.int32)
+        assert lib.vq3_resample_plan(i, o, b.ctypes.data, c.ctypes.data) == 0
+        k2, b2, c2 = opre.precompute_coeffs(i, o)
+        assert ks == k2 and np.array_equal(b, b2) and np.array_equal(c, c2), (i, o)
+    assert lib.vq3_resample_ksize(0, 5) == -1
+    assert lib.vq3_resample_plan(5, 0, b.ctypes.data, c.ctypes.data) != 0

@@ -29,6 +29,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class ImageDesc(C.Structure):
+    _fields_ = [("src", c_p), ("h", i32), ("w", i32), ("pitch", i32), ("ksize_h", i32), ("ksize_v", i32),
+                ("kh_off", i32), ("kv_off", i32), ("bh_off", i32), ("bv_off", i32), ("crop_x", i32), ("crop_y", i32)]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES). Must match include/vq3_hip.h.
 SIGNATURES = {
     "vq3_abi_version": [],
@@ -57,6 +62,10 @@ SIGNATURES = {
     "vq3_vit_qkprep": [c_p] * 10 + [i64, i32, i32, i32, i32, i32, i32, i32, i32, f32, c_p],
     "vq3_flash_attn_fwd": [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i64, f32, c_p],
     "vq3_adamw_step": [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p],
+    "vq3_resample_ksize": [i32, i32],
+    "vq3_resample_plan": [i32, i32, c_p, c_p],
+    "vq3_resize_crop_u8": [c_p, i32, c_p, c_p, c_p, i32, i32, i32, c_p],
+    "vq3_pack_tokens": [c_p, c_p, c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p, c_p],
 }
 _RESTYPES = {"vq3_last_error": C.c_char_p, "vq3_target_arch": C.c_char_p}
 

@@ -159,6 +159,14 @@ class VGGTQwen3VLM(nn.Module):
         self._prefetched = None
         self._text_param_names = [n for n, _ in self.text_model.named_parameters()]
 
+    def _apply(self, fn, recurse=True):
+        """`.to(...)`, `.cpu()`, `.cuda()`, `.float()`, `.bfloat16()` are no-ops: the weights live in HBM in the flat,
+        GEMM-ready layout they were allocated in (config.device / config.dtype decide that at construction). Callers
+        written for the reference - `VGGTQwen3VLM(cfg).to(device)` (qa_inference.py:44), the checkpoint loader's
+        `model.to("cpu") ... model.to(orig_device)` (qa_inference.py:60,104) - therefore work unchanged;
+        `load_state_dict` copies host tensors into the resident parameters."""
+        return self
+
     # ------------------------------------------------------------------ loaders
     @staticmethod
     def _load_tokenizer(name: str, vocab: int):
