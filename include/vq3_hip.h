@@ -223,6 +223,34 @@ int vq3_pack_tokens(const int32_t* prompt_ids, const int32_t* prompt_off, const 
                     const int32_t* answer_off, int32_t B, int32_t L, int32_t max_length, int64_t pad_id,
                     int64_t* input_ids, int64_t* labels, int64_t* attention_mask, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Greedy decoding with a resident KV cache (src/inference/qa_inference.py:207-216, arkit_inference.py:274-284:
+ * text_model.generate(inputs_embeds=..., do_sample=False, num_beams=1, repetition_penalty, no_repeat_ngram_size))
+ * All per-step state (lens, step, generated, finished) is read from DEVICE memory so a step can be graph-replayed.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* y[M, N] = x[M, K] . W[N, K]^T (+ residual[M, N] bf16), 1 <= M <= 8: the weight-streaming (HBM-bound) form of
+ * nn.Linear for one token per row. x, W bf16, K % 8 == 0; y bf16 (or f32 if out_f32). */
+int vq3_skinny_gemm_bf16(const void* x, const void* W, void* y, const void* residual, int32_t M, int32_t N, int32_t K,
+                         int64_t ldx, int64_t ldw, int64_t ldy, int64_t ldr, int32_t out_f32, void* stream);
+/* One new token per row: qkv bf16 [B, (Hq+2Hkv)*128] -> q_norm/k_norm + RoPE at position lens[b]
+ * (modeling_qwen3.py:237-253); Q bf16 [B, Hq, 128]; K, V written into the caches [B, Hkv, Lmax, 128] at slot lens[b].
+ * cos/sin: bf16 [>= Lmax, 128] tables. */
+int vq3_qwen_decode_qkprep(const void* qkv, const void* q_w, const void* k_w, const void* cos, const void* sin,
+                           const int32_t* lens, void* Q, void* Kcache, void* Vcache, int32_t B, int32_t Hq,
+                           int32_t Hkv, int32_t head_dim, int32_t Lmax, float eps, void* stream);
+/* O[b, h, :] = softmax(scale * q . K[b, h/G, :lens[b]+1]^T) . V[b, h/G, :lens[b]+1]  (GQA, fp32 softmax). */
+int vq3_qwen_decode_attn(const void* Q, const void* Kcache, const void* Vcache, const int32_t* lens, void* O, int32_t B,
+                         int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t Lmax, float scale, void* stream);
+/* transformers greedy step on bf16 logits [B, ld]: RepetitionPenaltyLogitsProcessor over generated[b, :*step], then
+ * NoRepeatNGramLogitsProcessor, argmax (first index on ties), finished rows emit pad_id, eos marks a row finished.
+ * Writes generated[b, *step] and next_ids[b]. work: f32 scratch [B, V]. */
+int vq3_greedy_pick(const void* logits_bf16, int64_t ld_logits, float* work, int32_t B, int32_t V, int64_t* generated,
+                    int32_t max_new, const int32_t* step, int32_t* finished, float repetition_penalty,
+                    int32_t no_repeat_ngram, const int64_t* eos_ids, int32_t n_eos, int64_t pad_id, int32_t* next_ids,
+                    void* stream);
+/* lens[b] += 1 for b < B (B <= 64), *step += 1 (either pointer may be NULL): the last launch of a decode step. */
+int vq3_decode_advance(int32_t* lens, int32_t B, int32_t* step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

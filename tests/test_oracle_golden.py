@@ -133,3 +133,21 @@ def test_library_resample_plan_matches_oracle():
         assert ks == k2 and np.array_equal(b, b2) and np.array_equal(c, c2), (i, o)
     assert lib.vq3_resample_ksize(0, 5) == -1
     assert lib.vq3_resample_plan(5, 0, b.ctypes.data, c.ctypes.data) != 0
+
+
+def test_generate_oracle_matches_transformers_golden():
+    """oracle.generate (cache-free greedy loop + restated logits processors) reproduces transformers' generate() ids
+    exactly on every golden case: single row, n-gram ban, left-padded batch with early finish, multi-eos, input_ids."""
+    from oracle import generate as ogen
+    z = load("qwen3_tiny.npz")
+    sd = weights(z)
+    cfg = oq.Qwen3Cfg(**meta(z, "config"))
+    g = load("generate_tiny.npz")
+    for case in meta(g)["cases"]:
+        n, kw = case["name"], dict(case["kw"])
+        mask = torch.from_numpy(g[f"{n}:mask"])
+        if n == "ids":
+            out = ogen.greedy_generate(sd, cfg, None, mask, input_ids=torch.from_numpy(g["ids:input_ids"]), **kw)
+        else:
+            out = ogen.greedy_generate(sd, cfg, bf16(g[f"{n}:embeds"]), mask, **kw)
+        assert np.array_equal(out.numpy(), g[f"{n}:out"]), n

@@ -359,3 +359,57 @@ def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     check(_lib.load().vq3_flash_attn_fwd(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), G, NH, N, Np, D,
                                          out.stride(0), D ** -0.5, _stream()), "vq3_flash_attn_fwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- decoding
+def skinny_linear(x: torch.Tensor, w: torch.Tensor, *, residual: Optional[torch.Tensor] = None, n: Optional[int] = None,
+                  out: Optional[torch.Tensor] = None, out_dtype=BF16) -> torch.Tensor:
+    """y = x w^T (+ residual) for 1..8 rows: streams the weight once (vq3_skinny_gemm_bf16). `n` limits the output
+    features to the first n rows of w (tied lm_head: the vocabulary rows of the padded embedding)."""
+    _req(x, BF16, "skinny x"); _req(w, BF16, "skinny w")
+    assert x.dim() == 2 and w.dim() == 2 and x.is_contiguous() and w.is_contiguous() and x.shape[1] == w.shape[1]
+    M, K = x.shape
+    N = w.shape[0] if n is None else n
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=out_dtype)
+    if residual is not None:
+        _req(residual, BF16, "skinny residual"); assert residual.shape == (M, N) and residual.is_contiguous()
+    check(_lib.load().vq3_skinny_gemm_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), _p(residual), M, N, K, K, K,
+                                           out.stride(0), N, 1 if out.dtype == F32 else 0, _stream()),
+          "vq3_skinny_gemm_bf16")
+    return out
+
+
+def qwen_decode_qkprep(qkv, q_w, k_w, cos, sin, lens, Kc, Vc, B, Hq, Hkv, D, Lmax, eps) -> torch.Tensor:
+    _req(qkv, BF16, "decode qkv"); _req(lens, torch.int32, "decode lens"); _req(Kc, BF16, "K cache"); _req(Vc, BF16, "V cache")
+    assert qkv.is_contiguous() and qkv.shape == (B, (Hq + 2 * Hkv) * D)
+    assert Kc.is_contiguous() and Vc.is_contiguous() and Kc.shape == (B, Hkv, Lmax, D) and Vc.shape == Kc.shape
+    assert cos.shape[-2] >= Lmax and cos.shape[-1] == D and cos.is_contiguous() and sin.is_contiguous()
+    Q = torch.empty((B, Hq * D), device=qkv.device, dtype=BF16)
+    check(_lib.load().vq3_qwen_decode_qkprep(qkv.data_ptr(), q_w.data_ptr(), k_w.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                             lens.data_ptr(), Q.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), B, Hq, Hkv, D,
+                                             Lmax, eps, _stream()), "vq3_qwen_decode_qkprep")
+    return Q
+
+
+def qwen_decode_attn(Q, Kc, Vc, lens, B, Hq, Hkv, D, Lmax, scale) -> torch.Tensor:
+    _req(Q, BF16, "decode Q"); assert Q.is_contiguous() and Q.shape == (B, Hq * D)
+    O = torch.empty_like(Q)
+    check(_lib.load().vq3_qwen_decode_attn(Q.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), lens.data_ptr(), O.data_ptr(), B, Hq,
+                                           Hkv, D, Lmax, scale, _stream()), "vq3_qwen_decode_attn")
+    return O
+
+
+def greedy_pick(logits, work, generated, step, finished, penalty, ngram, eos_ids, pad_id, next_ids, V) -> None:
+    _req(logits, BF16, "pick logits"); _req(work, F32, "pick work"); _req(generated, torch.int64, "pick generated")
+    _req(step, torch.int32, "pick step"); _req(finished, torch.int32, "pick finished"); _req(next_ids, torch.int32, "pick next")
+    B = logits.shape[0]
+    assert logits.stride(1) == 1 and work.shape == (B, V) and generated.is_contiguous() and generated.shape[0] == B
+    n_eos = 0 if eos_ids is None else int(eos_ids.numel())
+    check(_lib.load().vq3_greedy_pick(logits.data_ptr(), logits.stride(0), work.data_ptr(), B, V, generated.data_ptr(),
+                                      generated.shape[1], step.data_ptr(), finished.data_ptr(), float(penalty), int(ngram),
+                                      _p(eos_ids), n_eos, int(pad_id), next_ids.data_ptr(), _stream()), "vq3_greedy_pick")
+
+
+def decode_advance(lens: Optional[torch.Tensor], B: int, step: Optional[torch.Tensor]) -> None:
+    check(_lib.load().vq3_decode_advance(_p(lens), B, _p(step), _stream()), "vq3_decode_advance")

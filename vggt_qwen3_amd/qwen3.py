@@ -68,6 +68,16 @@ class _W(nn.Module):
         self.weight = nn.Parameter(weight, requires_grad=True)
 
 
+class _Embedding(_W):
+    """`get_input_embeddings()(input_ids)` as the reference's inference scripts call it (qa_inference.py:189-190)."""
+
+    def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
+        ids = input_ids.to(self.weight.device).reshape(-1).to(torch.int32).contiguous()
+        n = ids.numel()
+        rows = ops.gather_rows(self.weight.detach(), ids, n, n)
+        return rows.view(*input_ids.shape, self.weight.shape[1])
+
+
 class _Attn(nn.Module):
     pass
 
@@ -159,7 +169,7 @@ class Qwen3ForCausalLM(nn.Module):
         c = self.config
         H, I, D = c.hidden_size, c.intermediate_size, c.head_dim
         body = _Body()
-        body.embed_tokens = _W(self._w["embed"])
+        body.embed_tokens = _Embedding(self._w["embed"])
         layers = []
         for i in range(c.num_hidden_layers):
             L = _Layer()
@@ -258,6 +268,11 @@ class Qwen3ForCausalLM(nn.Module):
             sd.update(load_file(str(f)))
         m.load_hf_state_dict(sd, strict=True)
         return m
+
+    def generate(self, *args, **kwargs):
+        """Greedy decoding with a KV cache (vggt_qwen3_amd/generate.py); transformers-compatible keywords."""
+        from .generate import generate as _generate
+        return _generate(self, *args, **kwargs)
 
     # ------------------------------------------------------------------ helpers
     def rope(self, L: int):
