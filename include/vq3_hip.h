@@ -228,10 +228,14 @@ int vq3_pack_tokens(const int32_t* prompt_ids, const int32_t* prompt_off, const 
  * text_model.generate(inputs_embeds=..., do_sample=False, num_beams=1, repetition_penalty, no_repeat_ngram_size))
  * All per-step state (lens, step, generated, finished) is read from DEVICE memory so a step can be graph-replayed.
  * ---------------------------------------------------------------------------------------------------------- */
-/* y[M, N] = x[M, K] . W[N, K]^T (+ residual[M, N] bf16), 1 <= M <= 8: the weight-streaming (HBM-bound) form of
- * nn.Linear for one token per row. x, W bf16, K % 8 == 0; y bf16 (or f32 if out_f32). */
-int vq3_skinny_gemm_bf16(const void* x, const void* W, void* y, const void* residual, int32_t M, int32_t N, int32_t K,
-                         int64_t ldx, int64_t ldw, int64_t ldy, int64_t ldr, int32_t out_f32, void* stream);
+/* y[M, N] = f(x)[M, K] . W[N, K]^T (+ residual[M, N] bf16), 1 <= M <= 8: the weight-streaming (HBM-bound) form of
+ * nn.Linear for one token per row. x, W bf16, K % 8 == 0; y bf16 (or f32 if out_f32). xmode selects f:
+ *   0  f(x) = x
+ *   1  f(x) = ln_w * bf16(x * rsqrt(mean(x^2) + eps))       Qwen3RMSNorm (modeling_qwen3.py:49-64) fused in
+ *   2  f(x) = bf16(bf16(silu(x[:, :K])) * x[:, K:2K])        SwiGLU (modeling_qwen3.py:81-83) fused into down_proj */
+int vq3_skinny_gemm_bf16(const void* x, const void* W, void* y, const void* residual, const void* ln_w, float eps,
+                         int32_t xmode, int32_t M, int32_t N, int32_t K, int64_t ldx, int64_t ldw, int64_t ldy,
+                         int64_t ldr, int32_t out_f32, void* stream);
 /* One new token per row: qkv bf16 [B, (Hq+2Hkv)*128] -> q_norm/k_norm + RoPE at position lens[b]
  * (modeling_qwen3.py:237-253); Q bf16 [B, Hq, 128]; K, V written into the caches [B, Hkv, Lmax, 128] at slot lens[b].
  * cos/sin: bf16 [>= Lmax, 128] tables. */
@@ -243,7 +247,8 @@ int vq3_qwen_decode_attn(const void* Q, const void* Kcache, const void* Vcache, 
                          int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t Lmax, float scale, void* stream);
 /* transformers greedy step on bf16 logits [B, ld]: RepetitionPenaltyLogitsProcessor over generated[b, :*step], then
  * NoRepeatNGramLogitsProcessor, argmax (first index on ties), finished rows emit pad_id, eos marks a row finished.
- * Writes generated[b, *step] and next_ids[b]. work: f32 scratch [B, V]. */
+ * Writes generated[b, *step] and next_ids[b]. work: scratch of >= B*128 + 1 four-byte slots; max_new (columns of
+ * `generated`, prompt ids included when they take part in the penalty) <= 512. */
 int vq3_greedy_pick(const void* logits_bf16, int64_t ld_logits, float* work, int32_t B, int32_t V, int64_t* generated,
                     int32_t max_new, const int32_t* step, int32_t* finished, float repetition_penalty,
                     int32_t no_repeat_ngram, const int64_t* eos_ids, int32_t n_eos, int64_t pad_id, int32_t* next_ids,

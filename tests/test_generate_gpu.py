@@ -48,6 +48,14 @@ def test_skinny_gemm_vs_fp32(ops):
         # first-n rows only (tied lm_head over the padded embedding)
         yn = ops.skinny_linear(x, w, n=N - 3)
         assert yn.shape == (M, N - 3) and torch.equal(yn, y[:, : N - 3])
+    # fused input transforms equal the stand-alone kernels feeding the plain product, bit for bit
+    for M, N, K in [(1, 512, 2560), (6, 300, 1024)]:
+        x = torch.randn(M, K, device="cuda").to(BF16)
+        lnw = (1 + 0.2 * torch.randn(K, device="cuda")).to(BF16)
+        w = (torch.randn(N, K, device="cuda") * 0.05).to(BF16)
+        assert torch.equal(ops.skinny_linear(x, w, ln_w=lnw, eps=1e-6), ops.skinny_linear(ops.rmsnorm_fwd(x, lnw, 1e-6), w))
+        gu = torch.randn(M, 2 * K, device="cuda").to(BF16)
+        assert torch.equal(ops.skinny_linear(gu, w, swiglu=True), ops.skinny_linear(ops.silu_mul_fwd(gu), w))
     from vggt_qwen3_amd import _lib
     with pytest.raises(_lib.Vq3Error, match=r"M must be in \[1, 8\]"):
         ops.skinny_linear(torch.zeros(9, 64, device="cuda", dtype=BF16), torch.zeros(8, 64, device="cuda", dtype=BF16))

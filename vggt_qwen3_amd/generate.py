@@ -67,7 +67,7 @@ class DecodeState:
         self.finished = torch.zeros(B, device=dev, dtype=torch.int32)
         self.next_ids = torch.zeros(B, device=dev, dtype=torch.int32)
         self.generated = torch.zeros((B, gen_cols), device=dev, dtype=torch.int64)
-        self.work = torch.empty((B, tm.vocab), device=dev, dtype=F32)
+        self.work = torch.zeros(B * 128 + 8, device=dev, dtype=F32)     # pick partials + overflow flag
 
 
 def _prefill(tm, st: DecodeState, embeds: torch.Tensor, spans: Sequence[Tuple[int, int]]) -> torch.Tensor:
@@ -95,8 +95,7 @@ def _prefill(tm, st: DecodeState, embeds: torch.Tensor, spans: Sequence[Tuple[in
 
 def _logits_and_pick(tm, st: DecodeState, h: torch.Tensor, opts) -> None:
     c = tm.config
-    hn = ops.rmsnorm_fwd(h, tm._w["norm"], c.rms_norm_eps)
-    logits = ops.skinny_linear(hn, tm._w["embed"], n=tm.vocab)
+    logits = ops.skinny_linear(h, tm._w["embed"], n=tm.vocab, ln_w=tm._w["norm"], eps=c.rms_norm_eps)
     ops.greedy_pick(logits, st.work, st.generated, st.step, st.finished, opts["penalty"], opts["ngram"], opts["eos"],
                     opts["pad"], st.next_ids, tm.vocab)
 
@@ -107,16 +106,13 @@ def _decode_step(tm, st: DecodeState, cos, sin, opts) -> None:
     B, Hq, Hkv, D = st.B, tm.Hq, tm.Hkv, tm.D
     h = ops.gather_rows(tm._w["embed"], st.next_ids, B, B)
     for i in range(c.num_hidden_layers):
-        xn = ops.rmsnorm_fwd(h, tm._w[f"l{i}.ln1"], c.rms_norm_eps)
-        qkv = ops.skinny_linear(xn, tm._w[f"l{i}.qkv"])
+        qkv = ops.skinny_linear(h, tm._w[f"l{i}.qkv"], ln_w=tm._w[f"l{i}.ln1"], eps=c.rms_norm_eps)
         Q = ops.qwen_decode_qkprep(qkv, tm._w[f"l{i}.qn"], tm._w[f"l{i}.kn"], cos, sin, st.lens, st.K[i], st.V[i], B, Hq, Hkv,
                                    D, st.Lmax, c.rms_norm_eps)
         ao = ops.qwen_decode_attn(Q, st.K[i], st.V[i], st.lens, B, Hq, Hkv, D, st.Lmax, D ** -0.5)
         h_mid = ops.skinny_linear(ao, tm._w[f"l{i}.o"], residual=h)
-        xn2 = ops.rmsnorm_fwd(h_mid, tm._w[f"l{i}.ln2"], c.rms_norm_eps)
-        gu = ops.skinny_linear(xn2, tm._w[f"l{i}.gu"])
-        act = ops.silu_mul_fwd(gu)
-        h = ops.skinny_linear(act, tm._w[f"l{i}.down"], residual=h_mid)
+        gu = ops.skinny_linear(h_mid, tm._w[f"l{i}.gu"], ln_w=tm._w[f"l{i}.ln2"], eps=c.rms_norm_eps)
+        h = ops.skinny_linear(gu, tm._w[f"l{i}.down"], residual=h_mid, swiglu=True)
     _logits_and_pick(tm, st, h, opts)
     ops.decode_advance(st.lens, B, st.step)         # the processed token is now cached; one more id has been picked
 

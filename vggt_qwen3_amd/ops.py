@@ -363,20 +363,25 @@ def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None) -> torch.Tensor:
 
 # ---------------------------------------------------------------------------------------------- decoding
 def skinny_linear(x: torch.Tensor, w: torch.Tensor, *, residual: Optional[torch.Tensor] = None, n: Optional[int] = None,
-                  out: Optional[torch.Tensor] = None, out_dtype=BF16) -> torch.Tensor:
-    """y = x w^T (+ residual) for 1..8 rows: streams the weight once (vq3_skinny_gemm_bf16). `n` limits the output
-    features to the first n rows of w (tied lm_head: the vocabulary rows of the padded embedding)."""
+                  out: Optional[torch.Tensor] = None, out_dtype=BF16, ln_w: Optional[torch.Tensor] = None, eps: float = 0.0,
+                  swiglu: bool = False) -> torch.Tensor:
+    """y = f(x) w^T (+ residual) for 1..8 rows: streams the weight once (vq3_skinny_gemm_bf16). `n` limits the output
+    features to the first n rows of w (tied lm_head: the vocabulary rows of the padded embedding). ln_w: RMSNorm with
+    that weight is applied to x on the fly; swiglu: x is [M, 2K] = gate | up and f = silu(gate) * up."""
     _req(x, BF16, "skinny x"); _req(w, BF16, "skinny w")
-    assert x.dim() == 2 and w.dim() == 2 and x.is_contiguous() and w.is_contiguous() and x.shape[1] == w.shape[1]
-    M, K = x.shape
+    assert x.dim() == 2 and w.dim() == 2 and x.is_contiguous() and w.is_contiguous()
+    assert not (swiglu and ln_w is not None)
+    M, K = x.shape[0], w.shape[1]
+    assert x.shape[1] == (2 * K if swiglu else K)
     N = w.shape[0] if n is None else n
     if out is None:
         out = torch.empty((M, N), device=x.device, dtype=out_dtype)
     if residual is not None:
         _req(residual, BF16, "skinny residual"); assert residual.shape == (M, N) and residual.is_contiguous()
-    check(_lib.load().vq3_skinny_gemm_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), _p(residual), M, N, K, K, K,
-                                           out.stride(0), N, 1 if out.dtype == F32 else 0, _stream()),
-          "vq3_skinny_gemm_bf16")
+    xmode = 2 if swiglu else (1 if ln_w is not None else 0)
+    check(_lib.load().vq3_skinny_gemm_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), _p(residual), _p(ln_w), eps, xmode,
+                                           M, N, K, x.shape[1], K, out.stride(0), N, 1 if out.dtype == F32 else 0,
+                                           _stream()), "vq3_skinny_gemm_bf16")
     return out
 
 
@@ -404,7 +409,7 @@ def greedy_pick(logits, work, generated, step, finished, penalty, ngram, eos_ids
     _req(logits, BF16, "pick logits"); _req(work, F32, "pick work"); _req(generated, torch.int64, "pick generated")
     _req(step, torch.int32, "pick step"); _req(finished, torch.int32, "pick finished"); _req(next_ids, torch.int32, "pick next")
     B = logits.shape[0]
-    assert logits.stride(1) == 1 and work.shape == (B, V) and generated.is_contiguous() and generated.shape[0] == B
+    assert logits.stride(1) == 1 and work.numel() >= B * 128 + 1 and generated.is_contiguous() and generated.shape[0] == B
     n_eos = 0 if eos_ids is None else int(eos_ids.numel())
     check(_lib.load().vq3_greedy_pick(logits.data_ptr(), logits.stride(0), work.data_ptr(), B, V, generated.data_ptr(),
                                       generated.shape[1], step.data_ptr(), finished.data_ptr(), float(penalty), int(ngram),
