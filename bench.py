@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--seq-len", type=int, default=200)
     ap.add_argument("--image-size", type=int, default=448)
     ap.add_argument("--geom", action="store_true", help="geometry tokens on (config C4)")
+    ap.add_argument("--fp8", action="store_true",
+                    help="config C5: Qwen3 forward projections in e4m3 (block-scaled MFMA), backward bf16; NOT the default")
     ap.add_argument("--trim-pad", action="store_true",
                     help="drop the all-padding tail of the batch (exact; NOT the default: fewer FLOPs are executed)")
     ap.add_argument("--vision-prefetch", action="store_true",
@@ -185,7 +187,7 @@ def main():
     pcfg = PerceiverConfig(**yaml.safe_load((ROOT / "configs" / "perceiver_small.yaml").read_text()))
     vcfg = VisionLanguageConfig(text_model_name="synthetic", vision_ckpt_dir="none", num_vis_tokens=128,
                                 geom_tokens=8 if args.geom else 0, projector_cfg=pcfg, text_config=qcfg,
-                                device=str(dev), seed=0, trim_padding=args.trim_pad)
+                                device=str(dev), seed=0, trim_padding=args.trim_pad, fp8_text_forward=args.fp8)
     model = VGGTQwen3VLM(vcfg)
     model.train()
     accum = args.grad_accum if args.grad_accum > 0 else max(1, min(32, args.steps))
@@ -275,13 +277,13 @@ def main():
         out = {
             "metric": "Stage-1 train samples/sec (VGGT+Qwen3-4B bf16)", "value": round(value, 3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8-e4m3 fwd / bf16 bwd" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": ("Stage-1 ScanQA bf16: VGGT-1B aggregator @%dpx x %d view(s) + 128-latent/6-layer "
                                     "Perceiver + Qwen3-4B fwd+bwd + RCCL all-reduce + AdamW(fp32 master); random-init "
                                     "weights" % (args.image_size, V)),
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": L, "views": V,
                        "grad_accum": accum, "optimizer_steps_timed": len(cycles), "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
-                       "trim_padding": bool(args.trim_pad), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
+                       "trim_padding": bool(args.trim_pad), "fp8_text_forward": bool(args.fp8), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),
             "algorithmic_tflop_per_sample": round(tf_train, 3),
             "model_flops_utilisation": round(value * tf_train / (world * BF16_DENSE_PEAK_TFLOPS), 4),

@@ -256,6 +256,21 @@ int vq3_greedy_pick(const void* logits_bf16, int64_t ld_logits, float* work, int
 /* lens[b] += 1 for b < B (B <= 64), *step += 1 (either pointer may be NULL): the last launch of a decode step. */
 int vq3_decode_advance(int32_t* lens, int32_t B, int32_t* step, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * FP8 forward GEMM (BASELINE config C5: Qwen3 linear weights in OCP e4m3, one fp32 scale per output channel;
+ * activations quantised per token on the fly; fp32 accumulate). Replaces nn.Linear of modeling_qwen3.py:81-83,241-280.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Per-row quantisation: scale[r] = max|x[r,:]| / 448 (1 if the row is zero), q[r,k] = e4m3_rne(x[r,k] * 448 / amax).
+ * x bf16 [rows, K] (ldx), q uint8 e4m3 [rows, K] (ldq). Used for activations (row = token) and weights (row = output
+ * channel). */
+int vq3_quant_fp8_rows(const void* x_bf16, int64_t ldx, int64_t rows, int32_t K, void* q, int64_t ldq, float* scale,
+                       void* stream);
+/* C[M,N] bf16 = bf16(x_scale[m] * w_scale[n] * sum_k Xq[m,k] Wq[n,k]) (+ residual bf16). Xq [M,K], Wq [N,K] e4m3,
+ * K % 128 == 0. Block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales) at 2x the bf16 rate. */
+int vq3_gemm_fp8_nt(const void* Xq, const float* x_scale, const void* Wq, const float* w_scale, void* C,
+                    const void* residual, int32_t M, int32_t N, int32_t K, int64_t ldx, int64_t ldw, int64_t ldc,
+                    int64_t ldr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

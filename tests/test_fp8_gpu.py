@@ -1,0 +1,152 @@
+"""FP8 forward path (BASELINE config C5). The reference has no fp8 code, so the contract is the one SURVEY.md 8(d)
+states: e4m3 weights with per-output-channel fp32 scales, activations quantised per token on the fly, fp32 accumulate.
+oracle/fp8.py restates that contract on the CPU (torch.float8_e4m3fn); quantisation is bit-exact, the product is
+compared within fp32-accumulation-order tolerance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vggt_qwen3_amd import _lib
+    from vggt_qwen3_amd import ops as _ops
+    _lib.load()
+    return _ops
+
+
+def _e4m3_bytes(t):
+    return t.to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def test_fp8_gemm_exact_integers_asymmetric(ops):
+    """Operand lane map of the 16x16x128 block-scaled MFMA checked with exact data: small integers (exact in e4m3, exact
+    in fp32 accumulation), different in every row, column and k position."""
+    torch.manual_seed(0)
+    for M, N, K in [(16, 16, 128), (128, 128, 256), (200, 130, 384), (1200, 384, 2560)]:
+        x = torch.randint(-3, 4, (M, K)).float()
+        w = torch.randint(-2, 3, (N, K)).float()
+        x[:, 0] = torch.arange(M).float() % 5           # row-dependent at k = 0
+        w[:, K - 1] = (torch.arange(N).float() % 3) - 1  # column-dependent at the last k
+        k_ramp = (torch.arange(K) % 4).float()
+        x[0] = k_ramp                                    # k-dependent within a row
+        ref = x @ w.t()
+        xs = torch.ones(M, device="cuda"); ws = torch.ones(N, device="cuda")
+        out = ops.gemm_fp8(_e4m3_bytes(x).cuda(), xs, _e4m3_bytes(w).cuda(), ws)
+        want = ref.to(BF16).float()                       # the fp32 sums are exact integers; only the bf16 store rounds
+        assert torch.equal(out.float().cpu(), want), (M, N, K, (out.float().cpu() - want).abs().max())
+
+
+def test_fp8_quant_rows_bit_exact_vs_oracle(ops):
+    from oracle import fp8 as ofp8
+    torch.manual_seed(1)
+    x = (torch.randn(37, 2560) * torch.logspace(-3, 2, 37)[:, None]).to(BF16)
+    x[5] = 0
+    x[6, 17] = 1e4
+    q, s = ops.quant_fp8_rows(x.cuda())
+    rq, rs = ofp8.quant_rows(x)
+    assert torch.equal(s.cpu(), rs)
+    assert torch.equal(q.cpu(), rq.view(torch.uint8))
+
+
+def test_fp8_linear_vs_oracle_and_bf16(ops):
+    from oracle import fp8 as ofp8
+    torch.manual_seed(2)
+    for M, N, K in [(1200, 2560, 2560), (77, 640, 1024), (1200, 2560, 9728)]:
+        x = torch.randn(M, K).to(BF16)
+        w = (torch.randn(N, K) * 0.02).to(BF16)
+        r = torch.randn(M, N).to(BF16)
+        wq, ws = ops.quant_fp8_rows(w.cuda())
+        out = ops.linear_fp8(x.cuda(), wq, ws)
+        ref = ofp8.linear(x, w)
+        e = ((out.float().cpu() - ref.float()).norm() / ref.float().norm()).item()
+        assert e < 4e-3, (M, N, K, e)                     # same quantised operands: only accumulation order + bf16 rounding
+        full = x.float() @ w.float().t()
+        e2 = ((out.float().cpu() - full).norm() / full.norm()).item()
+        assert e2 < 6e-2, e2                              # what e4m3 itself costs against the unquantised product
+        out_r = ops.linear_fp8(x.cuda(), wq, ws, residual=r.cuda())
+        ref_r = (ref.float() + r.float()).to(BF16)
+        assert ((out_r.float().cpu() - ref_r.float()).norm() / ref_r.float().norm()).item() < 4e-3
+    from vggt_qwen3_amd import _lib
+    with pytest.raises(_lib.Vq3Error, match="K % 128"):
+        ops.gemm_fp8(torch.zeros(4, 64, dtype=torch.uint8, device="cuda"), torch.ones(4, device="cuda"),
+                     torch.zeros(4, 64, dtype=torch.uint8, device="cuda"), torch.ones(4, device="cuda"))
+
+
+def _tiny():
+    from tests.golden_io import load, meta, weights
+    from tests.test_parity_gpu import _tiny_qcfg
+    from vggt_qwen3_amd.qwen3 import Qwen3ForCausalLM
+    z = load("qwen3_tiny.npz")
+    c = meta(z, "config")
+    m = Qwen3ForCausalLM(_tiny_qcfg(c), device="cuda", seed=0)
+    m.load_hf_state_dict(weights(z))
+    return m, z, c
+
+
+def test_qwen3_fp8_forward_vs_oracle_contract():
+    """Whole text model with e4m3 projections against the CPU statement of the same contract (same inputs as the bf16
+    golden), and the distance of both from the bf16 reference logits."""
+    from oracle import fp8 as ofp8
+    from oracle import qwen3 as oq
+    from tests.golden_io import bf16, weights
+    model, z, c = _tiny()
+    emb = bf16(z["inputs_embeds"])
+    mask = torch.from_numpy(z["attention_mask"])
+    labels = torch.from_numpy(z["labels"])
+    sd = weights(z)
+    with ofp8.fp8_projections():
+        ref_loss, ref_logits = oq.causal_lm(emb, mask, labels, sd, oq.Qwen3Cfg(**c))
+    assert oq.attention.__module__ == "oracle.qwen3"                       # patch removed again
+    bf_loss = float(z["loss"])
+    model.enable_fp8_forward(True)
+    h, saved = model.forward_hidden(emb.cuda(), mask.cuda(), save=False)
+    loss, _ = model.loss_head(h, labels.cuda(), save=False, L=saved["L"])
+    B, L = mask.shape
+    logits = model.logits_all(h).view(B, saved["L"], -1)[:, :L].float().cpu()
+    keep = mask.bool()
+    e = ((logits[keep] - ref_logits.float()[keep]).norm() / ref_logits.float()[keep].norm()).item()
+    assert e < 1e-2, f"fp8 logits vs fp8 oracle: {e}"
+    assert abs(loss.item() - ref_loss.item()) < 5e-3 * abs(ref_loss.item())
+    gold = bf16(z["logits"]).float()
+    e_q = ((logits[keep] - gold[keep]).norm() / gold[keep].norm()).item()
+    assert e_q < 0.1, f"fp8 vs bf16 reference logits: {e_q}"               # what e4m3 costs; reported, bounded
+    assert abs(loss.item() - bf_loss) < 0.05 * abs(bf_loss)
+    # switching it off restores the bf16 path exactly
+    model.enable_fp8_forward(False)
+    h2, _ = model.forward_hidden(emb.cuda(), mask.cuda(), save=False)
+    model2, _, _ = _tiny()
+    h3, _ = model2.forward_hidden(emb.cuda(), mask.cuda(), save=False)
+    assert torch.equal(h2, h3)
+
+
+def test_fp8_forward_training_follows_weight_updates():
+    """fp8 forward + bf16 backward in the native trainer: the e4m3 copies are refreshed after every optimiser step (loss
+    falls on a fixed batch), and loading weights re-quantises."""
+    from tests.golden_io import load, meta
+    from tests.test_checkpoint_gpu import _batch
+    from tests.test_parity_gpu import _build_vlm
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z = load("vlm_tiny.npz")
+    m = meta(z)
+    model = _build_vlm(z, m).train()
+    model.text_model.enable_fp8_forward(True)
+    b = _batch(z)
+    tr = Stage1Trainer(model, lr=2e-3, proj_lr=2e-3, weight_decay=0.0, warmup_ratio=0.0, max_steps=50, grad_accum=1)
+    q_before = model.text_model._fp8["l0.qkv"][0].clone()
+    losses = [tr.micro_step(b).item() for _ in range(5)]
+    assert losses[-1] < losses[0] - 0.05, losses
+    assert not torch.equal(q_before, model.text_model._fp8["l0.qkv"][0])
+    ref = float(z["loss"])
+    assert abs(losses[0] - ref) < 0.05 * abs(ref)                          # first step: golden weights, e4m3 noise only
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        model.text_model.flat_w.mul_(0.5)
+    model.load_state_dict(sd, strict=False)
+    wq, ws = model.text_model._fp8["l1.down"]
+    from vggt_qwen3_amd import ops
+    wq2, ws2 = ops.quant_fp8_rows(model.text_model._w["l1.down"])
+    assert torch.equal(wq, wq2) and torch.equal(ws, ws2)

@@ -151,3 +151,20 @@ def test_generate_oracle_matches_transformers_golden():
         else:
             out = ogen.greedy_generate(sd, cfg, bf16(g[f"{n}:embeds"]), mask, **kw)
         assert np.array_equal(out.numpy(), g[f"{n}:out"]), n
+
+
+def test_fp8_oracle_known_answers():
+    """oracle.fp8 against the OCP e4m3 (fn) encoding itself - the only external fixed point config C5 has (the reference
+    holds no fp8 code): known byte patterns, per-row scale rule, round-to-nearest-even, zero rows."""
+    from oracle import fp8 as ofp8
+    x = torch.tensor([[448.0, 1.0, -2.0, 2.0 ** -6, 2.0 ** -9, 0.0, 17.0, 19.0]])      # amax 448 -> scale exactly 1
+    q, s = ofp8.quant_rows(x)
+    assert s.tolist() == [1.0]
+    assert q.view(torch.uint8)[0].tolist() == [0x7E, 0x38, 0xC0, 0x08, 0x01, 0x00, 0x58, 0x5A]   # 17 -> 16 (tie to even), 19 -> 20
+    y = torch.tensor([[0.0, 0.0], [3.0, -1.5]])
+    q, s = ofp8.quant_rows(y)
+    assert s[0].item() == 1.0 and s[1].item() == np.float32(3.0) / np.float32(448.0)
+    assert q.float().tolist() == [[0.0, 0.0], [448.0, -224.0]]
+    w = torch.eye(4)[:, [1, 0, 3, 2]] * 2.0
+    out = ofp8.linear(torch.arange(8.0).view(2, 4).to(torch.bfloat16), w.to(torch.bfloat16))
+    assert torch.allclose(out.float(), torch.tensor([[2.0, 0.0, 6.0, 4.0], [10.0, 8.0, 14.0, 12.0]]), rtol=0.07)

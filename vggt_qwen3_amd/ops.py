@@ -418,3 +418,38 @@ def greedy_pick(logits, work, generated, step, finished, penalty, ngram, eos_ids
 
 def decode_advance(lens: Optional[torch.Tensor], B: int, step: Optional[torch.Tensor]) -> None:
     check(_lib.load().vq3_decode_advance(_p(lens), B, _p(step), _stream()), "vq3_decode_advance")
+
+
+# ---------------------------------------------------------------------------------------------- fp8 forward (config C5)
+def quant_fp8_rows(x: torch.Tensor):
+    """bf16 [rows, K] -> (uint8 e4m3 [rows, K], f32 scale [rows]); x ~ q * scale[:, None]."""
+    _req(x, BF16, "quant_fp8 x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, K = x.shape
+    q = torch.empty((rows, K), device=x.device, dtype=torch.uint8)
+    s = torch.empty((rows,), device=x.device, dtype=F32)
+    check(_lib.load().vq3_quant_fp8_rows(x.data_ptr(), x.stride(0), rows, K, q.data_ptr(), K, s.data_ptr(), _stream()),
+          "vq3_quant_fp8_rows")
+    return q, s
+
+
+def gemm_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 [M, N] = (xs[:, None] * ws[None, :]) * (xq @ wq^T) (+ residual); xq [M, K], wq [N, K] e4m3 bytes."""
+    _req(xq, torch.uint8, "gemm_fp8 xq"); _req(wq, torch.uint8, "gemm_fp8 wq"); _req(xs, F32, "xs"); _req(ws, F32, "ws")
+    assert xq.dim() == 2 and wq.dim() == 2 and xq.is_contiguous() and wq.is_contiguous() and xq.shape[1] == wq.shape[1]
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert xs.numel() == M and ws.numel() == N
+    if out is None:
+        out = torch.empty((M, N), device=xq.device, dtype=BF16)
+    if residual is not None:
+        _req(residual, BF16, "gemm_fp8 residual"); assert residual.shape == (M, N) and residual.is_contiguous()
+    check(_lib.load().vq3_gemm_fp8_nt(xq.data_ptr(), xs.data_ptr(), wq.data_ptr(), ws.data_ptr(), out.data_ptr(),
+                                      _p(residual), M, N, K, K, K, out.stride(0), N, _stream()), "vq3_gemm_fp8_nt")
+    return out
+
+
+def linear_fp8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    xq, xs = quant_fp8_rows(x)
+    return gemm_fp8(xq, xs, wq, ws, residual=residual)

@@ -111,7 +111,10 @@ class Qwen3ForCausalLM(nn.Module):
         self._wgrad_stream = None
         if self.device_.type == "cuda" and os.environ.get("VQ3_WGRAD_STREAM", "1") != "0":
             self._wgrad_stream = torch.cuda.Stream(device=self.device_)
+        self._fp8 = None
         self._alloc(c.vocab_size, seed)
+        # weights written through load_state_dict() (any route) invalidate the e4m3 copies
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.requantize_fp8())
 
     # ------------------------------------------------------------------ storage
     def _layout(self, vocab: int):
@@ -254,6 +257,7 @@ class Qwen3ForCausalLM(nn.Module):
                     missing.append(n)
         if strict and missing:
             raise KeyError(f"missing keys: {missing[:5]}...")
+        self.requantize_fp8()
         return missing
 
     @classmethod
@@ -287,6 +291,34 @@ class Qwen3ForCausalLM(nn.Module):
                                    emb.sin().to(BF16).to(self.device_).contiguous())
         return self._rope_cache[L]
 
+    # ------------------------------------------------------------------ fp8 forward (BASELINE config C5)
+    def enable_fp8_forward(self, on: bool = True) -> None:
+        """Forward projections (q|k|v, o, gate|up, down of every layer) through the e4m3 block-scaled-MFMA GEMM: weights
+        quantised per output channel (refresh with requantize_fp8() after every weight update), activations per token on
+        the fly, fp32 accumulation. Embedding / lm_head, norms, attention and the whole backward stay bf16 (the backward
+        reads the bf16 weights and the saved bf16 activations)."""
+        self._fp8 = {} if on else None
+        if on:
+            self.requantize_fp8()
+
+    def requantize_fp8(self) -> None:
+        if getattr(self, "_fp8", None) is None:
+            return
+        for i in range(self.config.num_hidden_layers):
+            for k in ("qkv", "o", "gu", "down"):
+                name = f"l{i}.{k}"
+                w = self._w[name]
+                if w.shape[1] % 128:
+                    raise ops._lib.Vq3Error(f"fp8 forward needs in_features % 128 == 0, {name} has {w.shape[1]}")
+                self._fp8[name] = ops.quant_fp8_rows(w)
+
+    def _proj(self, x: torch.Tensor, name: str, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        f8 = getattr(self, "_fp8", None)
+        if f8 is not None:
+            wq, ws = f8[name]
+            return ops.linear_fp8(x, wq, ws, residual=residual)
+        return ops.linear(x, self._w[name], residual=residual)
+
     # ------------------------------------------------------------------ forward
     def _attention_fwd(self, i, xn, B, L, keymask, ctx):
         """L is a multiple of 8 here (forward_hidden pads). Scores are materialised per (b, head) - at L = 200 the
@@ -294,7 +326,7 @@ class Qwen3ForCausalLM(nn.Module):
         c = self.config
         Hq, Hkv, D, G = self.Hq, self.Hkv, self.D, self.Hq // self.Hkv
         cos, sin = self.rope(L)
-        qkv = ops.linear(xn, self._w[f"l{i}.qkv"])
+        qkv = self._proj(xn, f"l{i}.qkv")
         Q, K, V, qr, kr = ops.qwen_qkprep_fwd(qkv, self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin, B, L, Hq, Hkv,
                                               D, c.rms_norm_eps, want_rstd=ctx is not None)
         S = torch.empty((B * Hq, L, L), device=xn.device, dtype=F32)
@@ -325,11 +357,11 @@ class Qwen3ForCausalLM(nn.Module):
             ctx = {} if save else None
             xn1, r1 = ops.rmsnorm_fwd(h, self._w[f"l{i}.ln1"], c.rms_norm_eps, want_rstd=True)
             ao = self._attention_fwd(i, xn1, B, L, keymask, ctx)
-            h_mid = ops.linear(ao, self._w[f"l{i}.o"], residual=h)
+            h_mid = self._proj(ao, f"l{i}.o", residual=h)
             xn2, r2 = ops.rmsnorm_fwd(h_mid, self._w[f"l{i}.ln2"], c.rms_norm_eps, want_rstd=True)
-            gu = ops.linear(xn2, self._w[f"l{i}.gu"])
+            gu = self._proj(xn2, f"l{i}.gu")
             act = ops.silu_mul_fwd(gu)
-            h_out = ops.linear(act, self._w[f"l{i}.down"], residual=h_mid)
+            h_out = self._proj(act, f"l{i}.down", residual=h_mid)
             if save:
                 ctx.update(h_in=h, r1=r1, xn1=xn1, h_mid=h_mid, r2=r2, xn2=xn2, gu=gu, act=act)
                 saved.append(ctx)

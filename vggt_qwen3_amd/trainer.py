@@ -119,6 +119,7 @@ class Stage1Trainer:
         gscale = 1.0 / self.world
         ops.adamw_step(self.master, self.m, self.v, tm.flat_g, tm.flat_w, self.lr * mult, self.betas[0], self.betas[1],
                        self.eps, self.wd, self.opt_step, gscale)
+        tm.requantize_fp8()      # no-op unless the fp8 forward is enabled
         if self._geom_has_grad:
             ops.adamw_step(self.geom_master, self.geom_m, self.geom_v, ops.cast(self.geom_grad, BF16), self.geom_w16,
                            self.proj_lr * mult, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step, gscale)

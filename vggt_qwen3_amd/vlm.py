@@ -43,6 +43,7 @@ class VisionLanguageConfig:
     device: str = "cuda"
     seed: int = 0
     trim_padding: bool = False
+    fp8_text_forward: bool = False               # BASELINE config C5: e4m3 forward GEMMs in the text model
 
 
 def build_srcmap(input_ids: torch.Tensor, image_id: int, S: int) -> torch.Tensor:
@@ -155,6 +156,8 @@ class VGGTQwen3VLM(nn.Module):
         # False = compute all L positions like the reference; True = drop the all-padding tail of the batch (same
         # loss and gradients, fewer rows). Off by default so the dense figure stays comparable with the reference's.
         self.trim_padding = bool(config.trim_padding)
+        if config.fp8_text_forward:
+            self.text_model.enable_fp8_forward(True)
         self._vis_stream = None
         self._prefetched = None
         self._text_param_names = [n for n, _ in self.text_model.named_parameters()]
