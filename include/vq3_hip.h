@@ -271,6 +271,21 @@ int vq3_gemm_fp8_nt(const void* Xq, const float* x_scale, const void* Wq, const 
                     const void* residual, int32_t M, int32_t N, int32_t K, int64_t ldx, int64_t ldw, int64_t ldc,
                     int64_t ldr, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused causal GQA attention for Qwen3, head_dim 128, 1..4 query heads per kv head (modeling_qwen3.py:185-207,254-280 + autograd):
+ * softmax(scale * Q K^T + causal & key-padding mask) V, scores in fp32, probabilities bf16 before the PV product.
+ * Q [B,Hq,L,128], K/V [B,Hkv,L,128] bf16 (as vq3_qwen_qkprep_fwd writes them); keymask uint8 [B,L] (0 = padded key);
+ * O / dO token-major: row (b*L + q), head h at column h*128, row stride ldo / lddo elements.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* LSE f32 [B,Hq,L]: log2-domain log-sum-exp of the scaled scores (+inf for rows with no visible key; their O is 0). */
+int vq3_qwen_flash_fwd(const void* Q, const void* K, const void* V, const void* keymask, void* O, float* LSE, int32_t B,
+                       int32_t L, int32_t Hq, int32_t Hkv, int32_t head_dim, int64_t ldo, float scale, void* stream);
+/* dQ [B,Hq,L,128], dK/dV [B,Hkv,L,128] bf16 (summed over the query heads of each kv head in registers/LDS, no atomics).
+ * Delta f32 [B,Hq,L] is scratch (rowsum(dO * O), written by the dQ pass, read by the dK/dV pass). */
+int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* keymask, const void* O, const void* dO,
+                       const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t B, int32_t L, int32_t Hq,
+                       int32_t Hkv, int32_t head_dim, int64_t ldo, int64_t lddo, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -385,3 +385,50 @@ def test_gemm_split_k(ops):
     out = torch.zeros((M, N), device="cuda", dtype=F32)
     ops.gemm_raw(A, Bk, out, M, N, K, K, N, N, transB=True, ksplit=12, alpha=0.5)
     assert _relerr(out, 0.5 * ref) < 1e-4
+
+
+@pytest.mark.parametrize("B,Hkv,L,pad,G", [(1, 1, 32, "none", 4), (2, 2, 40, "right", 4), (3, 1, 200, "right", 4),
+                                            (2, 2, 104, "left", 4), (1, 2, 264, "none", 4), (2, 1, 72, "right", 2),
+                                            (1, 3, 50, "left", 1)])
+def test_qwen_flash_attention_fwd_bwd(ops, B, Hkv, L, pad, G):
+    """Fused causal GQA attention vs an fp32 autograd reference: padding on either side (left padding makes whole query rows
+    maskless: their output and gradients must be exactly zero, never NaN), L not a multiple of the 32-row blocks."""
+    torch.manual_seed(L)
+    Hq, D = G * Hkv, 128
+    dev = "cuda"
+    Q = torch.randn(B, Hq, L, D, device=dev).to(BF16)
+    K = torch.randn(B, Hkv, L, D, device=dev).to(BF16)
+    V = torch.randn(B, Hkv, L, D, device=dev).to(BF16)
+    dO = torch.randn(B * L, Hq * D, device=dev).to(BF16)
+    mask = torch.ones(B, L, dtype=torch.uint8, device=dev)
+    if pad == "right":
+        for b in range(B):
+            mask[b, L - 3 - 7 * b:] = 0
+    elif pad == "left":
+        for b in range(B):
+            mask[b, : 2 + 5 * b] = 0
+    scale = D ** -0.5
+    O, lse = ops.qwen_flash_fwd(Q, K, V, mask, B, L, Hq, Hkv, D, scale)
+    dQ, dK, dV = ops.qwen_flash_bwd(Q, K, V, mask, O, dO, lse, B, L, Hq, Hkv, D, scale)
+    q, k, v = (t.float().detach().requires_grad_(True) for t in (Q, K, V))
+    ke, ve = k.repeat_interleave(G, dim=1), v.repeat_interleave(G, dim=1)
+    s = (q @ ke.transpose(2, 3)) * scale
+    vis = torch.tril(torch.ones(L, L, dtype=torch.bool, device=dev))[None, None] & (mask.bool()[:, None, None, :])
+    s = s.masked_fill(~vis, float("-inf"))
+    rowvis = vis.any(-1, keepdim=True)
+    p = torch.softmax(s.masked_fill(~rowvis, 0.0), dim=-1) * rowvis          # maskless rows -> 0
+    ref = (p @ ve).permute(0, 2, 1, 3).reshape(B * L, Hq * D)
+    ref.backward(dO.float())
+    def rel(a, b):
+        return ((a.float() - b).norm() / (b.norm() + 1e-9)).item()
+    assert torch.isfinite(O.float()).all() and torch.isfinite(dQ.float()).all() and torch.isfinite(dK.float()).all()
+    assert rel(O, ref.detach()) < 1e-2
+    assert rel(dQ, q.grad) < 2e-2 and rel(dK, k.grad) < 2e-2 and rel(dV, v.grad) < 2e-2
+    dead = ~rowvis.expand(B, Hq, L, 1).reshape(B, Hq, L)
+    if dead.any():
+        Oh = O.view(B, L, Hq, D).permute(0, 2, 1, 3)
+        assert (Oh[dead] == 0).all() and (dQ[dead] == 0).all()
+    # reference LSE (log2 domain of the scaled scores)
+    lse_ref = torch.logsumexp(s.detach(), dim=-1) * 1.4426950408889634
+    ok = rowvis.squeeze(-1).expand(B, Hq, L)
+    assert (lse[ok] - lse_ref[ok]).abs().max() < 2e-2

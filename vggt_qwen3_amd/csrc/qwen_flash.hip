@@ -1,0 +1,351 @@
+// Fused causal GQA attention for Qwen3 (head_dim 128) - forward and backward - replacing the batched
+// QK^T GEMM / softmax / PV GEMM chain of modeling_qwen3.py:185-207 (eager) / SDPA and its autograd backward.
+// At Stage-1 lengths (L = 200) attention is < 1 % of the FLOPs but was 7 launches and ~270 MB of score traffic per
+// layer; here scores never leave registers.
+//
+// MFMA 32x32x16 bf16 throughout, one wave per 32-row block, no LDS in the main loops:
+//   forward / dQ kernels: S^T = K Q^T (key rows, query columns): the C layout puts the QUERY on the lane, so the online
+//     softmax state, LSE and delta are per-lane scalars, and P^T / dS^T feed the next MFMA straight from the accumulator
+//     registers (k order permuted: element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)).
+//   dK/dV kernel: S = Q K^T (query rows, key columns): the KEY is on the lane, dK^T / dV^T accumulate in registers over
+//     the q-blocks and (through LDS) over the 4 query heads of the GQA group - no atomics.
+// The operand that would need a transposed tile (V^T, K^T, dO^T, Q^T as the A matrix) is gathered instead: MFMA row r of
+// d-block db stands for feature d = 4 r + db, so one 8-byte load per key/query row feeds all four d-blocks.
+// Layouts: Q, dQ [B, Hq, L, 128]; K, V, dK, dV [B, Hkv, L, 128]; O, dO token-major rows (b*L + q) with row stride ld,
+// head h at column h*128; LSE (log2 domain, scaled) and Delta f32 [B, Hq, L].
+#include "common.h"
+#include "vq3_hip.h"
+
+namespace {
+
+constexpr int D = 128;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int rho(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+__device__ __forceinline__ bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[8 * s + j]);
+  return o;
+}
+// gather the A operand of "X^T . (acc)" for all four d-blocks: rows[j] = 4 consecutive bf16 of row key(j) at column 4r
+__device__ __forceinline__ void gather4(const bf16_t* base, long rowstride, int row0, int s, int h, int r, int maxrow,
+                                        bf16x8 (&a)[4]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int row = row0 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+    row = row < maxrow ? row : maxrow;
+    const u32x2 v = *reinterpret_cast<const u32x2*>(base + (long)row * rowstride + 4 * r);
+    a[0][j] = (short)(v[0] & 0xffff);
+    a[1][j] = (short)(v[0] >> 16);
+    a[2][j] = (short)(v[1] & 0xffff);
+    a[3][j] = (short)(v[1] >> 16);
+  }
+}
+// lanes 0..31 (and their mirrors 32..63) vote on "key kb*32 + r is a real, attended key"
+__device__ __forceinline__ unsigned key_bits(const uint8_t* km, int kb, int r, int L) {
+  const int key = kb * 32 + r;
+  const bool ok = key < L && km[key < L ? key : L - 1] != 0;
+  return (unsigned)(__ballot(ok) & 0xffffffffull);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// grid: B * Hkv * nqb blocks of 4 waves; wave g = query head hk*G + g (G = Hq / Hkv <= 4; spare waves idle)
+__global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                            const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
+                                                            bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Hq,
+                                                            int Hkv, long ldo, float scale) {
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nqb = (L + 31) / 32;
+  const int qb = nqb - 1 - (int)(blockIdx.x % nqb);          // longest rows first
+  const int hk = (blockIdx.x / nqb) % Hkv, b = blockIdx.x / (nqb * Hkv);
+  const int G = Hq / Hkv, hq = hk * G + g;
+  if (g >= G) return;
+  const int q = qb * 32 + r, qc = q < L ? q : L - 1;
+  const bf16_t* Qr = Q + (((long)b * Hq + hq) * L + qc) * D + 8 * h;
+  const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
+  const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
+  const uint8_t* km = keymask + (long)b * L;
+  bf16x8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s] = ld8(Qr + 16 * s);
+  f32x16 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sl2e = scale * LOG2E;
+  for (int kb = 0; kb <= qb; ++kb) {
+    const int kr = kb * 32 + r;
+    const bf16_t* Kr = Kb + (long)(kr < L ? kr : L - 1) * D + 8 * h;
+    f32x16 s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(Kr + 16 * t), qf[t], s, 0, 0, 0);
+    const unsigned bits = key_bits(km, kb, r, L);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kl = rho(i, h);
+      const bool ok = ((bits >> kl) & 1u) && (kb * 32 + kl <= q);
+      s[i] = ok ? s[i] : -INFINITY;
+      mx = fmaxf(mx, s[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * sl2e);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2e, -m_safe));
+      ps += s[i];
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      bf16x8 vf[4];
+      gather4(Vb, D, kb * 32, sp, h, r, L - 1, vf);
+      const bf16x8 pf = pack8(s, sp);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db], pf, o[db], 0, 0, 0);
+    }
+  }
+  if (q >= L) return;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  bf16_t* Or = O + ((long)b * L + q) * ldo + (long)hq * D;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    u32x2 w;
+    w[0] = pack2bf(o[0][i] * inv, o[1][i] * inv);
+    w[1] = pack2bf(o[2][i] * inv, o[3][i] * inv);
+    *reinterpret_cast<u32x2*>(Or + 4 * rho(i, h)) = w;
+  }
+  if (h == 0) LSE[((long)b * Hq + hq) * L + q] = l_run > 0.f ? m_run + __builtin_amdgcn_logf(l_run) : INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
+__global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                               const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
+                                                               const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
+                                                               const float* __restrict__ LSE, float* __restrict__ Delta,
+                                                               bf16_t* __restrict__ dQ, int L, int Hq, int Hkv, long ldo,
+                                                               long lddo, float scale) {
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nqb = (L + 31) / 32;
+  const int qb = nqb - 1 - (int)(blockIdx.x % nqb);
+  const int hk = (blockIdx.x / nqb) % Hkv, b = blockIdx.x / (nqb * Hkv);
+  const int G = Hq / Hkv, hq = hk * G + g;
+  if (g >= G) return;
+  const int q = qb * 32 + r, qc = q < L ? q : L - 1;
+  const bf16_t* Qr = Q + (((long)b * Hq + hq) * L + qc) * D + 8 * h;
+  const bf16_t* Or = O + ((long)b * L + qc) * ldo + (long)hq * D + 8 * h;
+  const bf16_t* dOr = dO + ((long)b * L + qc) * lddo + (long)hq * D + 8 * h;
+  const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
+  const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
+  const uint8_t* km = keymask + (long)b * L;
+  bf16x8 qf[8], dof[8];
+  float delta = 0.f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    qf[s] = ld8(Qr + 16 * s);
+    dof[s] = ld8(dOr + 16 * s);
+    const bf16x8 of = ld8(Or + 16 * s);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) delta = fmaf(bf2f((bf16_t)dof[s][j]), bf2f((bf16_t)of[j]), delta);
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  const float lse = LSE[((long)b * Hq + hq) * L + qc];
+  f32x16 dq[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
+  const float sl2e = scale * LOG2E;
+  for (int kb = 0; kb <= qb; ++kb) {
+    const int kr = kb * 32 + r;
+    const long koff = (long)(kr < L ? kr : L - 1) * D + 8 * h;
+    f32x16 s, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(Kb + koff + 16 * t), qf[t], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(Vb + koff + 16 * t), dof[t], dp, 0, 0, 0);
+    }
+    const unsigned bits = key_bits(km, kb, r, L);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kl = rho(i, h);
+      const bool ok = ((bits >> kl) & 1u) && (kb * 32 + kl <= q);
+      const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2e, -lse)) : 0.f;
+      s[i] = p * (dp[i] - delta) * scale;          // dS^T
+    }
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      bf16x8 kf[4];
+      gather4(Kb, D, kb * 32, sp, h, r, L - 1, kf);
+      const bf16x8 dsf = pack8(s, sp);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[db], dsf, dq[db], 0, 0, 0);
+    }
+  }
+  if (q >= L) return;
+  bf16_t* dQr = dQ + (((long)b * Hq + hq) * L + q) * D;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    u32x2 w;
+    w[0] = pack2bf(dq[0][i], dq[1][i]);
+    w[1] = pack2bf(dq[2][i], dq[3][i]);
+    *reinterpret_cast<u32x2*>(dQr + 4 * rho(i, h)) = w;
+  }
+  if (h == 0) Delta[((long)b * Hq + hq) * L + q] = delta;
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+// grid: B * Hkv * nkb blocks; wave g = query head of the group; the four waves' accumulators meet in LDS.
+__global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
+                                                                const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
+                                                                const float* __restrict__ Delta, bf16_t* __restrict__ dK,
+                                                                bf16_t* __restrict__ dV, int L, int Hq, int Hkv, long lddo,
+                                                                float scale) {
+  __shared__ float red[4][16][64];     // one f32x16 accumulator block per wave
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nkb = (L + 31) / 32;
+  const int kb = blockIdx.x % nkb;                              // kb = 0 has the most q-blocks: it is scheduled first
+  const int hk = (blockIdx.x / nkb) % Hkv, b = blockIdx.x / (nkb * Hkv);
+  const int G = Hq / Hkv, hq = hk * G + g;
+  const bool active = g < G;
+  const int key = kb * 32 + r, kc = key < L ? key : L - 1;
+  const bf16_t* Kr = K + (((long)b * Hkv + hk) * L + kc) * D + 8 * h;
+  const bf16_t* Vr = V + (((long)b * Hkv + hk) * L + kc) * D + 8 * h;
+  const bool key_ok = key < L && keymask[(long)b * L + kc] != 0;
+  bf16x8 kf[8], vf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { kf[s] = ld8(Kr + 16 * s); vf[s] = ld8(Vr + 16 * s); }
+  f32x16 dk[4], dv[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+  const float sl2e = scale * LOG2E;
+  if (active) {
+    const bf16_t* Qh = Q + ((long)b * Hq + hq) * L * D;
+    const bf16_t* dOh = dO + (long)b * L * lddo + (long)hq * D;
+    const float* lse_h = LSE + ((long)b * Hq + hq) * L;
+    const float* del_h = Delta + ((long)b * Hq + hq) * L;
+    for (int qb = kb; qb < nkb; ++qb) {
+      const int qr = qb * 32 + r, qrc = qr < L ? qr : L - 1;
+      const bf16_t* Qr = Qh + (long)qrc * D + 8 * h;
+      const bf16_t* dOr = dOh + (long)qrc * lddo + 8 * h;
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(Qr + 16 * t), kf[t], s, 0, 0, 0);      // S[q, key]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(dOr + 16 * t), vf[t], dp, 0, 0, 0);   // dP[q, key]
+      }
+      f32x16 p;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qg = qb * 32 + rho(i, h);
+        const int qgc = qg < L ? qg : L - 1;
+        const bool ok = key_ok && qg < L && key <= qg;
+        const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2e, -lse_h[qgc])) : 0.f;
+        p[i] = pv;
+        s[i] = pv * (dp[i] - del_h[qgc]) * scale;     // dS[q, key]
+      }
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        bf16x8 a[4];
+        gather4(dOh, lddo, qb * 32, sp, h, r, L - 1, a);                 // dO^T rows d = 4r + db
+        const bf16x8 pf = pack8(p, sp);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[db], pf, dv[db], 0, 0, 0);
+        gather4(Qh, D, qb * 32, sp, h, r, L - 1, a);                      // Q^T rows
+        const bf16x8 dsf = pack8(s, sp);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[db], dsf, dk[db], 0, 0, 0);
+      }
+    }
+  }
+  // sum the G query heads: 8 accumulator blocks (dk[0..3], dv[0..3]), each reduced through LDS; wave (blk & 3) keeps blk
+  bf16_t* dKr = dK + (((long)b * Hkv + hk) * L + kc) * D;
+  bf16_t* dVr = dV + (((long)b * Hkv + hk) * L + kc) * D;
+  f32x16 keep[2];
+#pragma unroll
+  for (int blk = 0; blk < 8; ++blk) {
+    const f32x16& mine = blk < 4 ? dk[blk] : dv[blk - 4];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[g][i][lane] = mine[i];
+    __syncthreads();
+    if ((blk & 3) == g) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) keep[blk >> 2][i] = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
+    }
+  }
+  if (key >= L) return;
+  // wave g holds d-block db = g of both dK^T and dV^T: element i is feature d = 4 rho(i) + g
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    dKr[4 * rho(i, h) + g] = f2bf(keep[0][i]);
+    dVr[4 * rho(i, h) + g] = f2bf(keep[1][i]);
+  }
+}
+
+}  // namespace
+
+static int flash_check(const char* who, int B, int L, int Hq, int Hkv, int Dh) {
+  VQ3_CHECK_ARG(Dh == D, "%s: head_dim must be %d, got %d", who, D, Dh);
+  VQ3_CHECK_ARG(B > 0 && L > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 4,
+                "%s: need 1..4 query heads per kv head (B=%d L=%d Hq=%d Hkv=%d)", who, B, L, Hq, Hkv);
+  VQ3_CHECK_ARG((long)B * Hkv * ((L + 31) / 32) < (1l << 31), "%s: grid too large", who);
+  return 0;
+}
+
+extern "C" int vq3_qwen_flash_fwd(const void* Q, const void* K, const void* V, const void* keymask, void* O, float* LSE,
+                                  int32_t B, int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, float scale,
+                                  void* stream) {
+  VQ3_CHECK_ARG(Q && K && V && keymask && O && LSE, "qwen_flash_fwd: null pointer");
+  if (flash_check("qwen_flash_fwd", B, L, Hq, Hkv, Dh)) return 1;
+  VQ3_CHECK_ARG(ldo >= (long)Hq * D && ldo % 4 == 0, "qwen_flash_fwd: bad output row stride");
+  const int nqb = (L + 31) / 32;
+  hipLaunchKernelGGL(qwen_flash_fwd_kernel, dim3(B * Hkv * nqb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
+                     (const bf16_t*)K, (const bf16_t*)V, (const uint8_t*)keymask, (bf16_t*)O, LSE, L, Hq, Hkv, (long)ldo, scale);
+  VQ3_CHECK_LAUNCH("qwen_flash_fwd");
+  return 0;
+}
+
+extern "C" int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* keymask, const void* O,
+                                  const void* dO, const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t B,
+                                  int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, int64_t lddo, float scale,
+                                  void* stream) {
+  VQ3_CHECK_ARG(Q && K && V && keymask && O && dO && LSE && Delta && dQ && dK && dV, "qwen_flash_bwd: null pointer");
+  if (flash_check("qwen_flash_bwd", B, L, Hq, Hkv, Dh)) return 1;
+  VQ3_CHECK_ARG(ldo >= (long)Hq * D && lddo >= (long)Hq * D && ldo % 8 == 0 && lddo % 8 == 0, "qwen_flash_bwd: bad row strides");
+  const int nqb = (L + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(qwen_flash_bwd_dq_kernel, dim3(B * Hkv * nqb), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
+                     (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)O, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dQ, L,
+                     Hq, Hkv, (long)ldo, (long)lddo, scale);
+  hipLaunchKernelGGL(qwen_flash_bwd_dkv_kernel, dim3(B * Hkv * nqb), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
+                     (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dK, (bf16_t*)dV, L, Hq,
+                     Hkv, (long)lddo, scale);
+  VQ3_CHECK_LAUNCH("qwen_flash_bwd");
+  return 0;
+}

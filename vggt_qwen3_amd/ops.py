@@ -453,3 +453,33 @@ def gemm_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Ten
 def linear_fp8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     xq, xs = quant_fp8_rows(x)
     return gemm_fp8(xq, xs, wq, ws, residual=residual)
+
+
+# ---------------------------------------------------------------------------------------------- fused Qwen3 attention
+def qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, scale):
+    """-> (O bf16 [B*L, Hq*D] token-major, LSE f32 [B, Hq, L])."""
+    for t in (Q, K, V):
+        _req(t, BF16, "qwen_flash"); assert t.is_contiguous()
+    _req(keymask, torch.uint8, "qwen_flash keymask")
+    assert Q.shape == (B, Hq, L, D) and K.shape == (B, Hkv, L, D) and V.shape == K.shape and keymask.shape == (B, L)
+    O = torch.empty((B * L, Hq * D), device=Q.device, dtype=BF16)
+    lse = torch.empty((B, Hq, L), device=Q.device, dtype=F32)
+    check(_lib.load().vq3_qwen_flash_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
+                                         lse.data_ptr(), B, L, Hq, Hkv, D, Hq * D, scale, _stream()), "vq3_qwen_flash_fwd")
+    return O, lse
+
+
+def qwen_flash_bwd(Q, K, V, keymask, O, dO, lse, B, L, Hq, Hkv, D, scale):
+    """O, dO: bf16 [B*L, Hq*D] token-major. -> dQ [B,Hq,L,D], dK, dV [B,Hkv,L,D] bf16."""
+    _req(O, BF16, "flash_bwd O"); _req(dO, BF16, "flash_bwd dO"); _req(lse, F32, "flash_bwd lse")
+    assert O.shape == (B * L, Hq * D) and dO.shape == O.shape and O.stride(1) == 1 and dO.stride(1) == 1
+    dev = Q.device
+    dQ = torch.empty((B, Hq, L, D), device=dev, dtype=BF16)
+    dK = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
+    dV = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
+    delta = torch.empty((B, Hq, L), device=dev, dtype=F32)
+    check(_lib.load().vq3_qwen_flash_bwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
+                                         dO.data_ptr(), lse.data_ptr(), delta.data_ptr(), dQ.data_ptr(), dK.data_ptr(),
+                                         dV.data_ptr(), B, L, Hq, Hkv, D, O.stride(0), dO.stride(0), scale, _stream()),
+          "vq3_qwen_flash_bwd")
+    return dQ, dK, dV

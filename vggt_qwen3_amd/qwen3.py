@@ -112,6 +112,9 @@ class Qwen3ForCausalLM(nn.Module):
         if self.device_.type == "cuda" and os.environ.get("VQ3_WGRAD_STREAM", "1") != "0":
             self._wgrad_stream = torch.cuda.Stream(device=self.device_)
         self._fp8 = None
+        # fused causal attention (csrc/qwen_flash.hip) covers up to 4 query heads per kv head (Qwen3-4B: 4);
+        # VQ3_QWEN_FLASH=0 keeps the batched GEMM + softmax chain
+        self._flash = self.Hq % self.Hkv == 0 and self.Hq // self.Hkv <= 4 and os.environ.get("VQ3_QWEN_FLASH", "1") != "0"
         self._alloc(c.vocab_size, seed)
         # weights written through load_state_dict() (any route) invalidate the e4m3 copies
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.requantize_fp8())
@@ -329,6 +332,12 @@ class Qwen3ForCausalLM(nn.Module):
         qkv = self._proj(xn, f"l{i}.qkv")
         Q, K, V, qr, kr = ops.qwen_qkprep_fwd(qkv, self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin, B, L, Hq, Hkv,
                                               D, c.rms_norm_eps, want_rstd=ctx is not None)
+        if self._flash:
+            # fused causal GQA attention: scores stay in registers; LSE is all the backward needs
+            ao, lse = ops.qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, D ** -0.5)
+            if ctx is not None:
+                ctx.update(qkv=qkv, Q=Q, K=K, V=V, qr=qr, kr=kr, lse=lse, ao=ao)
+            return ao
         S = torch.empty((B * Hq, L, L), device=xn.device, dtype=F32)
         ops.gemm_raw(Q, K, S, L, L, D, D, D, L, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * D, L * D),
                      sB=(Hkv * L * D, L * D), sC=(Hq * L * L, L * L), alpha=D ** -0.5)
@@ -497,11 +506,17 @@ class Qwen3ForCausalLM(nn.Module):
             # o_proj
             # d(attention out) head-major [B, Hq, L, D]: one batch per (b, head) over the column block of W_o
             Wo = self._w[f"l{i}.o"]
-            d_ao = torch.empty((B, self.Hq, L, D), device=dev, dtype=BF16)
-            ops.gemm_raw(dh_mid, Wo, d_ao, L, D, H, H, self.Hq * D, D, nb1=B, nb2=self.Hq, sA=(L * H, 0), sB=(0, D),
-                         sC=(self.Hq * L * D, L * D), transB=True)
-            self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
-            dQ, dK, dV = self._attention_bwd(i, ctx, d_ao, B, L)
+            if self._flash:
+                d_ao = self._dgrad(dh_mid, f"l{i}.o")                   # token-major [B*L, Hq*D]: one plain GEMM
+                self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
+                dQ, dK, dV = ops.qwen_flash_bwd(ctx["Q"], ctx["K"], ctx["V"], saved["keymask"], ctx["ao"], d_ao, ctx["lse"],
+                                                B, L, self.Hq, self.Hkv, D, D ** -0.5)
+            else:
+                d_ao = torch.empty((B, self.Hq, L, D), device=dev, dtype=BF16)
+                ops.gemm_raw(dh_mid, Wo, d_ao, L, D, H, H, self.Hq * D, D, nb1=B, nb2=self.Hq, sA=(L * H, 0), sB=(0, D),
+                             sC=(self.Hq * L * D, L * D), transB=True)
+                self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
+                dQ, dK, dV = self._attention_bwd(i, ctx, d_ao, B, L)
             dqkv = ops.qwen_qkprep_bwd(dQ, dK, dV, ctx["qkv"], self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin,
                                        ctx["qr"], ctx["kr"], self._g[f"l{i}.qn"], self._g[f"l{i}.kn"], accumulate, B, L,
                                        self.Hq, self.Hkv, D)
