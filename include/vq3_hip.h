@@ -277,7 +277,8 @@ int vq3_gemm_fp8_nt(const void* Xq, const float* x_scale, const void* Wq, const 
  * Q [B,Hq,L,128], K/V [B,Hkv,L,128] bf16 (as vq3_qwen_qkprep_fwd writes them); keymask uint8 [B,L] (0 = padded key);
  * O / dO token-major: row (b*L + q), head h at column h*128, row stride ldo / lddo elements.
  * ---------------------------------------------------------------------------------------------------------- */
-/* LSE f32 [B,Hq,L]: log2-domain log-sum-exp of the scaled scores (+inf for rows with no visible key; their O is 0). */
+/* LSE f32 [B,Hq,L] (+ 4 floats of slack behind it, also behind Delta: the backward reads them 16 bytes at a time):
+ * log2-domain log-sum-exp of the scaled scores (+inf for rows with no visible key; their O is 0). */
 int vq3_qwen_flash_fwd(const void* Q, const void* K, const void* V, const void* keymask, void* O, float* LSE, int32_t B,
                        int32_t L, int32_t Hq, int32_t Hkv, int32_t head_dim, int64_t ldo, float scale, void* stream);
 /* dQ [B,Hq,L,128], dK/dV [B,Hkv,L,128] bf16 (summed over the query heads of each kv head in registers/LDS, no atomics).

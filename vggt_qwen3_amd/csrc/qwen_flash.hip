@@ -43,6 +43,32 @@ __device__ __forceinline__ void gather4(const bf16_t* base, long rowstride, int 
     a[3][j] = (short)(v[1] >> 16);
   }
 }
+// the same gather in two phases, so the loads can be issued a whole tile ahead of their use
+__device__ __forceinline__ void gather_load(const bf16_t* base, long rowstride, int row0, int h, int r, int maxrow,
+                                            u32x2 (&g)[2][8]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int row = row0 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+      row = row < maxrow ? row : maxrow;
+      g[s][j] = *reinterpret_cast<const u32x2*>(base + (long)row * rowstride + 4 * r);
+    }
+}
+__device__ __forceinline__ void gather_split(const u32x2 (&g)[8], bf16x8 (&a)[4]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[0][j] = (short)(g[j][0] & 0xffff);
+    a[1][j] = (short)(g[j][0] >> 16);
+    a[2][j] = (short)(g[j][1] & 0xffff);
+    a[3][j] = (short)(g[j][1] >> 16);
+  }
+}
+__device__ __forceinline__ void rows_load(const bf16_t* base, long rowstride, int row, int h, int maxrow, bf16x8 (&f)[8]) {
+  const bf16_t* p = base + (long)(row < maxrow ? row : maxrow) * rowstride + 8 * h;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) f[t] = ld8(p + 16 * t);
+}
 // lanes 0..31 (and their mirrors 32..63) vote on "key kb*32 + r is a real, attended key"
 __device__ __forceinline__ unsigned key_bits(const uint8_t* km, int kb, int r, int L) {
   const int key = kb * 32 + r;
@@ -79,13 +105,16 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
   float m_run = -INFINITY, l_run = 0.f;
   const float sl2e = scale * LOG2E;
   for (int kb = 0; kb <= qb; ++kb) {
-    const int kr = kb * 32 + r;
-    const bf16_t* Kr = Kb + (long)(kr < L ? kr : L - 1) * D + 8 * h;
+    // every load of the tile is issued before its first use: one memory round trip per tile
+    bf16x8 kc[8];
+    u32x2 vc[2][8];
+    rows_load(Kb, D, kb * 32 + r, h, L - 1, kc);
+    gather_load(Vb, D, kb * 32, h, r, L - 1, vc);
     f32x16 s;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(Kr + 16 * t), qf[t], s, 0, 0, 0);
+    for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[t], qf[t], s, 0, 0, 0);
     const unsigned bits = key_bits(km, kb, r, L);
     float mx = -INFINITY;
 #pragma unroll
@@ -115,7 +144,7 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
       bf16x8 vf[4];
-      gather4(Vb, D, kb * 32, sp, h, r, L - 1, vf);
+      gather_split(vc[sp], vf);
       const bf16x8 pf = pack8(s, sp);
 #pragma unroll
       for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db], pf, o[db], 0, 0, 0);
@@ -174,15 +203,18 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
     for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
   const float sl2e = scale * LOG2E;
   for (int kb = 0; kb <= qb; ++kb) {
-    const int kr = kb * 32 + r;
-    const long koff = (long)(kr < L ? kr : L - 1) * D + 8 * h;
+    bf16x8 kc[8], vc[8];
+    u32x2 gc[2][8];
+    rows_load(Kb, D, kb * 32 + r, h, L - 1, kc);
+    rows_load(Vb, D, kb * 32 + r, h, L - 1, vc);
+    gather_load(Kb, D, kb * 32, h, r, L - 1, gc);
     f32x16 s, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(Kb + koff + 16 * t), qf[t], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(Vb + koff + 16 * t), dof[t], dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[t], qf[t], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc[t], dof[t], dp, 0, 0, 0);
     }
     const unsigned bits = key_bits(km, kb, r, L);
 #pragma unroll
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
       bf16x8 kf[4];
-      gather4(Kb, D, kb * 32, sp, h, r, L - 1, kf);
+      gather_split(gc[sp], kf);
       const bf16x8 dsf = pack8(s, sp);
 #pragma unroll
       for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[db], dsf, dq[db], 0, 0, 0);
@@ -248,35 +280,49 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* _
     const float* lse_h = LSE + ((long)b * Hq + hq) * L;
     const float* del_h = Delta + ((long)b * Hq + hq) * L;
     for (int qb = kb; qb < nkb; ++qb) {
-      const int qr = qb * 32 + r, qrc = qr < L ? qr : L - 1;
-      const bf16_t* Qr = Qh + (long)qrc * D + 8 * h;
-      const bf16_t* dOr = dOh + (long)qrc * lddo + 8 * h;
+      // every load of the tile is issued before its first use: one memory round trip per tile instead of four
+      bf16x8 qrow[8], dorow[8];
+      u32x2 gdo[2][8], gq[2][8];
+      f32x4 lse4[4], del4[4];
+      rows_load(Qh, D, qb * 32 + r, h, L - 1, qrow);
+      rows_load(dOh, lddo, qb * 32 + r, h, L - 1, dorow);
+      gather_load(dOh, lddo, qb * 32, h, r, L - 1, gdo);                 // dO^T rows d = 4r + db
+      gather_load(Qh, D, qb * 32, h, r, L - 1, gq);                       // Q^T rows
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {      // rows rho(4c .. 4c+3, h) = 8c + 4h .. +3 are consecutive
+        // unconditional 16-byte loads (a branch here would drain the load queue): a group that starts past the end is
+        // clamped (all its rows are masked), a group that straddles the end reads into the next row / the 4-float slack
+        // the caller guarantees behind LSE and Delta - those rows are masked too
+        int q0 = qb * 32 + 8 * c + 4 * h;
+        q0 = q0 < L ? q0 : (L >= 4 ? L - 4 : 0);
+        lse4[c] = *reinterpret_cast<const f32x4*>(lse_h + q0);
+        del4[c] = *reinterpret_cast<const f32x4*>(del_h + q0);
+      }
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(Qr + 16 * t), kf[t], s, 0, 0, 0);      // S[q, key]
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld8(dOr + 16 * t), vf[t], dp, 0, 0, 0);   // dP[q, key]
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qrow[t], kf[t], s, 0, 0, 0);      // S[q, key]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dorow[t], vf[t], dp, 0, 0, 0);   // dP[q, key]
       }
       f32x16 p;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int qg = qb * 32 + rho(i, h);
-        const int qgc = qg < L ? qg : L - 1;
         const bool ok = key_ok && qg < L && key <= qg;
-        const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2e, -lse_h[qgc])) : 0.f;
+        const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2e, -lse4[i >> 2][i & 3])) : 0.f;
         p[i] = pv;
-        s[i] = pv * (dp[i] - del_h[qgc]) * scale;     // dS[q, key]
+        s[i] = pv * (dp[i] - del4[i >> 2][i & 3]) * scale;     // dS[q, key]
       }
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
         bf16x8 a[4];
-        gather4(dOh, lddo, qb * 32, sp, h, r, L - 1, a);                 // dO^T rows d = 4r + db
+        gather_split(gdo[sp], a);
         const bf16x8 pf = pack8(p, sp);
 #pragma unroll
         for (int db = 0; db < 4; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[db], pf, dv[db], 0, 0, 0);
-        gather4(Qh, D, qb * 32, sp, h, r, L - 1, a);                      // Q^T rows
+        gather_split(gq[sp], a);
         const bf16x8 dsf = pack8(s, sp);
 #pragma unroll
         for (int db = 0; db < 4; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[db], dsf, dk[db], 0, 0, 0);

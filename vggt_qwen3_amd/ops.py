@@ -463,7 +463,7 @@ def qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, scale):
     _req(keymask, torch.uint8, "qwen_flash keymask")
     assert Q.shape == (B, Hq, L, D) and K.shape == (B, Hkv, L, D) and V.shape == K.shape and keymask.shape == (B, L)
     O = torch.empty((B * L, Hq * D), device=Q.device, dtype=BF16)
-    lse = torch.empty((B, Hq, L), device=Q.device, dtype=F32)
+    lse = torch.empty(B * Hq * L + 4, device=Q.device, dtype=F32)[: B * Hq * L].view(B, Hq, L)   # 16 B of slack
     check(_lib.load().vq3_qwen_flash_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
                                          lse.data_ptr(), B, L, Hq, Hkv, D, Hq * D, scale, _stream()), "vq3_qwen_flash_fwd")
     return O, lse
@@ -477,7 +477,7 @@ def qwen_flash_bwd(Q, K, V, keymask, O, dO, lse, B, L, Hq, Hkv, D, scale):
     dQ = torch.empty((B, Hq, L, D), device=dev, dtype=BF16)
     dK = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
     dV = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
-    delta = torch.empty((B, Hq, L), device=dev, dtype=F32)
+    delta = torch.empty(B * Hq * L + 4, device=dev, dtype=F32)
     check(_lib.load().vq3_qwen_flash_bwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
                                          dO.data_ptr(), lse.data_ptr(), delta.data_ptr(), dQ.data_ptr(), dK.data_ptr(),
                                          dV.data_ptr(), B, L, Hq, Hkv, D, O.stride(0), dO.stride(0), scale, _stream()),
