@@ -133,7 +133,7 @@ def cpu_baseline(model, batch, L):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grad-accum", type=int, default=0,
                     help="micro-batches per optimiser step; 0 = min(32, --steps): the timed window is one accumulation "

@@ -105,6 +105,30 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     }
   };
+  // Epilogue operands (bias / LayerScale column vectors, residual quads) are fetched before the LAST K step's MFMAs so
+  // their L2 round trip is hidden; only for the common case (bf16 output, 4-wide aligned rows).
+  constexpr bool PRE_RES = TM * TN <= 8;      // the 256-row tiles have no registers to spare for the residual quads
+  f32x4 bias_r[TN], cs_r[TN];
+  u32x2 res_r[PRE_RES ? TM : 1][TN];
+  const bool pre_ok = !OUT_F32 && p.vec_ok && (p.bias || p.colscale || p.R);
+  auto prefetch_epilogue = [&]() {
+    if (!pre_ok) return;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int n = n0 + wn * (BN / WN) + j * 16 + 4 * fq;
+      n = n + 3 < p.N ? n : (p.N >= 4 ? p.N - 4 : 0);     // clamped lanes fall back to the generic path at store time
+      if (p.bias) bias_r[j] = *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.colscale) cs_r[j] = *reinterpret_cast<const f32x4*>(p.colscale + n);
+      if (PRE_RES && p.R) {
+#pragma unroll
+        for (int i = 0; i < (PRE_RES ? TM : 1); ++i) {
+          int m = m0 + wm * (BM / WM) + i * 16 + fr;
+          m = m < p.M ? m : p.M - 1;
+          res_r[i][j] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.R) + roff + (long)m * p.ldr + n);
+        }
+      }
+    }
+  };
   if (NSTAGE >= 3 && NLOAD > 0) {
     // producer / consumer split inside the workgroup (one s_barrier per K step for everybody):
     //   loader waves:  wait until their pieces of tile t landed -> barrier -> issue tile t+2
@@ -131,22 +155,22 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
       return;
     }
     int stage = 0;
-    for (int t = 0; t < nt; ++t) {
+    for (int t = 0; t < last; ++t) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       compute(stage);
       stage = stage == NSTAGE - 1 ? 0 : stage + 1;
     }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch_epilogue();
+    compute(stage);
   } else if (NSTAGE == 3) {
     issue(0, 0);
     if (nt > 1) issue(1, 1);
     int stage = 0;
-    for (int t = 0; t < nt; ++t) {
-      if (t < last) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+    for (int t = 0; t < last; ++t) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (t + 2 <= last) {
@@ -156,6 +180,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
       compute(stage);
       stage = stage == 2 ? 0 : stage + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch_epilogue();
+    compute(stage);
   } else {
     // two stages, two workgroups per CU: tile t+1 streams in while tile t is multiplied; the co-resident workgroup
     // (its own barrier, naturally out of phase) fills the MFMA pipe while this one waits.
@@ -163,13 +192,15 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    for (int t = 0; t < nt; ++t) {
-      if (t < last) issue(t + 1, (t + 1) & 1);
+    for (int t = 0; t < last; ++t) {
+      issue(t + 1, (t + 1) & 1);
       compute(t & 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
+    prefetch_epilogue();
+    compute(last & 1);
   }
 
 #pragma unroll
@@ -180,7 +211,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / WN) + j * 16 + 4 * fq;
       if (n >= p.N) continue;
-      store_quad<OUT_F32>(p, coff, roff, m, n, acc[i][j]);
+      if (pre_ok && n + 3 < p.N) {
+        u32x2 rv = res_r[PRE_RES ? i : 0][j];
+        if (!PRE_RES && p.R)
+          rv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.R) + roff + (long)m * p.ldr + n);
+        store_quad_pre(p, coff, m, n, acc[i][j], bias_r[j], cs_r[j], rv);
+      }
+      else store_quad<OUT_F32>(p, coff, roff, m, n, acc[i][j]);
     }
   }
 }

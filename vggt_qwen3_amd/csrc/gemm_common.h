@@ -172,6 +172,48 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, long coff, long 
   }
 }
 
+// bf16 epilogue with operands fetched BEFORE the last K step (bias / LayerScale column vectors and the residual quad): the
+// loads' round trip to L2 hides under the final MFMAs instead of stalling the stores. Same arithmetic and rounding
+// points as store_quad; the caller guarantees n + 3 < N, vec_ok, bf16 output, no split-K.
+__device__ __forceinline__ void store_quad_pre(const GemmParams& p, long coff, int m, int n, const f32x4& a, const f32x4& bias_v,
+                                               const f32x4& cs_v, const u32x2& res_v) {
+  bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + coff + (long)m * p.ldc + n;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += bias_v[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+  if (p.act) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rbf(apply_act(v[r], p.act));
+  }
+  if (p.colscale) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rbf(v[r] * cs_v[r]);
+  }
+  if (p.R) {
+    v[0] = rbf(v[0] + bf2f((bf16_t)(res_v[0] & 0xffff)));
+    v[1] = rbf(v[1] + bf2f((bf16_t)(res_v[0] >> 16)));
+    v[2] = rbf(v[2] + bf2f((bf16_t)(res_v[1] & 0xffff)));
+    v[3] = rbf(v[3] + bf2f((bf16_t)(res_v[1] >> 16)));
+  }
+  if (p.accumulate) {
+    const u32x2 cv = *reinterpret_cast<const u32x2*>(cp);
+    v[0] += bf2f((bf16_t)(cv[0] & 0xffff));
+    v[1] += bf2f((bf16_t)(cv[0] >> 16));
+    v[2] += bf2f((bf16_t)(cv[1] & 0xffff));
+    v[3] += bf2f((bf16_t)(cv[1] >> 16));
+  }
+  u32x2 o;
+  o[0] = pack2bf(v[0], v[1]);
+  o[1] = pack2bf(v[2], v[3]);
+  *reinterpret_cast<u32x2*>(cp) = o;
+}
+
 // host: pick the XCD blocking for a tile grid
 inline int choose_xm(int mtiles, int ntiles) {
   int best = 1;
