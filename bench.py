@@ -257,7 +257,7 @@ def main():
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12
         traffic = None
-        tj = ROOT / "profiles" / "r1_pmc_traffic.json"
+        tj = ROOT / "profiles" / "r1c_pmc_traffic.json"
         if tj.exists():  # PMC counters cannot be read from inside the run: this is the committed rocprofv3 --pmc result
             traffic = round(json.loads(tj.read_text())["traffic_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (vq3_gemm_bf16_nt)", "achieved": round(ach, 1),

@@ -18,6 +18,8 @@ def short(name: str) -> str:
     name = name.replace("(anonymous namespace)::", "").replace("vq3gemm::", "")
     if "gemm_v2_kernel" in name or "gemm_nt_kernel" in name:
         return "gemm(" + name.split("<")[1].split(">")[0].replace(" ", "") + ")"
+    if "gemm_v3_kernel" in name or "gemm_v4_kernel" in name:
+        return "gemm(v3:" + name.split("<")[1].split(">")[0].replace(" ", "") + ")"
     return name.split("(")[0][:60]
 
 
