@@ -168,3 +168,43 @@ def test_checkpoint_layout_and_search_order(tmp_path):
     (tmp_path / "empty").mkdir()
     assert ck.load_checkpoint_if_available(make(7), str(tmp_path / "empty"), verbose=False) is None
     assert ck.load_checkpoint_if_available(make(8), None) is None
+
+
+def test_generate_host_logic_cpu():
+    """Host-side pieces of the inference path that need no GPU: the insertion splice (qa_inference.py:119-145, integer
+    layout bit-exact) and the attended-span detection that decides how prompts are compacted."""
+    from vggt_qwen3_amd.generate import _row_spans, insert_vision_tokens
+    ids = torch.tensor([[5, 6, 9, 7, 8], [1, 9, 2, 3, 9]])
+    mask = torch.tensor([[1, 1, 1, 1, 0], [0, 1, 1, 1, 1]])
+    emb = torch.arange(2 * 5 * 4, dtype=torch.float32).view(2, 5, 4)
+    vis = -torch.ones(2, 3, 4)
+    e2, m2 = insert_vision_tokens(ids, mask, emb, vis, 9)
+    assert e2.shape == (2, 7, 4) and m2.tolist() == [[1, 1, 1, 1, 1, 1, 0], [0, 1, 1, 1, 1, 1, 1]]
+    assert torch.equal(e2[:, :2], emb[:, :2]) and torch.equal(e2[:, 2:5], vis) and torch.equal(e2[:, 5:], emb[:, 3:])
+    e3, m3 = insert_vision_tokens(ids, mask, emb, vis, 77)          # no <image>: untouched, same objects
+    assert e3 is emb and m3 is mask
+    assert _row_spans(torch.tensor([[1, 1, 1], [0, 1, 1], [0, 1, 0]])) == [(0, 3), (1, 2), (1, 1)]
+    with pytest.raises(ValueError, match="contiguous"):
+        _row_spans(torch.tensor([[1, 0, 1]]))
+    with pytest.raises(ValueError, match="attends to nothing"):
+        _row_spans(torch.tensor([[0, 0, 0]]))
+
+
+def test_collate_size_rules_and_plan_cpu():
+    """torchvision's Resize / CenterCrop integer rules as the batch builder applies them, against the oracle's
+    restatement, and the plan cache of the library's host-side resampling routine."""
+    from oracle import preprocess as opre
+    from vggt_qwen3_amd import collate
+    for h, w, S in [(480, 640, 448), (640, 480, 448), (448, 448, 448), (449, 448, 448), (100, 1000, 56), (37, 53, 16),
+                    (3, 1000, 8)]:
+        assert collate.resized_size(h, w, S) == opre.resized_size(h, w, S)
+        nh, nw = collate.resized_size(h, w, S)
+        assert min(nh, nw) == S or (h, w) == (nh, nw)
+        assert collate.crop_offset(nw, S) == int(round((nw - S) / 2.0)) and collate.crop_offset(nh, S) == int(round((nh - S) / 2.0))
+    assert collate.crop_offset(451, 448) == 2 and collate.crop_offset(453, 448) == 2      # 1.5 -> 2, 2.5 -> 2 (half to even)
+    ks, b, c = collate.axis_plan(640, 448)
+    k2, b2, c2 = opre.precompute_coeffs(640, 448)
+    assert ks == k2 and (b == b2).all() and (c == c2).all()
+    assert collate.axis_plan(640, 448)[1] is b                                              # cached
+    rows = collate._max_src_rows(b, collate.crop_offset(448, 448), 448, 16)
+    assert rows == int(max(b[min(y + 15, 447), 0] + b[min(y + 15, 447), 1] - b[y, 0] for y in range(0, 448, 16)))
