@@ -236,6 +236,12 @@ int vq3_pack_tokens(const int32_t* prompt_ids, const int32_t* prompt_off, const 
 int vq3_skinny_gemm_bf16(const void* x, const void* W, void* y, const void* residual, const void* ln_w, float eps,
                          int32_t xmode, int32_t M, int32_t N, int32_t K, int64_t ldx, int64_t ldw, int64_t ldy,
                          int64_t ldr, int32_t out_f32, void* stream);
+/* The same product with e4m3 weights (config C5): Wq uint8 e4m3 [N, K] with one f32 scale per output row; the prepared
+ * activation row f(x) is quantised per token in registers exactly as vq3_quant_fp8_rows does, so decode and the fp8
+ * GEMM share one numeric contract. M <= 2, K % 16 == 0, K <= 12288; y bf16. */
+int vq3_skinny_gemm_fp8(const void* x, const void* Wq, const float* w_scale, void* y, const void* residual,
+                        const void* ln_w, float eps, int32_t xmode, int32_t M, int32_t N, int32_t K, int64_t ldx,
+                        int64_t ldw, int64_t ldy, int64_t ldr, void* stream);
 /* One new token per row: qkv bf16 [B, (Hq+2Hkv)*128] -> q_norm/k_norm + RoPE at position lens[b]
  * (modeling_qwen3.py:237-253); Q bf16 [B, Hq, 128]; K, V written into the caches [B, Hkv, Lmax, 128] at slot lens[b].
  * cos/sin: bf16 [>= Lmax, 128] tables. */

@@ -150,3 +150,44 @@ def test_fp8_forward_training_follows_weight_updates():
     from vggt_qwen3_amd import ops
     wq2, ws2 = ops.quant_fp8_rows(model.text_model._w["l1.down"])
     assert torch.equal(wq, wq2) and torch.equal(ws, ws2)
+
+
+def test_fp8_skinny_matches_fp8_gemm_contract(ops):
+    """Decode-time e4m3 product (register-resident row, in-register quantisation, fused RMSNorm / SwiGLU) against the
+    stand-alone kernels feeding the fp8 GEMM: same contract, only the fp32 summation order differs."""
+    torch.manual_seed(4)
+    for M, N, K in [(1, 512, 2560), (2, 6144, 2560), (1, 2560, 4096), (2, 2560, 9728), (1, 100, 1024)]:
+        x = torch.randn(M, K, device="cuda").to(BF16)
+        w = (torch.randn(N, K, device="cuda") * 0.03).to(BF16)
+        r = torch.randn(M, N, device="cuda").to(BF16)
+        lnw = (1 + 0.2 * torch.randn(K, device="cuda")).to(BF16)
+        gu = torch.randn(M, 2 * K, device="cuda").to(BF16)
+        wq, ws = ops.quant_fp8_rows(w)
+        def close(a, b):
+            return ((a.float() - b.float()).norm() / b.float().norm()).item() < 3e-3
+        assert close(ops.skinny_linear_fp8(x, wq, ws), ops.linear_fp8(x, wq, ws))
+        assert close(ops.skinny_linear_fp8(x, wq, ws, residual=r), ops.linear_fp8(x, wq, ws, residual=r))
+        assert close(ops.skinny_linear_fp8(x, wq, ws, ln_w=lnw, eps=1e-6), ops.linear_fp8(ops.rmsnorm_fwd(x, lnw, 1e-6), wq, ws))
+        assert close(ops.skinny_linear_fp8(gu, wq, ws, swiglu=True), ops.linear_fp8(ops.silu_mul_fwd(gu), wq, ws))
+    from vggt_qwen3_amd import _lib
+    with pytest.raises(_lib.Vq3Error, match="M must be 1 or 2"):
+        ops.skinny_linear_fp8(torch.zeros(3, 128, device="cuda", dtype=BF16), torch.zeros(8, 128, device="cuda", dtype=torch.uint8),
+                              torch.ones(8, device="cuda"))
+
+
+def test_fp8_decode_follows_fp8_prefill():
+    """generate() with the e4m3 forward enabled: every picked token is a (near-)argmax of the logits the fp8 prefill path
+    computes for the same prefix - cache, skinny fp8 kernels and the fp8 GEMM agree."""
+    model, z, c = _tiny()
+    model.enable_fp8_forward(True)
+    torch.manual_seed(5)
+    B, L = 2, 21
+    emb = (torch.randn(B, L, c["hidden_size"]) * 0.5).to(BF16).cuda()
+    out = model.generate(inputs_embeds=emb, attention_mask=torch.ones(B, L, dtype=torch.long).cuda(), max_new_tokens=8)
+    assert out.shape == (B, 8)
+    full = torch.cat([emb, model.get_input_embeddings()(out[:, :-1])], dim=1)
+    h, _ = model.forward_hidden(full, torch.ones(B, full.shape[1], dtype=torch.long).cuda(), save=False)
+    logits = model.logits_all(h).view(B, h.shape[0] // B, -1).float()
+    for t in range(8):
+        row = logits[:, L - 1 + t]
+        assert ((row.max(-1).values - row.gather(1, out[:, t:t + 1]).squeeze(1)) < 0.12).all(), t

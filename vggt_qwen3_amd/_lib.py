@@ -66,6 +66,7 @@ SIGNATURES = {
     "vq3_resample_plan": [i32, i32, c_p, c_p],
     "vq3_resize_crop_u8": [c_p, i32, c_p, c_p, c_p, i32, i32, i32, c_p],
     "vq3_skinny_gemm_bf16": [c_p, c_p, c_p, c_p, c_p, f32, i32, i32, i32, i32, i64, i64, i64, i64, i32, c_p],
+    "vq3_skinny_gemm_fp8": [c_p, c_p, c_p, c_p, c_p, c_p, f32, i32, i32, i32, i32, i64, i64, i64, i64, c_p],
     "vq3_qwen_decode_qkprep": [c_p] * 9 + [i32, i32, i32, i32, i32, f32, c_p],
     "vq3_qwen_decode_attn": [c_p] * 5 + [i32, i32, i32, i32, i32, f32, c_p],
     "vq3_greedy_pick": [c_p, i64, c_p, i32, i32, c_p, i32, c_p, c_p, f32, i32, c_p, i32, i64, c_p, c_p],

@@ -245,6 +245,166 @@ __global__ __launch_bounds__(256) void skinny_regx_kernel(const bf16_t* __restri
     }
 }
 
+// e4m3 weights (config C5): the same register-resident-x scheme with 16-byte pieces = 16 weights. The activation row is
+// quantised per token exactly as the fp8 GEMM does (amax over the whole row -> e4m3 round trip in registers), so decode
+// and prefill follow one numeric contract; the weight stream - the only thing that costs time here - is halved.
+__device__ __forceinline__ void unpack16_fp8(const u32x4 v, float* f) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], false);
+    const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], true);
+    f[4 * w + 0] = lo[0]; f[4 * w + 1] = lo[1]; f[4 * w + 2] = hi[0]; f[4 * w + 3] = hi[1];
+  }
+}
+
+template <int MT, int R, int KS, int XMODE>
+__global__ __launch_bounds__(256) void skinny_fp8_kernel(const bf16_t* __restrict__ x, const uint8_t* __restrict__ W,
+                                                        const float* __restrict__ wscale, bf16_t* __restrict__ y,
+                                                        const bf16_t* __restrict__ res, const bf16_t* __restrict__ ln_w,
+                                                        float eps, int M, int N, int K, long ldx, long ldw, long ldy, long ldr) {
+  constexpr int CH = 3;
+  constexpr int G = 4 / KS;
+  __shared__ float red[4][MT];
+  __shared__ float redm[4][MT];
+  __shared__ float part[4][R][MT];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int g = wid / KS, ks = wid % KS;
+  const int n0 = (blockIdx.x * G + g) * R;
+  const bool active = n0 < N;
+  int kof[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) kof[c] = (c * KS + ks) * 1024 + lane * 16;
+  u32x4 wv[R][CH];
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint8_t* wr = W + (long)min(n0 + r, N - 1) * ldw;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) wv[r][c] = __builtin_nontemporal_load((const u32x4*)(wr + min(kof[c], K - 16)));
+    }
+  }
+  float xf[MT][CH][16];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const bf16_t* xr = x + (long)min(m, M - 1) * ldx;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (kof[c] < K) {
+        unpack8(*(const u32x4*)(xr + kof[c]), xf[m][c]);
+        unpack8(*(const u32x4*)(xr + kof[c] + 8), xf[m][c] + 8);
+        if (XMODE == 2) {
+          float up[16];
+          unpack8(*(const u32x4*)(xr + K + kof[c]), up);
+          unpack8(*(const u32x4*)(xr + K + kof[c] + 8), up + 8);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) xf[m][c][j] = rbf(rbf(silu_f(xf[m][c][j])) * up[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xf[m][c][j] = 0.f;
+      }
+    }
+  }
+  if (XMODE == 1) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ss = fmaf(xf[m][c][j], xf[m][c][j], ss);
+      ss = wave_sum(ss);
+      if (lane == 0) red[wid][m] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < KS; ++q) tot += red[g * KS + q][m];
+      const float rstd = rsqrtf(tot / (float)K + eps);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (kof[c] < K) {
+          float lw[16];
+          unpack8(*(const u32x4*)(ln_w + kof[c]), lw);
+          unpack8(*(const u32x4*)(ln_w + kof[c] + 8), lw + 8);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) xf[m][c][j] = rbf(lw[j] * rbf(xf[m][c][j] * rstd));
+        }
+      }
+    }
+  }
+  // per-token e4m3 quantisation of the prepared row (vq3_quant_fp8_rows contract): q = e4m3(x * 448 / amax)
+  float sx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float am = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) am = fmaxf(am, fabsf(xf[m][c][j]));
+    am = wave_max(am);
+    if (lane == 0) redm[wid][m] = am;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float am = 0.f;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) am = fmaxf(am, redm[g * KS + q][m]);
+    const float inv = am > 0.f ? 448.0f / am : 1.0f;
+    sx[m] = am > 0.f ? am / 448.0f : 1.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int j = 0; j < 16; j += 2) {
+        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(xf[m][c][j] * inv, xf[m][c][j + 1] * inv, 0, false);
+        const auto back = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+        xf[m][c][j] = back[0];
+        xf[m][c][j + 1] = back[1];
+      }
+  }
+  float acc[R][MT];
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        float wf[16];
+        unpack16_fp8(wv[r][c], wf);          // chunks past K meet x == 0
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc[r][m] = fmaf(wf[j], xf[m][c][j], acc[r][m]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[r][m] = wave_sum(acc[r][m]);
+        if (KS > 1 && lane == 0) part[wid][r][m] = acc[r][m];
+      }
+  }
+  if (KS > 1) __syncthreads();
+  if (!active || ks != 0 || lane != 0) return;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m >= M || n0 + r >= N) continue;
+      float v = acc[r][m];
+#pragma unroll
+      for (int q = 1; q < KS; ++q) v += part[wid + q][r][m];
+      v = rbf(v * (sx[m] * wscale[n0 + r]));
+      if (res) v += bf2f(res[(long)m * ldr + n0 + r]);
+      y[(long)m * ldy + n0 + r] = f2bf(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ decode q/k prep
 // grid (B, ceil(heads/4)): one head per wave; lane i holds elements i and i+64 (the rotate_half pair)
 __global__ __launch_bounds__(256) void decode_qkprep_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ q_w,
@@ -546,6 +706,21 @@ void launch_skinny(int xmode, const void* x, const void* W, void* y, const void*
   }
 }
 
+template <int MT, int KS>
+void launch_fp8_skinny(int xmode, const void* x, const void* W, const float* ws, void* y, const void* res, const void* ln_w,
+                       float eps, int M, int N, int K, long ldx, long ldw, long ldy, long ldr, hipStream_t s) {
+  constexpr int R = 4;
+  const int rows_per_block = (4 / KS) * R;
+  const dim3 grid((N + rows_per_block - 1) / rows_per_block), block(256);
+#define VQ3_F8(XM)                                                                                                          \
+  hipLaunchKernelGGL((skinny_fp8_kernel<MT, R, KS, XM>), grid, block, 0, s, (const bf16_t*)x, (const uint8_t*)W, ws,        \
+                     (bf16_t*)y, (const bf16_t*)res, (const bf16_t*)ln_w, eps, M, N, K, ldx, ldw, ldy, ldr)
+  if (xmode == 0) VQ3_F8(0);
+  else if (xmode == 1) VQ3_F8(1);
+  else VQ3_F8(2);
+#undef VQ3_F8
+}
+
 }  // namespace
 
 extern "C" int vq3_skinny_gemm_bf16(const void* x, const void* W, void* y, const void* residual, const void* ln_w,
@@ -565,6 +740,32 @@ extern "C" int vq3_skinny_gemm_bf16(const void* x, const void* W, void* y, const
   else if (M <= 4) launch_skinny<4>(xmode, x, W, y, residual, ln_w, eps, M, N, K, ldx, ldw, ldy, ldr, out_f32, s);
   else launch_skinny<8>(xmode, x, W, y, residual, ln_w, eps, M, N, K, ldx, ldw, ldy, ldr, out_f32, s);
   VQ3_CHECK_LAUNCH("skinny_gemm");
+  return 0;
+}
+
+extern "C" int vq3_skinny_gemm_fp8(const void* x, const void* Wq, const float* w_scale, void* y, const void* residual,
+                                   const void* ln_w, float eps, int32_t xmode, int32_t M, int32_t N, int32_t K, int64_t ldx,
+                                   int64_t ldw, int64_t ldy, int64_t ldr, void* stream) {
+  VQ3_CHECK_ARG(x && Wq && w_scale && y, "skinny_gemm_fp8: null pointer");
+  VQ3_CHECK_ARG(M >= 1 && M <= 2, "skinny_gemm_fp8: M must be 1 or 2, got %d (prefill / larger batches use vq3_gemm_fp8_nt)", M);
+  VQ3_CHECK_ARG(N > 0 && K > 0 && K % 16 == 0 && K <= 12288, "skinny_gemm_fp8: need K %% 16 == 0 and K <= 12288 (N=%d K=%d)", N, K);
+  VQ3_CHECK_ARG(xmode >= 0 && xmode <= 2 && (xmode != 1 || ln_w), "skinny_gemm_fp8: xmode must be 0, 1 (needs ln_w) or 2");
+  VQ3_CHECK_ARG(ldx % 8 == 0 && ldw % 16 == 0 && ldx >= (xmode == 2 ? 2l * K : (long)K) && ldw >= K,
+                "skinny_gemm_fp8: row strides must cover the row (x: multiple of 8, W: multiple of 16)");
+  VQ3_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)Wq % 16 == 0) && (!ln_w || (uintptr_t)ln_w % 16 == 0),
+                "skinny_gemm_fp8: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = (K + 1023) / 1024;
+#define VQ3_GO(MT)                                                                                                                  \
+  do {                                                                                                                              \
+    if (chunks <= 3) launch_fp8_skinny<MT, 1>(xmode, x, Wq, w_scale, y, residual, ln_w, eps, M, N, K, ldx, ldw, ldy, ldr, s);       \
+    else if (chunks <= 6) launch_fp8_skinny<MT, 2>(xmode, x, Wq, w_scale, y, residual, ln_w, eps, M, N, K, ldx, ldw, ldy, ldr, s);  \
+    else launch_fp8_skinny<MT, 4>(xmode, x, Wq, w_scale, y, residual, ln_w, eps, M, N, K, ldx, ldw, ldy, ldr, s);                   \
+  } while (0)
+  if (M == 1) VQ3_GO(1);
+  else VQ3_GO(2);
+#undef VQ3_GO
+  VQ3_CHECK_LAUNCH("skinny_gemm_fp8");
   return 0;
 }
 

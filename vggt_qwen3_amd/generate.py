@@ -105,14 +105,22 @@ def _decode_step(tm, st: DecodeState, cos, sin, opts) -> None:
     c = tm.config
     B, Hq, Hkv, D = st.B, tm.Hq, tm.Hkv, tm.D
     h = ops.gather_rows(tm._w["embed"], st.next_ids, B, B)
+    f8 = tm._fp8 if (tm._fp8 is not None and B <= 2) else None     # e4m3 weight stream (config C5): half the bytes per token
+
+    def proj(x, name, **kw):
+        if f8 is not None:
+            wq, ws = f8[name]
+            return ops.skinny_linear_fp8(x, wq, ws, **kw)
+        return ops.skinny_linear(x, tm._w[name], **kw)
+
     for i in range(c.num_hidden_layers):
-        qkv = ops.skinny_linear(h, tm._w[f"l{i}.qkv"], ln_w=tm._w[f"l{i}.ln1"], eps=c.rms_norm_eps)
+        qkv = proj(h, f"l{i}.qkv", ln_w=tm._w[f"l{i}.ln1"], eps=c.rms_norm_eps)
         Q = ops.qwen_decode_qkprep(qkv, tm._w[f"l{i}.qn"], tm._w[f"l{i}.kn"], cos, sin, st.lens, st.K[i], st.V[i], B, Hq, Hkv,
                                    D, st.Lmax, c.rms_norm_eps)
         ao = ops.qwen_decode_attn(Q, st.K[i], st.V[i], st.lens, B, Hq, Hkv, D, st.Lmax, D ** -0.5)
-        h_mid = ops.skinny_linear(ao, tm._w[f"l{i}.o"], residual=h)
-        gu = ops.skinny_linear(h_mid, tm._w[f"l{i}.gu"], ln_w=tm._w[f"l{i}.ln2"], eps=c.rms_norm_eps)
-        h = ops.skinny_linear(gu, tm._w[f"l{i}.down"], residual=h_mid, swiglu=True)
+        h_mid = proj(ao, f"l{i}.o", residual=h)
+        gu = proj(h_mid, f"l{i}.gu", ln_w=tm._w[f"l{i}.ln2"], eps=c.rms_norm_eps)
+        h = proj(gu, f"l{i}.down", residual=h_mid, swiglu=True)
     _logits_and_pick(tm, st, h, opts)
     ops.decode_advance(st.lens, B, st.step)         # the processed token is now cached; one more id has been picked
 

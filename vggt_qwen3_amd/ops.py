@@ -483,3 +483,20 @@ def qwen_flash_bwd(Q, K, V, keymask, O, dO, lse, B, L, Hq, Hkv, D, scale):
                                          dV.data_ptr(), B, L, Hq, Hkv, D, O.stride(0), dO.stride(0), scale, _stream()),
           "vq3_qwen_flash_bwd")
     return dQ, dK, dV
+
+
+def skinny_linear_fp8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
+                      ln_w: Optional[torch.Tensor] = None, eps: float = 0.0, swiglu: bool = False) -> torch.Tensor:
+    """Decode-time form of linear_fp8 for 1-2 rows: e4m3 weight rows streamed once, the activation row prepared (RMSNorm /
+    SwiGLU) and quantised per token in registers (vq3_skinny_gemm_fp8)."""
+    _req(x, BF16, "skinny_fp8 x"); _req(wq, torch.uint8, "skinny_fp8 wq"); _req(ws, F32, "skinny_fp8 ws")
+    assert x.dim() == 2 and wq.dim() == 2 and x.is_contiguous() and wq.is_contiguous() and not (swiglu and ln_w is not None)
+    M, (N, K) = x.shape[0], wq.shape
+    assert x.shape[1] == (2 * K if swiglu else K) and ws.numel() == N
+    out = torch.empty((M, N), device=x.device, dtype=BF16)
+    if residual is not None:
+        _req(residual, BF16, "skinny_fp8 residual"); assert residual.shape == (M, N) and residual.is_contiguous()
+    xmode = 2 if swiglu else (1 if ln_w is not None else 0)
+    check(_lib.load().vq3_skinny_gemm_fp8(x.data_ptr(), wq.data_ptr(), ws.data_ptr(), out.data_ptr(), _p(residual), _p(ln_w),
+                                          eps, xmode, M, N, K, x.shape[1], K, N, N, _stream()), "vq3_skinny_gemm_fp8")
+    return out
