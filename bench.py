@@ -151,6 +151,7 @@ def main():
                     help="run the (frozen) vision tower one micro-batch ahead on a second stream (measured: no gain "
                          "on a saturated GPU; off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trim-variant", action="store_true", help="skip the second timed window (exact padding shortcut)")
     ap.add_argument("--layers", type=int, default=36, help="debug only; anything but 36 marks the line invalid")
     args = ap.parse_args()
 
@@ -233,6 +234,34 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
+    # ---- the same K steps once more with the exact padding shortcut ("if the implementation skips padded
+    # rows ... recompute the figure for the tokens actually executed and report both"). `value` above is the dense run;
+    # this is reported beside it, never instead of it. Loss and gradients are identical (tests/test_fullsize_gpu.py).
+    trimmed = None
+    if not args.trim_pad and not args.no_trim_variant:
+        model.trim_padding = True
+        trainer.grad_accum, trainer.micro = 1, 0
+        loss_t = trainer.micro_step(batch, nxt)      # warm the trimmed shapes (allocator, LDS attributes)
+        sync()
+        t0 = time.perf_counter()
+        for clen in cycles:
+            trainer.grad_accum, trainer.micro = clen, 0
+            for _ in range(clen):
+                loss_t = trainer.micro_step(batch, nxt)
+        sync()
+        dtt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dtt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtt = float(t.item())
+        L_eff = int(model._last_L) if hasattr(model, "_last_L") else None
+        trimmed = {"value": round(world * B * args.steps / dtt, 3), "unit": "samples/s", "ms_per_step": round(dtt / args.steps * 1e3, 2),
+                   "executed_seq_len": L_eff, "loss": round(float(loss_t.item()), 4),
+                   "executed_tflop_per_sample": None if L_eff is None else round(
+                       (flops_vggt(V, args.image_size) + flops_perceiver() + 3 * flops_qwen(L_eff)) / 1e12, 3),
+                   "note": "exact: columns that are padding for every row of the batch are not computed; same loss and gradients"}
+        model.trim_padding = False
+
     # ---- live roofline of the dominant kernel (gemm_nt_kernel): one extra instrumented step, HIP events per launch
     roof = None
     if rank == 0:
@@ -289,6 +318,7 @@ def main():
             "model_flops_utilisation": round(value * tf_train / (world * BF16_DENSE_PEAK_TFLOPS), 4),
             "build_s": round(t_build, 1),
             "roofline": roof,
+            "trimmed_padding_variant": trimmed,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -300,6 +300,7 @@ class VGGTQwen3VLM(nn.Module):
                 labels = labels[:, :L_eff].contiguous()
                 srcmap = srcmap[:, :L_eff].contiguous()
                 L = L_eff
+        self._last_L = L
         emb = ops.embed_splice_fwd(input_ids.contiguous(), tm._w["embed"], feats16, srcmap, B, L, H, S)
         h_last, saved = tm.forward_hidden(emb, attention_mask, save=need_grad)
         loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad, L=saved["L"])
