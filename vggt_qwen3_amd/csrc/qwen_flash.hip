@@ -85,8 +85,11 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nqb = (L + 31) / 32;
-  const int qb = nqb - 1 - (int)(blockIdx.x % nqb);          // longest rows first
-  const int hk = (blockIdx.x / nqb) % Hkv, b = blockIdx.x / (nqb * Hkv);
+  // heaviest blocks first: block ids are handed out in order, so all (b, kv-head) pairs of the last query block (the
+  // most key tiles) start before any lighter one and the light blocks fill the tail
+  const int nbh = gridDim.x / nqb;                            // B * Hkv
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);
+  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
   const int G = Hq / Hkv, hq = hk * G + g;
   if (g >= G) return;
   const int q = qb * 32 + r, qc = q < L ? q : L - 1;
@@ -173,8 +176,9 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nqb = (L + 31) / 32;
-  const int qb = nqb - 1 - (int)(blockIdx.x % nqb);
-  const int hk = (blockIdx.x / nqb) % Hkv, b = blockIdx.x / (nqb * Hkv);
+  const int nbh = gridDim.x / nqb;
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);           // heaviest first (see the forward kernel)
+  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
   const int G = Hq / Hkv, hq = hk * G + g;
   if (g >= G) return;
   const int q = qb * 32 + r, qc = q < L ? q : L - 1;
@@ -257,8 +261,9 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* _
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nkb = (L + 31) / 32;
-  const int kb = blockIdx.x % nkb;                              // kb = 0 has the most q-blocks: it is scheduled first
-  const int hk = (blockIdx.x / nkb) % Hkv, b = blockIdx.x / (nkb * Hkv);
+  const int nbh = gridDim.x / nkb;
+  const int kb = blockIdx.x / nbh;                              // kb = 0 walks the most q-blocks: heaviest first
+  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
   const int G = Hq / Hkv, hq = hk * G + g;
   const bool active = g < G;
   const int key = kb * 32 + r, kc = key < L ? key : L - 1;
