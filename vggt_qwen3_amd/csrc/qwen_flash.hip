@@ -29,21 +29,8 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
   for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[8 * s + j]);
   return o;
 }
-// gather the A operand of "X^T . (acc)" for all four d-blocks: rows[j] = 4 consecutive bf16 of row key(j) at column 4r
-__device__ __forceinline__ void gather4(const bf16_t* base, long rowstride, int row0, int s, int h, int r, int maxrow,
-                                        bf16x8 (&a)[4]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int row = row0 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-    row = row < maxrow ? row : maxrow;
-    const u32x2 v = *reinterpret_cast<const u32x2*>(base + (long)row * rowstride + 4 * r);
-    a[0][j] = (short)(v[0] & 0xffff);
-    a[1][j] = (short)(v[0] >> 16);
-    a[2][j] = (short)(v[1] & 0xffff);
-    a[3][j] = (short)(v[1] >> 16);
-  }
-}
-// the same gather in two phases, so the loads can be issued a whole tile ahead of their use
+// Gather of the A operand of "X^T . (acc)" for all four d-blocks: row key(j) contributes 4 consecutive bf16 at column 4r.
+// Done in two phases so the loads can be issued a whole tile ahead of their use.
 __device__ __forceinline__ void gather_load(const bf16_t* base, long rowstride, int row0, int h, int r, int maxrow,
                                             u32x2 (&g)[2][8]) {
 #pragma unroll

@@ -7,7 +7,7 @@ all-reduce of the gradients before the optimiser step, bucketed so that it can b
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Tuple
+from typing import Dict, Tuple
 
 import torch
 import torch.distributed as dist

@@ -2,7 +2,7 @@
 host, and enqueue the HIP kernel on torch's current stream. No math happens in Python or in torch here."""
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

@@ -7,7 +7,6 @@ ever reaches it. Parameters stay fp32 like the reference's; bf16 compute copies 
 while the residual / LayerNorm stream stays fp32."""
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 
 import torch

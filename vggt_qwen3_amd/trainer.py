@@ -11,7 +11,7 @@ stepped once per optimiser step, loss/grad_accum scaling, and `max_steps` counti
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import BF16, F32, round_up
+from .ops import BF16, F32
 from .perceiver import PerceiverConfig, PerceiverProjector
 from .qwen3 import Qwen3Config, Qwen3ForCausalLM
 
@@ -107,7 +107,6 @@ class _TextLossFn(torch.autograd.Function):
         model, st = ctx.model, ctx.state
         gscale = float(grad_out.item())
         d_geom = model._backward_text(st, gscale, accumulate=False)
-        named = dict(model.text_model.named_parameters())
         grads = []
         for n in model._text_param_names:
             grads.append(model.text_model.grad_views[n].clone() if n in model.text_model.grad_views else None)
