@@ -74,3 +74,49 @@ def test_aggregator_vs_cpu_restatement(H, W, S, B, C):
         e32 = relerr(outs[i], ref32[i])
         noise = relerr(ref16[i], ref32[i])       # what bf16 evaluation itself costs on the CPU restatement
         assert e32 < max(2e-2, 3 * noise), f"iterate {i}: HIP vs fp32 restatement {e32}, bf16 CPU noise {noise}"
+
+
+@pytest.mark.parametrize("use_norm,use_rope", [(True, True), (False, False), (True, False), (False, True)])
+def test_vit_qkprep_vs_fp32_reference(monkeypatch, use_norm, use_rope):
+    """Per-head LayerNorm(64) + 2-D rotate-half RoPE + head-major split, both lane layouts (4 features per lane; the
+    2-feature form forced through VQ3_VIT_QKPREP_VEC2=1) against a plain fp32 restatement of the same arithmetic."""
+    from vggt_qwen3_amd import ops
+    torch.manual_seed(0)
+    G, P, NH, Wp, ps = 2, 21, 4, 4, 5                  # 21 tokens per frame: 5 special + 4x4 patches
+    N = P                                               # frame attention: one frame per group
+    T = G * N
+    qkv = torch.randn(T, 3 * NH * 64, device="cuda").to(torch.bfloat16)
+    qn = (torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1)
+    kn = (torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1)
+    ang = torch.rand(Wp + 1, 16, device="cuda") * 3.0
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(torch.bfloat16).contiguous(), emb.sin().to(torch.bfloat16).contiguous()
+    kw = dict(qn=qn if use_norm else None, kn=kn if use_norm else None, cos=cos if use_rope else None,
+              sin=sin if use_rope else None, tokens_per_frame=P, patch_start=ps, Wp=Wp, eps=1e-5)
+    monkeypatch.delenv("VQ3_VIT_QKPREP_VEC2", raising=False)
+    Q4, K4, V4 = ops.vit_qkprep(qkv, N, NH, **kw)
+    monkeypatch.setenv("VQ3_VIT_QKPREP_VEC2", "1")
+    Q2, K2, V2 = ops.vit_qkprep(qkv, N, NH, **kw)
+    monkeypatch.delenv("VQ3_VIT_QKPREP_VEC2", raising=False)
+    assert torch.equal(V4, V2)
+    for a, b in ((Q4, Q2), (K4, K2)):
+        assert (a.float() - b.float()).abs().max() <= 2 ** -6 * b.float().abs().max()     # LayerNorm sums associate differently
+    # fp32 restatement
+    x = qkv.float().view(G, N, 3, NH, 64).permute(2, 0, 3, 1, 4)          # [3, G, NH, N, 64]
+    def prep(t, nw):
+        if use_norm:
+            t = torch.nn.functional.layer_norm(t, (64,), nw[0], nw[1], 1e-5)
+        t = t.to(torch.bfloat16).float()
+        if use_rope:
+            tp = torch.arange(N, device="cuda") % P
+            py = torch.where(tp >= ps, (tp - ps) // Wp + 1, torch.zeros_like(tp))
+            px = torch.where(tp >= ps, (tp - ps) % Wp + 1, torch.zeros_like(tp))
+            out = []
+            for blk, pos in ((t[..., :32], py), (t[..., 32:], px)):
+                c, s = cos.float()[pos], sin.float()[pos]                   # [N, 32]
+                rot = torch.cat([-blk[..., 16:], blk[..., :16]], -1)
+                out.append(blk * c + rot * s)
+            t = torch.cat(out, -1)
+        return t
+    for got, ref in ((Q4, prep(x[0], qn)), (K4, prep(x[1], kn)), (V4, x[2])):
+        assert ((got.float() - ref).norm() / ref.norm()).item() < 6e-3

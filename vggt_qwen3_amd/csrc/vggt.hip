@@ -106,6 +106,84 @@ __global__ __launch_bounds__(256) void vit_qkprep_kernel(const bf16_t* __restric
   }
 }
 
+// Same contract with 4 features (8 bytes) per lane: 16 lanes per head, four heads per wave pass - half the memory
+// instructions of the 2-feature form. Needs NH % 4 == 0. LayerNorm sums stay inside a 16-lane quarter, the rotate-half
+// partner of feature e is e ^ 16 = lane ^ 4 (same element slot).
+__global__ __launch_bounds__(256) void vit_qkprep4_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ qn_w,
+                                                          const float* __restrict__ qn_b, const float* __restrict__ kn_w,
+                                                          const float* __restrict__ kn_b, const bf16_t* __restrict__ cs,
+                                                          const bf16_t* __restrict__ sn, bf16_t* __restrict__ Q,
+                                                          bf16_t* __restrict__ K, bf16_t* __restrict__ V, int N, int NH,
+                                                          int P, int patch_start, int Wp, int use_norm, int use_rope,
+                                                          float eps) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l16 = lane & 15, quarter = lane >> 4;
+  const long t = blockIdx.x;
+  const long g = t / N;
+  const int n = (int)(t - g * N);
+  const int C = NH * 64;
+  const bf16_t* row = qkv + t * 3L * C;
+  int py = 0, px = 0;
+  if (use_rope) {
+    const int tp = n % P;
+    if (tp >= patch_start) {
+      py = (tp - patch_start) / Wp + 1;
+      px = (tp - patch_start) % Wp + 1;
+    }
+  }
+  const int e0 = 4 * l16;                       // features e0 .. e0+3 of the head
+  const int pos = l16 < 8 ? py : px;
+  const int f0 = e0 & 31;
+  float c[4] = {1.f, 1.f, 1.f, 1.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (use_rope) {
+    const u32x2 cr = *reinterpret_cast<const u32x2*>(cs + pos * 32 + f0);
+    const u32x2 sr = *reinterpret_cast<const u32x2*>(sn + pos * 32 + f0);
+    c[0] = bf2f((bf16_t)(cr[0] & 0xffff)); c[1] = bf2f((bf16_t)(cr[0] >> 16));
+    c[2] = bf2f((bf16_t)(cr[1] & 0xffff)); c[3] = bf2f((bf16_t)(cr[1] >> 16));
+    sv[0] = bf2f((bf16_t)(sr[0] & 0xffff)); sv[1] = bf2f((bf16_t)(sr[0] >> 16));
+    sv[2] = bf2f((bf16_t)(sr[1] & 0xffff)); sv[3] = bf2f((bf16_t)(sr[1] >> 16));
+  }
+  const bool neg = (l16 & 4) == 0;              // (e & 16) == 0 -> rotate-half takes -x[e+16]
+  for (int hq = wid; hq < (3 * NH) / 4; hq += 4) {
+    const int hh = 4 * hq + quarter;
+    const int which = hh / NH, h = hh - which * NH;
+    const u32x2 raw = *reinterpret_cast<const u32x2*>(row + which * C + h * 64 + e0);
+    float x[4] = {bf2f((bf16_t)(raw[0] & 0xffff)), bf2f((bf16_t)(raw[0] >> 16)), bf2f((bf16_t)(raw[1] & 0xffff)),
+                  bf2f((bf16_t)(raw[1] >> 16))};
+    bf16_t* dst = (which == 0 ? Q : (which == 1 ? K : V)) + ((g * NH + h) * (long)N + n) * 64 + e0;
+    if (which < 2) {
+      if (use_norm) {
+        float sum = (x[0] + x[1]) + (x[2] + x[3]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum * (1.f / 64.f);
+        float d[4], sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d[j] = x[j] - mean; sq = fmaf(d[j], d[j], sq); }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rs = rsqrtf(sq * (1.f / 64.f) + eps);
+        const f32x4 w = *reinterpret_cast<const f32x4*>((which == 0 ? qn_w : kn_w) + e0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>((which == 0 ? qn_b : kn_b) + e0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = rbf(d[j] * rs * w[j] + b[j]);
+      }
+      if (use_rope) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pj = __shfl_xor(x[j], 4, 64);
+          const float rj = neg ? -pj : pj;
+          x[j] = rbf(rbf(x[j] * c[j]) + rbf(rj * sv[j]));
+        }
+      }
+    }
+    u32x2 o;
+    o[0] = pack2bf(x[0], x[1]);
+    o[1] = pack2bf(x[2], x[3]);
+    *reinterpret_cast<u32x2*>(dst) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ flash attention
 // Q,K bf16 [NB, N, 64]; Vt bf16 [NB, 64, Np] (V transposed, zero-padded to Np % 64 == 0); O bf16 token-major:
 // O[(g*N + q) * ldo + h*64 + d] with NB = G*NH, g = nb / NH, h = nb % NH.
@@ -314,9 +392,17 @@ extern "C" int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* q
   VQ3_CHECK_ARG(T > 0 && N > 0 && T % N == 0 && NH > 0 && NH % 2 == 0, "vit_qkprep: bad shape (NH must be even)");
   VQ3_CHECK_ARG(!use_norm || (qn_w && qn_b && kn_w && kn_b), "vit_qkprep: norm weights missing");
   VQ3_CHECK_ARG(!use_rope || (cos && sin && tokens_per_frame > 0 && Wp > 0), "vit_qkprep: rope tables missing");
-  hipLaunchKernelGGL(vit_qkprep_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, qn_w,
-                     qn_b, kn_w, kn_b, (const bf16_t*)cos, (const bf16_t*)sin, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V, N, NH,
-                     tokens_per_frame, patch_start, Wp, use_norm, use_rope, eps);
+  const char* force2 = getenv("VQ3_VIT_QKPREP_VEC2");   // tests: compare the two lane layouts on the same input
+  const bool vec4 = !(force2 && force2[0] == '1') && NH % 4 == 0 && (!use_norm || (((uintptr_t)qn_w | (uintptr_t)qn_b | (uintptr_t)kn_w | (uintptr_t)kn_b) % 16 == 0)) &&
+                    (!use_rope || (((uintptr_t)cos | (uintptr_t)sin) % 8 == 0));
+  if (vec4)
+    hipLaunchKernelGGL(vit_qkprep4_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, qn_w,
+                       qn_b, kn_w, kn_b, (const bf16_t*)cos, (const bf16_t*)sin, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V, N, NH,
+                       tokens_per_frame, patch_start, Wp, use_norm, use_rope, eps);
+  else
+    hipLaunchKernelGGL(vit_qkprep_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, qn_w,
+                       qn_b, kn_w, kn_b, (const bf16_t*)cos, (const bf16_t*)sin, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V, N, NH,
+                       tokens_per_frame, patch_start, Wp, use_norm, use_rope, eps);
   VQ3_CHECK_LAUNCH("vit_qkprep");
   return 0;
 }
