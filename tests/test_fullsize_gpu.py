@@ -3,7 +3,7 @@ Qwen3-4B; C4 adds 8 geometry tokens) through size-independent properties - the C
 test time, the properties below hold for the reference by construction:
   * batch-order invariance of the mean token loss, invariance to extra padding columns (masked keys, no labels),
   * exactness of the trimmed-padding shortcut (loss and gradients),
-  * linearity of gradient accumulation, determinism of the forward,
+  * linearity of gradient accumulation, repeatability of the forward,
   * e4m3 forward stays within its stated distance of the bf16 loss,
   * greedy decoding: determinism, KV-cache logits == cache-free forward logits on the generated sequence."""
 import importlib.util
@@ -58,7 +58,7 @@ def test_c2_c4_forward_properties(full):
     model, b = full
     base = _loss(model, b)["loss"].item()
     assert 11.0 < base < 14.0                                   # random init: about ln(vocab)
-    assert _loss(model, b)["loss"].item() == base               # deterministic forward
+    assert abs(_loss(model, b)["loss"].item() - base) < 1e-6 * base   # repeatable (the CE row sums meet by f32 atomics)
     # batch-order invariance
     perm = torch.tensor([3, 0, 5, 1, 4, 2], device="cuda")
     pb = {k: (v[perm] if torch.is_tensor(v) else v) for k, v in b.items()}
@@ -111,7 +111,7 @@ def test_fp8_forward_and_decode_at_full_size(full):
     finally:
         tm.enable_fp8_forward(False)
     assert abs(f8 - base) < 0.02 * base, (f8, base)
-    assert _loss(model, b)["loss"].item() == base               # bf16 path restored exactly
+    assert abs(_loss(model, b)["loss"].item() - base) < 1e-6 * base   # bf16 path restored
     # greedy decoding on a 150-position prompt of spliced embeddings
     torch.manual_seed(0)
     emb = (torch.randn(1, 150, tm.config.hidden_size, device="cuda") * 0.02).to(BF16)
