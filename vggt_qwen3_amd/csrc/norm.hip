@@ -152,7 +152,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------- LayerNorm forward
-template <bool X_F32>
+template <bool X_F32, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ res_,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             bf16_t* y_bf16, float* y_f32, long rows, int cols,
@@ -182,27 +182,52 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
       }
     }
   };
+  // rows of up to 256 * NCH * ... elements are read ONCE and kept in registers (NCH chunks of 4 per lane); NCH == 0 is the
+  // generic three-pass form for other widths
+  float cache[NCH > 0 ? NCH : 1][4];
   float s = 0.f;
-  for (int c = lane * 4; c < cols; c += 256) {
-    float v[4];
-    ldrow(c, v);
-    s += v[0] + v[1] + v[2] + v[3];
+  if (NCH > 0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < cols) {
+        ldrow(c, cache[i]);
+        s += cache[i][0] + cache[i][1] + cache[i][2] + cache[i][3];
+      }
+    }
+  } else {
+    for (int c = lane * 4; c < cols; c += 256) {
+      float v[4];
+      ldrow(c, v);
+      s += v[0] + v[1] + v[2] + v[3];
+    }
   }
   const float mean = wave_sum(s) / (float)cols;
   float q = 0.f;
-  for (int c = lane * 4; c < cols; c += 256) {
-    float v[4];
-    ldrow(c, v);
+  if (NCH > 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float d = v[j] - mean;
-      q += d * d;
+    for (int i = 0; i < NCH; ++i) {
+      if (lane * 4 + 256 * i < cols) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = cache[i][j] - mean;
+          q += d * d;
+        }
+      }
+    }
+  } else {
+    for (int c = lane * 4; c < cols; c += 256) {
+      float v[4];
+      ldrow(c, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[j] - mean;
+        q += d * d;
+      }
     }
   }
   const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
-  for (int c = lane * 4; c < cols; c += 256) {
-    float v[4];
-    ldrow(c, v);
+  auto emit = [&](int c, const float (&v)[4]) {
     const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c);
     float o[4];
@@ -214,6 +239,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
       p[0] = pack2bf(o[0], o[1]);
       p[1] = pack2bf(o[2], o[3]);
       *reinterpret_cast<u32x2*>(y_bf16 + row * (long)cols + c) = p;
+    }
+  };
+  if constexpr (NCH > 0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < cols) emit(c, cache[i]);
+    }
+  } else {
+    for (int c = lane * 4; c < cols; c += 256) {
+      float v[4];
+      ldrow(c, v);
+      emit(c, v);
     }
   }
 }
@@ -258,12 +296,16 @@ extern "C" int vq3_layernorm_fwd(const void* x, const void* res, int32_t x_f32, 
   VQ3_CHECK_ARG(x && w && b && (y_bf16 || y_f32), "layernorm_fwd: null pointer");
   VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_fwd: cols=%d must be a positive multiple of 4", cols);
   const long nblk = (rows + 3) / 4;
-  if (x_f32)
-    hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, res, w,
-                       b, (bf16_t*)y_bf16, y_f32, (long)rows, cols, eps);
-  else
-    hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, res, w,
-                       b, (bf16_t*)y_bf16, y_f32, (long)rows, cols, eps);
+  const int nch = cols <= 1024 ? 4 : (cols <= 2048 ? 8 : (cols <= 4096 ? 16 : 0));
+#define VQ3_LN(F32, N)                                                                                                   \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<F32, N>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x, res, w, b, \
+                     (bf16_t*)y_bf16, y_f32, (long)rows, cols, eps)
+  if (x_f32) {
+    if (nch == 4) VQ3_LN(true, 4); else if (nch == 8) VQ3_LN(true, 8); else if (nch == 16) VQ3_LN(true, 16); else VQ3_LN(true, 0);
+  } else {
+    if (nch == 4) VQ3_LN(false, 4); else if (nch == 8) VQ3_LN(false, 8); else if (nch == 16) VQ3_LN(false, 16); else VQ3_LN(false, 0);
+  }
+#undef VQ3_LN
   VQ3_CHECK_LAUNCH("layernorm_fwd");
   return 0;
 }
