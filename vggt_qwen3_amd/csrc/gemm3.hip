@@ -207,6 +207,26 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     __syncthreads();
   };
 
+  // Read-modify-write operands of the epilogue (the gradient being accumulated into, a residual) are fetched before the
+  // last K tile's MFMAs, so their L2 round trip is not paid between the last MFMA and the first store.
+  u32x2 pre_r[TM][TN];     // one operand only (registers): the accumulation target, else the residual
+  const bool pre_ok = !OUT_F32 && p.vec_ok && p.nsplit == 1 && !p.bias && !p.colscale && (p.accumulate != 0) != (p.R != nullptr);
+  auto prefetch_epilogue = [&]() {
+    if (!pre_ok) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int m = m0 + wm * (BM / WM) + i * 16 + fr;
+      m = m < p.M ? m : p.M - 1;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int n = n0 + wn * (BN / WN) + j * 16 + 4 * fq;
+        n = n + 3 < p.N ? n : (p.N >= 4 ? p.N - 4 : 0);
+        if (p.accumulate) pre_r[i][j] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.C) + coff + (long)m * p.ldc + n);
+        else pre_r[i][j] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.R) + roff + (long)m * p.ldr + n);
+      }
+    }
+  };
+
   // The last K tile is peeled out of the loop: its zero-fill does LDS stores, and with LDS stores inside the loop
   // hipcc orders every fragment read behind the in-flight LDS-DMA (s_waitcnt vmcnt(0) per K step), which drains the
   // prefetch pipeline. The steady-state loop touches LDS by DMA and ds_read only.
@@ -246,6 +266,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (krem) zero_tail(stage);
+    prefetch_epilogue();
     compute(stage);
   } else if (NSTAGE == 3) {
     issue(0, 0);
@@ -266,6 +287,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (krem) zero_tail(stage);
+    prefetch_epilogue();
     compute(stage);
   } else {
     issue(0, 0);
@@ -280,6 +302,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
       __builtin_amdgcn_sched_barrier(0);
     }
     if (krem) zero_tail(last & 1);
+    prefetch_epilogue();
     compute(last & 1);
   }
 
@@ -291,7 +314,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / WN) + j * 16 + 4 * fq;
       if (n >= p.N) continue;
-      store_quad<OUT_F32>(p, coff, roff, m, n, acc[i][j]);
+      if (pre_ok && n + 3 < p.N) store_quad_pre(p, coff, m, n, acc[i][j], f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, pre_r[i][j], &pre_r[i][j]);
+      else store_quad<OUT_F32>(p, coff, roff, m, n, acc[i][j]);
     }
   }
 }

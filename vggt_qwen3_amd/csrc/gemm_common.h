@@ -176,7 +176,7 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, long coff, long 
 // loads' round trip to L2 hides under the final MFMAs instead of stalling the stores. Same arithmetic and rounding
 // points as store_quad; the caller guarantees n + 3 < N, vec_ok, bf16 output, no split-K.
 __device__ __forceinline__ void store_quad_pre(const GemmParams& p, long coff, int m, int n, const f32x4& a, const f32x4& bias_v,
-                                               const f32x4& cs_v, const u32x2& res_v) {
+                                               const f32x4& cs_v, const u32x2& res_v, const u32x2* c_pre = nullptr) {
   bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + coff + (long)m * p.ldc + n;
   float v[4];
 #pragma unroll
@@ -202,7 +202,7 @@ __device__ __forceinline__ void store_quad_pre(const GemmParams& p, long coff, i
     v[3] = rbf(v[3] + bf2f((bf16_t)(res_v[1] >> 16)));
   }
   if (p.accumulate) {
-    const u32x2 cv = *reinterpret_cast<const u32x2*>(cp);
+    const u32x2 cv = c_pre ? *c_pre : *reinterpret_cast<const u32x2*>(cp);
     v[0] += bf2f((bf16_t)(cv[0] & 0xffff));
     v[1] += bf2f((bf16_t)(cv[0] >> 16));
     v[2] += bf2f((bf16_t)(cv[1] & 0xffff));
