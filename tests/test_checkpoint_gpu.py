@@ -119,3 +119,51 @@ def test_trainer_resume(tmp_path):
     save_trainer_state(ta, tmp_path / "mid")
     with pytest.raises(RuntimeError, match="accumulation"):
         load_trainer_state(tc, tmp_path / "mid")
+
+
+def test_constructor_from_local_hf_directory(tmp_path):
+    """The reference's own constructor route (vggt_qwen3_vlm.py:29-45): `text_model_name` is a LOCAL directory with
+    config.json + *.safetensors + tokenizer files, `vision_ckpt_dir` has no checkpoint (warning + random init), only the
+    reference's dataclass fields are used. The tokenizer gains <image>, the embedding is resized, and the loaded text
+    weights reproduce the golden logits."""
+    import json
+    import shutil
+    from safetensors.torch import save_file
+    from tests.golden_io import GOLDEN, bf16
+    from vggt_qwen3_amd.perceiver import PerceiverConfig
+    from vggt_qwen3_amd.vlm import VGGTQwen3VLM, VisionLanguageConfig
+    z = load("qwen3_tiny.npz")
+    c = meta(z, "config")
+    d = tmp_path / "tiny_qwen3"
+    shutil.copytree(GOLDEN / "tiny_tokenizer", d)
+    hf_cfg = dict(architectures=["Qwen3ForCausalLM"], model_type="qwen3", hidden_size=c["hidden_size"],
+                  num_hidden_layers=c["num_hidden_layers"], num_attention_heads=c["num_attention_heads"],
+                  num_key_value_heads=c["num_key_value_heads"], head_dim=c["head_dim"],
+                  intermediate_size=c["intermediate_size"], vocab_size=c["vocab_size"], rms_norm_eps=c["rms_norm_eps"],
+                  rope_parameters={"rope_theta": c["rope_theta"], "rope_type": "default"}, tie_word_embeddings=True)
+    (d / "config.json").write_text(json.dumps(hf_cfg))
+    save_file({k: v.contiguous() for k, v in weights(z).items()}, str(d / "model.safetensors"))
+    cfg = VisionLanguageConfig(text_model_name=str(d), vision_ckpt_dir=str(tmp_path / "no_ckpt_here"), num_vis_tokens=16,
+                               geom_tokens=4, projector_cfg=PerceiverConfig(latent_dim=128, num_latents=16, num_heads=2,
+                                                                            num_layers=1, ffn_dim=256),
+                               freeze_vision=True, dtype="bfloat16")
+    cfg.vision_config = dict(depth=1, embed_dim=128, dino_depth=1)        # extension field: keep the test's vision tower tiny
+    model = VGGTQwen3VLM(cfg).to("cuda")
+    tm = model.text_model
+    vocab0 = c["vocab_size"]
+    assert "<image>" in model.tokenizer.get_vocab() and model.image_id == model.tokenizer.convert_tokens_to_ids("<image>")
+    assert tm.vocab == len(model.tokenizer)          # resize_token_embeddings(len(tokenizer)) as the reference does (:40-42)
+    assert tm.get_input_embeddings().weight.shape[0] == tm.vocab and tm.config.hidden_size == c["hidden_size"]
+    assert all(not p.requires_grad for p in model.vision_model.parameters())
+    # the loaded text weights reproduce the golden forward
+    emb = bf16(z["inputs_embeds"]).cuda()
+    mask = torch.from_numpy(z["attention_mask"]).cuda()
+    h, saved = tm.forward_hidden(emb, mask, save=False)
+    B, L = mask.shape
+    nv = min(vocab0, tm.vocab)
+    logits = tm.logits_all(h).view(B, saved["L"], -1)[:, :L, :nv].float().cpu()
+    gold = bf16(z["logits"]).float()[..., :nv]
+    keep = mask.bool().cpu()
+    assert ((logits[keep] - gold[keep]).norm() / gold[keep].norm()).item() < 1e-2
+    with pytest.raises(FileNotFoundError, match="local directory"):
+        VGGTQwen3VLM(VisionLanguageConfig(text_model_name="Qwen/Qwen3-4B-Instruct-2507", vision_ckpt_dir="x"))
