@@ -236,3 +236,56 @@ def test_generate_argument_errors():
         model.generate(inputs_embeds=e, attention_mask=torch.tensor([[1, 0, 1, 1]]).cuda())
     with pytest.raises(ValueError):
         model.generate(inputs_embeds=torch.zeros(9, 4, cfg["hidden_size"], device="cuda", dtype=BF16))
+
+
+def test_inference_flow_like_the_reference_script():
+    """qa_inference.run_inference's per-sample sequence (qa_inference.py:171-216) on the tiny golden VLM: tokenizer ->
+    embed -> encode_images -> insertion splice -> generate -> decode. The HIP ids must equal the CPU oracle's (oracle
+    Perceiver + splice + cache-free greedy loop on the same weights) up to a bf16 near-tie."""
+    from oracle import generate as og
+    from oracle import perceiver as operc
+    from oracle import qwen3 as oq
+    from oracle import vlm as ovlm
+    from tests.test_parity_gpu import _build_vlm
+    from vggt_qwen3_amd.generate import insert_vision_tokens
+    z = load("vlm_tiny.npz")
+    m = meta(z)
+    model = _build_vlm(z, m).eval()
+    tok = model.tokenizer
+    sd = weights(z)
+    prompt = "what color is the chair\n<image>\n"
+    enc = tok(prompt, return_tensors="pt")
+    input_ids, attn = enc["input_ids"].cuda(), enc["attention_mask"].cuda()
+    assert (input_ids == model.image_id).sum() == 1
+    views = torch.from_numpy(z["pixel_values"][:1].astype(np.float32)).cuda()         # [1, V, 3, H, W]
+    with torch.no_grad():
+        vis = model.encode_images(views)
+        text_dtype = model.text_model.get_input_embeddings().weight.dtype
+        emb = model.text_model.get_input_embeddings()(input_ids).to(text_dtype)
+        emb2, attn2 = insert_vision_tokens(input_ids, attn, emb, vis.to(text_dtype), model.image_id)
+        assert emb2.shape[1] == input_ids.shape[1] - 1 + m["num_vis_tokens"] and int(attn2.sum()) == emb2.shape[1]
+        out = model.text_model.generate(inputs_embeds=emb2, attention_mask=attn2, max_new_tokens=10, do_sample=False,
+                                        num_beams=1, eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id,
+                                        repetition_penalty=1.1)
+    assert out.dtype == torch.int64 and out.shape[0] == 1 and 1 <= out.shape[1] <= 10
+    assert int(out.max()) < len(tok) and isinstance(tok.decode(out[0], skip_special_tokens=True), str)
+    # CPU oracle of the same flow
+    tsd = {k[len("text_model."):]: v for k, v in sd.items() if k.startswith("text_model.")}
+    psd = {k[len("projector."):]: v.float() for k, v in sd.items() if k.startswith("projector.")}
+    agg = ovlm.select_tokens(bf16(z["agg"])[:1].float(), m["num_vis_tokens"])
+    vis_ref = operc.projector(agg, psd, m["num_heads"], m["num_layers"]).to(torch.bfloat16)
+    emb_ref = torch.nn.functional.embedding(input_ids.cpu(), tsd["model.embed_tokens.weight"])
+    e_ref, a_ref = insert_vision_tokens(input_ids.cpu(), attn.cpu(), emb_ref, vis_ref, model.image_id)
+    assert ((emb2.float().cpu() - e_ref.float()).norm() / e_ref.float().norm()).item() < 1e-2
+    qc = oq.Qwen3Cfg(hidden_size=m["hidden_size"], num_hidden_layers=m["num_hidden_layers"],
+                     num_attention_heads=m["num_attention_heads"], num_key_value_heads=m["num_key_value_heads"],
+                     head_dim=m["head_dim"], intermediate_size=m["intermediate_size"], vocab_size=m["vocab"],
+                     rms_norm_eps=m["rms_norm_eps"], rope_theta=m["rope_theta"])
+    trace = []
+    ref = og.greedy_generate(tsd, qc, e_ref, a_ref, max_new_tokens=10, repetition_penalty=1.1,
+                             eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id or 0, trace=trace)
+    n = min(ref.shape[1], out.shape[1])
+    diff = (out[0, :n].cpu() != ref[0, :n]).nonzero().flatten()
+    first = int(diff[0]) if diff.numel() else n
+    assert first == n or trace[first] < TIE_TOL, (out.tolist(), ref.tolist(), trace)
+    assert first >= 1
