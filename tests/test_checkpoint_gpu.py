@@ -167,3 +167,30 @@ def test_constructor_from_local_hf_directory(tmp_path):
     assert ((logits[keep] - gold[keep]).norm() / gold[keep].norm()).item() < 1e-2
     with pytest.raises(FileNotFoundError, match="local directory"):
         VGGTQwen3VLM(VisionLanguageConfig(text_model_name="Qwen/Qwen3-4B-Instruct-2507", vision_ckpt_dir="x"))
+
+
+def test_trainer_fit_loop_like_train_sft(tmp_path):
+    """Stage1Trainer.fit = the reference's loop body (train_sft.py:208-255): max_steps counts micro-batches, periodic
+    step_{n} checkpoints + a final one in the reference's layout, rank-0 log lines with both learning rates and samples/s,
+    the iterable restarts when exhausted, and the loss goes down on a tiny fixed set."""
+    from vggt_qwen3_amd.checkpoint import INDEX_NAME, MERGED_DIR, TRAINER_STATE, load_checkpoint_if_available
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z = load("vlm_tiny.npz")
+    m = meta(z)
+    model = _build_vlm(z, m).train()
+    b = _batch(z)
+    half = {k: (v[:3] if torch.is_tensor(v) else v) for k, v in b.items()}
+    half["geom_token"] = {k: v[:3] for k, v in b["geom_token"].items()}
+    tr = Stage1Trainer(model, lr=2e-3, proj_lr=2e-3, weight_decay=0.0, warmup_ratio=0.1, max_steps=10, grad_accum=2)
+    lines = []
+    recs = tr.fit([b, half], log_every_steps=3, save_every_steps=4, output_dir=tmp_path / "run", log=lines.append)
+    assert tr.micro == 10 and tr.opt_step == 5
+    assert [r["step"] for r in recs] == [0, 3, 6, 9] and len(lines) == 4 and "samples/s" in lines[0] and "LR:" in lines[0]
+    assert recs[-1]["loss"] < recs[0]["loss"]
+    assert recs[1]["samples_per_s"] > 0 and recs[0]["lr"] == 0.0 and recs[-1]["lr"] > 0     # warm-up starts at zero
+    for d in ("run/step_4", "run/step_8", "run"):
+        assert (tmp_path / d / MERGED_DIR / INDEX_NAME).exists(), d
+        assert (tmp_path / d / TRAINER_STATE).exists(), d                                  # 4, 8, 10: accumulation boundaries
+    fresh = _build_vlm(z, m)
+    assert load_checkpoint_if_available(fresh, str(tmp_path / "run"), verbose=False) is not None
+    assert torch.equal(fresh.text_model.flat_w, model.text_model.flat_w)

@@ -130,6 +130,56 @@ class Stage1Trainer:
                     off += p.numel()
             self._geom_has_grad = False
 
+    # ------------------------------------------------------------------ the reference's loop
+    def fit(self, batches, *, log_every_steps: int = 10, save_every_steps: Optional[int] = None, output_dir=None,
+            samples_per_batch: Optional[int] = None, log=print) -> List[dict]:
+        """The body of train_sft.py:208-255 around micro_step(): `batches` is any iterable of collator dicts (restarted when
+        exhausted); the loop stops after `max_steps` MICRO-batches (the reference's `step` counts micro-batches, :244-253);
+        rank 0 logs loss, both learning rates, steps/s and samples/s every `log_every_steps`; every `save_every_steps` and at
+        the end the model is written in the reference's key space (+ trainer state, when the step is an accumulation
+        boundary). Returns the log records."""
+        import time
+        from pathlib import Path
+        from . import checkpoint
+        rank = dist.get_rank(self.pg) if self.dist_on else 0
+        records: List[dict] = []
+        it = iter(batches)
+        t0 = time.perf_counter()
+        start = self.micro
+        while self.micro < self.max_steps:
+            try:
+                batch = next(it)
+            except StopIteration:
+                it = iter(batches)
+                batch = next(it)
+            loss = self.micro_step(batch)
+            step = self.micro - 1
+            if rank == 0 and step % log_every_steps == 0:
+                dt = time.perf_counter() - t0
+                done = self.micro - start
+                nb = samples_per_batch if samples_per_batch is not None else int(batch["input_ids"].shape[0])
+                lr, plr = self.lrs()
+                rec = {"step": step, "loss": float(loss.item()), "lr": lr, "proj_lr": plr, "steps_per_s": done / dt,
+                       "samples_per_s": done * nb * self.world / dt}
+                records.append(rec)
+                log(f"Step {step:5d}/{self.max_steps} | Loss: {rec['loss']:.4f} | LR: {lr:.2e}/{plr:.2e} | "
+                    f"Speed: {rec['steps_per_s']:.2f} steps/s, {rec['samples_per_s']:.1f} samples/s")
+            if save_every_steps and output_dir is not None and self.micro % save_every_steps == 0:
+                self._save(Path(output_dir) / f"step_{self.micro}", rank, checkpoint)
+        if output_dir is not None:
+            self._save(Path(output_dir), rank, checkpoint)
+        return records
+
+    def _save(self, path, rank: int, checkpoint) -> None:
+        if self.dist_on:
+            dist.barrier(group=self.pg)
+        if rank == 0:                       # replicas are identical: one writer (the reference makes every rank call save_state
+            checkpoint.save_model(self.model, path)        # only because ZeRO-3 shards need gathering)
+            if self.micro % self.grad_accum == 0:
+                checkpoint.save_trainer_state(self, path)
+        if self.dist_on:
+            dist.barrier(group=self.pg)
+
     def lrs(self):
         mult = cosine_with_warmup(max(0, self.opt_step - 1), self.warmup, self.max_steps)
         return self.lr * mult, self.proj_lr * mult
