@@ -175,6 +175,12 @@ int choose_config(int M, int N, int K, int nbatch) {
 
 // v3 (k-major operands / K tails) has 128x128 tiles only: 3-stage ring + loader waves vs 2 stages x 2 workgroups.
 int choose_v3_stages(int M, int N, int K, int nbatch) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("VQ3_GEMM_V3_STAGES");   // benchmarking override: 2 or 3
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 2 || forced == 3) return forced;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
   const bool shortk = K <= 1536;
   const double s2 = (shortk ? 1.00 : 0.93) * fill(t128, 512);
