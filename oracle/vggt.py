@@ -1,4 +1,5 @@
-"""VGGT aggregator restated on CPU (PARITY UNPINNED - see package docstring).
+"""VGGT aggregator restated on CPU (PARITY UNPINNED for the alternating frame/global stage; the DINOv2 backbone stage
+is pinned by tests/golden/dinov2_tiny.npz - see dino_tokens() and the package docstring).
 
 The reference repository holds neither the `vggt` package nor its weights nor any vector pinning its output; the
 only in-repo facts are the call site `VGGT(img_size=518, patch_size=14, embed_dim=1024, ...).aggregator(images)`
@@ -76,6 +77,26 @@ def interpolate_pos(pos_embed: torch.Tensor, Hp: int, Wp: int, dtype):
     return torch.cat((pe[:, :1], pp), dim=1).to(dtype)
 
 
+def dino_tokens(x: torch.Tensor, sd: Dict[str, torch.Tensor], *, patch_size=14, num_heads=16, dino_depth=24,
+                num_register_tokens=4) -> torch.Tensor:
+    """The DINOv2-with-registers backbone VGGT uses as `patch_embed` (layers/vision_transformer.py): normalised images
+    [N, 3, H, W] -> all tokens after the final LayerNorm [N, 1 + R + Np, C] in the order [cls | registers | patches].
+    This stage IS pinned: tests/golden/dinov2_tiny.npz holds the output of transformers' Dinov2WithRegistersModel (an
+    independent implementation of the same published model) on the same weights (tools/make_golden_dinov2.py)."""
+    p = patch_size
+    N, _, H, W = x.shape
+    Hp, Wp = H // p, W // p
+    t = F.conv2d(x, sd["patch_embed.patch_embed.proj.weight"], sd["patch_embed.patch_embed.proj.bias"], stride=p)
+    t = t.flatten(2).transpose(1, 2)                                    # [N, Np, C]
+    C = t.shape[-1]
+    t = torch.cat((sd["patch_embed.cls_token"].expand(N, -1, -1), t), dim=1)
+    t = t + interpolate_pos(sd["patch_embed.pos_embed"], Hp, Wp, x.dtype)
+    t = torch.cat((t[:, :1], sd["patch_embed.register_tokens"].expand(N, -1, -1), t[:, 1:]), dim=1)
+    for i in range(dino_depth):
+        t = block(t, sd, f"patch_embed.blocks.{i}.", num_heads, None, qk_norm=False, eps=1e-6, freq=0.0)
+    return F.layer_norm(t, (C,), sd["patch_embed.norm.weight"], sd["patch_embed.norm.bias"], 1e-6)
+
+
 def aggregator(images: torch.Tensor, sd: Dict[str, torch.Tensor], *, patch_size=14, num_heads=16, depth=24,
                dino_depth=24, num_register_tokens=4, rope_freq=100.0, dtype=torch.bfloat16) -> List[torch.Tensor]:
     """images [B,S,3,H,W] in [0,1]; returns the list of per-iteration tokens [B,S,P,2C] (all iterations)."""
@@ -88,15 +109,8 @@ def aggregator(images: torch.Tensor, sd: Dict[str, torch.Tensor], *, patch_size=
     std = torch.tensor(STD).view(1, 1, 3, 1, 1).to(dtype)
     x = ((x - mean) / std).reshape(B * S, 3, H, W)
     # DINOv2 ViT with registers
-    t = F.conv2d(x, sd["patch_embed.patch_embed.proj.weight"], sd["patch_embed.patch_embed.proj.bias"], stride=p)
-    t = t.flatten(2).transpose(1, 2)                                    # [BS, Np, C]
+    t = dino_tokens(x, sd, patch_size=p, num_heads=num_heads, dino_depth=dino_depth, num_register_tokens=num_register_tokens)
     C = t.shape[-1]
-    t = torch.cat((sd["patch_embed.cls_token"].expand(B * S, -1, -1), t), dim=1)
-    t = t + interpolate_pos(sd["patch_embed.pos_embed"], Hp, Wp, dtype)
-    t = torch.cat((t[:, :1], sd["patch_embed.register_tokens"].expand(B * S, -1, -1), t[:, 1:]), dim=1)
-    for i in range(dino_depth):
-        t = block(t, sd, f"patch_embed.blocks.{i}.", num_heads, None, qk_norm=False, eps=1e-6, freq=rope_freq)
-    t = F.layer_norm(t, (C,), sd["patch_embed.norm.weight"], sd["patch_embed.norm.bias"], 1e-6)
     patch_tokens = t[:, 1 + num_register_tokens:]
     # special tokens: slot 0 for the first frame, slot 1 for the others
     def expand(tok):  # [1, 2, X, C] -> [B*S, X, C]

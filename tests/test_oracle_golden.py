@@ -168,3 +168,21 @@ def test_fp8_oracle_known_answers():
     w = torch.eye(4)[:, [1, 0, 3, 2]] * 2.0
     out = ofp8.linear(torch.arange(8.0).view(2, 4).to(torch.bfloat16), w.to(torch.bfloat16))
     assert torch.allclose(out.float(), torch.tensor([[2.0, 0.0, 6.0, 4.0], [10.0, 8.0, 14.0, 12.0]]), rtol=0.07)
+
+
+def test_vggt_dino_backbone_matches_transformers_golden():
+    """The DINOv2-with-registers stage of oracle.vggt (VGGT's `patch_embed`, one third of the aggregator's FLOPs) against
+    transformers' Dinov2WithRegistersModel on the same weights: native grid and an interpolated non-square grid.
+    (The frame/global alternating stage has no independent implementation here and stays unpinned.)"""
+    from oracle import vggt as ovg
+    z = load("dinov2_tiny.npz")
+    m = meta(z)
+    sd = {k: v.float() for k, v in weights(z).items()}
+    mean = torch.tensor(ovg.MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(ovg.STD).view(1, 3, 1, 1)
+    for name in ("native", "interp"):
+        x = (torch.from_numpy(z[f"{name}:images"]) - mean) / std
+        t = ovg.dino_tokens(x, sd, patch_size=m["patch"], num_heads=m["num_heads"], dino_depth=m["depth"],
+                            num_register_tokens=m["registers"])
+        ref = torch.from_numpy(z[f"{name}:tokens"])
+        assert t.shape == ref.shape and relerr(t, ref) < 1e-5, name

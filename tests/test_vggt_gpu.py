@@ -120,3 +120,22 @@ def test_vit_qkprep_vs_fp32_reference(monkeypatch, use_norm, use_rope):
         return t
     for got, ref in ((Q4, prep(x[0], qn)), (K4, prep(x[1], kn)), (V4, x[2])):
         assert ((got.float() - ref).norm() / ref.norm()).item() < 6e-3
+
+
+def test_dino_backbone_vs_transformers_golden():
+    """HIP DINOv2-with-registers stage (im2col + patch GEMM + position table + 2 ViT blocks + final LayerNorm) against the
+    output of transformers' Dinov2WithRegistersModel on the same weights (tests/golden/dinov2_tiny.npz): bf16 tolerance."""
+    from tests.golden_io import load, meta, weights
+    from vggt_qwen3_amd.vggt import VGGT
+    z = load("dinov2_tiny.npz")
+    m = meta(z)
+    model = VGGT(img_size=56, patch_size=m["patch"], embed_dim=m["embed_dim"], depth=1, dino_depth=m["depth"], device="cuda", seed=3)
+    agg = model.aggregator
+    missing = agg.load_named({k: v for k, v in weights(z).items()})
+    assert all(not n.startswith("patch_embed.") for n in missing), [n for n in missing if n.startswith("patch_embed.")][:4]
+    for name in ("native", "interp"):
+        images = torch.from_numpy(z[f"{name}:images"]).cuda()[:, None]          # [N, 1, 3, H, W]: one view per sample
+        got = agg.dino_tokens(images)
+        ref = torch.from_numpy(z[f"{name}:tokens"])
+        assert got.shape == ref.shape
+        assert relerr(got, ref) < 2e-2, (name, relerr(got, ref))

@@ -193,11 +193,9 @@ class Aggregator(nn.Module):
         h = ops.linear(xn2, w["fc1_w"], bias=w["fc1_b"], act=ops.ACT_GELU)
         return ops.linear(h, w["fc2_w"], bias=w["fc2_b"], colscale=w["ls2"], residual=x)
 
-    @torch.no_grad()
-    def forward(self, images: torch.Tensor, return_all: bool = False):
-        """images [B, S, 3, H, W] in [0,1] -> ([... , tokens [B, S, P, 2C]], patch_start_idx).
-        Only the last iterate is materialised unless return_all (the reference reads list[-1] only)."""
-        cc = self._prepare()
+    def _dino(self, cc, images: torch.Tensor):
+        """ImageNet normalisation + DINOv2-with-registers backbone (`patch_embed`): images [B, S, 3, H, W] in [0,1] ->
+        tokens after the final LayerNorm [B*S*P, C], rows ordered [cls | 4 registers | patches] per frame."""
         B, S, Cin, H, W = images.shape
         p, C = self.patch_size, self.embed_dim
         if Cin != 3 or H % p or W % p:
@@ -218,6 +216,27 @@ class Aggregator(nn.Module):
         for w in cc["dino"]:
             x = self._block(x, w, P, rope=None, eps=1e-6, P=P, Wp=Wp)
         x, _ = ops.layernorm_fwd(x, cc["dino_norm"][0], cc["dino_norm"][1], 1e-6)
+        return x
+
+    @torch.no_grad()
+    def dino_tokens(self, images: torch.Tensor) -> torch.Tensor:
+        """The backbone stage alone: [B, S, 3, H, W] -> [B*S, 1 + 4 + Hp*Wp, C] (what transformers'
+        Dinov2WithRegistersModel calls last_hidden_state; pinned by tests/golden/dinov2_tiny.npz)."""
+        x = self._dino(self._prepare(), images)
+        B, S = images.shape[:2]
+        return x.view(B * S, -1, self.embed_dim)
+
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, return_all: bool = False):
+        """images [B, S, 3, H, W] in [0,1] -> ([... , tokens [B, S, P, 2C]], patch_start_idx).
+        Only the last iterate is materialised unless return_all (the reference reads list[-1] only)."""
+        cc = self._prepare()
+        B, S, Cin, H, W = images.shape
+        p, C = self.patch_size, self.embed_dim
+        x = self._dino(cc, images)
+        Hp, Wp = H // p, W // p
+        P = self.patch_start_idx + Hp * Wp
+        dev = images.device
         # [camera | register | patch tokens]: frame 0 takes slot 0 of the learned tokens, the other frames slot 1
         cam, reg = self.p("camera_token").detach()[0], self.p("register_token").detach()[0]   # [2,1,C], [2,4,C]
         sp = torch.cat([cam, reg], dim=1)                                                     # [2, 5, C]
