@@ -11,8 +11,15 @@ reference's algorithm:
                 torch/nn/functional.py `multi_head_attention_forward`)
   vlm.py        /root/reference/src/models/vggt_qwen3_vlm.py:128-201 (encode_images slice, encode_geom, splice, loss)
   vggt.py       the un-vendored `vggt` package's Aggregator, restated from its published architecture
+  collate.py    /root/reference/src/dataio/collate_multiview.py:46-79 (token ids / labels / mask layout)
+  preprocess.py Pillow's two-pass bicubic resampler + torchvision's Resize/CenterCrop integer rules (collate_multiview.py:12-19)
+  generate.py   transformers' greedy generate() with RepetitionPenalty / NoRepeatNGram processors (qa_inference.py:207-216)
+  fp8.py        the e4m3 forward contract of BASELINE config C5 (no reference code exists: parity unpinned)
 
 Pinning: qwen3/perceiver/vlm are pinned by tests/golden/*.npz, generated in the build container by
 tools/make_golden.py from the reference's own modules (imported from /root/reference) and HF transformers'
-Qwen3ForCausalLM. vggt.py is PARITY UNPINNED: the reference does not vendor the package or any test vector for it.
+Qwen3ForCausalLM; collate by the reference collator's ids; preprocess by Pillow itself; generate by transformers' own
+generate() (tools/make_golden_generate.py). vggt.py: the DINOv2-with-registers stage is pinned against transformers'
+Dinov2WithRegistersModel (tools/make_golden_dinov2.py); the alternating frame/global stage is PARITY UNPINNED - the
+reference does not vendor the package or any test vector for it.
 """
