@@ -267,3 +267,27 @@ def test_native_trainer_matches_autograd_gradients():
     assert abs(loss_a.item() - loss_b.item()) < 1e-5
     cos = torch.nn.functional.cosine_similarity(da, db, dim=0).item()
     assert cos > 0.9, cos
+
+
+def test_perceiver_layer_full_width_vs_oracle():
+    """One Perceiver layer at the real width (latent 4096, 8 heads of 512, FFN 16384, 128 latents, in 2048 -> out 2560;
+    projector_perceiver.py:30-82 with configs/perceiver_small.yaml) against the CPU oracle in fp32."""
+    from oracle import perceiver as operc
+    from vggt_qwen3_amd.perceiver import PerceiverConfig, PerceiverProjector
+    torch.manual_seed(3)
+    proj = PerceiverProjector(PerceiverConfig(latent_dim=4096, num_latents=128, num_heads=8, num_layers=1, ffn_dim=16384),
+                              2048, 2560)
+    with torch.no_grad():                       # biases / norm weights away from their trivial init
+        for n, p in proj.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    sd = {k: v.detach().float().clone() for k, v in proj.state_dict().items()}
+    tokens = torch.randn(2, 128, 2048)
+    ref = operc.projector(tokens, sd, 8, 1)
+    proj.cuda()
+    out = proj(tokens.cuda())
+    assert out.shape == (2, 128, 2560)
+    e = relerr(out, ref)
+    assert e < 1e-2, f"full-width perceiver layer rel err {e}"
