@@ -2,13 +2,27 @@
 // (modeling_qwen3.py:237-238,252-253), rotate-half RoPE (modeling_qwen3.py:104-148), and the layout change
 // [B*L, heads*D] -> [B, heads, L, D] that the batched attention GEMMs consume. head_dim is 128: one wave owns one
 // head vector, lane i holds elements i and i+64 - exactly the rotate_half pair, so RoPE needs no cross-lane
-// traffic and the RMS reduction is a single wave_sum.
+// traffic and the RMS reduction is one butterfly.
 #include "common.h"
 #include "vq3_hip.h"
 
 namespace {
 
 constexpr int D = 128;
+
+// Lane layout: a HALF wave (32 lanes) owns one head; lane j holds elements 2j, 2j+1 and their rotate-half partners
+// 2j+64, 2j+65 (two 4-byte accesses), so a wave covers two heads per pass, RoPE needs no cross-lane traffic and the RMS
+// reduction is a 32-lane butterfly.
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void ld2(const bf16_t* p, float& a, float& b) {
+  const uint32_t r = *reinterpret_cast<const uint32_t*>(p);
+  a = bf2f((bf16_t)(r & 0xffff));
+  b = bf2f((bf16_t)(r >> 16));
+}
 
 __global__ __launch_bounds__(256) void qkprep_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ q_w,
                                                          const bf16_t* __restrict__ k_w, const bf16_t* __restrict__ cs,
@@ -17,40 +31,47 @@ __global__ __launch_bounds__(256) void qkprep_fwd_kernel(const bf16_t* __restric
                                                          float* __restrict__ q_rstd, float* __restrict__ k_rstd, int L,
                                                          int Hq, int Hkv, float eps) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const int e = 2 * j;                       // elements e, e+1 and e+64, e+65
   const long t = blockIdx.x;  // b*L + l
   const int b = (int)(t / L), l = (int)(t - (long)b * L);
   const int HT = Hq + 2 * Hkv;
   const bf16_t* row = qkv + t * (long)HT * D;
-  const float c1 = bf2f(cs[l * D + lane]), c2 = bf2f(cs[l * D + lane + 64]);
-  const float s1 = bf2f(sn[l * D + lane]), s2 = bf2f(sn[l * D + lane + 64]);
-  for (int h = wid; h < HT; h += 4) {
-    const float x1 = bf2f(row[h * D + lane]), x2 = bf2f(row[h * D + lane + 64]);
+  float c1a, c1b, c2a, c2b, s1a, s1b, s2a, s2b;
+  ld2(cs + l * D + e, c1a, c1b); ld2(cs + l * D + e + 64, c2a, c2b);
+  ld2(sn + l * D + e, s1a, s1b); ld2(sn + l * D + e + 64, s2a, s2b);
+  for (int h = 2 * wid + half; h < HT; h += 8) {
+    float x1a, x1b, x2a, x2b;
+    ld2(row + h * D + e, x1a, x1b);
+    ld2(row + h * D + e + 64, x2a, x2b);
     if (h >= Hq + Hkv) {  // value head: plain copy
       const int hv = h - Hq - Hkv;
       bf16_t* o = V + (((long)b * Hkv + hv) * L + l) * D;
-      o[lane] = f2bf(x1);
-      o[lane + 64] = f2bf(x2);
+      *reinterpret_cast<uint32_t*>(o + e) = pack2bf(x1a, x1b);
+      *reinterpret_cast<uint32_t*>(o + e + 64) = pack2bf(x2a, x2b);
       continue;
     }
     const bool isq = h < Hq;
     const bf16_t* w = isq ? q_w : k_w;
-    const float rs = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)D + eps);
-    const float n1 = rbf(bf2f(w[lane]) * rbf(x1 * rs));
-    const float n2 = rbf(bf2f(w[lane + 64]) * rbf(x2 * rs));
+    float w1a, w1b, w2a, w2b;
+    ld2(w + e, w1a, w1b); ld2(w + e + 64, w2a, w2b);
+    const float rs = rsqrtf(half_sum(x1a * x1a + x1b * x1b + x2a * x2a + x2b * x2b) / (float)D + eps);
+    const float n1a = rbf(w1a * rbf(x1a * rs)), n1b = rbf(w1b * rbf(x1b * rs));
+    const float n2a = rbf(w2a * rbf(x2a * rs)), n2b = rbf(w2b * rbf(x2b * rs));
     // q*cos + rotate_half(q)*sin, each product and the sum rounded to bf16 as the PyTorch bf16 ops do
-    const float o1 = rbf(rbf(n1 * c1) + rbf(-n2 * s1));
-    const float o2 = rbf(rbf(n2 * c2) + rbf(n1 * s2));
+    const float o1a = rbf(rbf(n1a * c1a) + rbf(-n2a * s1a)), o1b = rbf(rbf(n1b * c1b) + rbf(-n2b * s1b));
+    const float o2a = rbf(rbf(n2a * c2a) + rbf(n1a * s2a)), o2b = rbf(rbf(n2b * c2b) + rbf(n1b * s2b));
     bf16_t* o;
     if (isq) {
       o = Q + (((long)b * Hq + h) * L + l) * D;
-      if (q_rstd && lane == 0) q_rstd[t * Hq + h] = rs;
+      if (q_rstd && j == 0) q_rstd[t * Hq + h] = rs;
     } else {
       const int hk = h - Hq;
       o = K + (((long)b * Hkv + hk) * L + l) * D;
-      if (k_rstd && lane == 0) k_rstd[t * Hkv + hk] = rs;
+      if (k_rstd && j == 0) k_rstd[t * Hkv + hk] = rs;
     }
-    o[lane] = f2bf(o1);
-    o[lane + 64] = f2bf(o2);
+    *reinterpret_cast<uint32_t*>(o + e) = pack2bf(o1a, o1b);
+    *reinterpret_cast<uint32_t*>(o + e + 64) = pack2bf(o2a, o2b);
   }
 }
 
@@ -64,6 +85,8 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
                                                          int Hq, int Hkv) {
   __shared__ float dw_s[2][D];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const int e = 2 * j;
   if (threadIdx.x < 2 * D) (&dw_s[0][0])[threadIdx.x] = 0.f;
   __syncthreads();
   const long t = blockIdx.x;
@@ -71,36 +94,51 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
   const int HT = Hq + 2 * Hkv;
   const bf16_t* row = qkv + t * (long)HT * D;
   bf16_t* drow = dqkv + t * (long)HT * D;
-  const float c1 = bf2f(cs[l * D + lane]), c2 = bf2f(cs[l * D + lane + 64]);
-  const float s1 = bf2f(sn[l * D + lane]), s2 = bf2f(sn[l * D + lane + 64]);
-  float aq1 = 0.f, aq2 = 0.f, ak1 = 0.f, ak2 = 0.f;
-  for (int h = wid; h < HT; h += 4) {
+  float c1[2], c2[2], s1[2], s2[2];
+  ld2(cs + l * D + e, c1[0], c1[1]); ld2(cs + l * D + e + 64, c2[0], c2[1]);
+  ld2(sn + l * D + e, s1[0], s1[1]); ld2(sn + l * D + e + 64, s2[0], s2[1]);
+  float aq1[2] = {0.f, 0.f}, aq2[2] = {0.f, 0.f}, ak1[2] = {0.f, 0.f}, ak2[2] = {0.f, 0.f};
+  for (int h = 2 * wid + half; h < HT; h += 8) {
     if (h >= Hq + Hkv) {
       const int hv = h - Hq - Hkv;
       const bf16_t* g = dV + (((long)b * Hkv + hv) * L + l) * D;
-      drow[h * D + lane] = g[lane];
-      drow[h * D + lane + 64] = g[lane + 64];
+      *reinterpret_cast<uint32_t*>(drow + h * D + e) = *reinterpret_cast<const uint32_t*>(g + e);
+      *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = *reinterpret_cast<const uint32_t*>(g + e + 64);
       continue;
     }
     const bool isq = h < Hq;
     const bf16_t* g = isq ? dQ + (((long)b * Hq + h) * L + l) * D : dK + (((long)b * Hkv + (h - Hq)) * L + l) * D;
     const bf16_t* w = isq ? q_w : k_w;
     const float rs = isq ? q_rstd[t * Hq + h] : k_rstd[t * Hkv + (h - Hq)];
-    const float dy1 = bf2f(g[lane]), dy2 = bf2f(g[lane + 64]);
-    // y1 = n1*c1 - n2*s1 ; y2 = n2*c2 + n1*s2
-    const float dn1 = dy1 * c1 + dy2 * s2;
-    const float dn2 = -dy1 * s1 + dy2 * c2;
-    const float xh1 = bf2f(row[h * D + lane]) * rs, xh2 = bf2f(row[h * D + lane + 64]) * rs;
-    const float g1 = dn1 * bf2f(w[lane]), g2 = dn2 * bf2f(w[lane + 64]);
-    const float dot = wave_sum(g1 * xh1 + g2 * xh2) / (float)D;
-    drow[h * D + lane] = f2bf(rs * (g1 - xh1 * dot));
-    drow[h * D + lane + 64] = f2bf(rs * (g2 - xh2 * dot));
-    if (isq) { aq1 += dn1 * xh1; aq2 += dn2 * xh2; } else { ak1 += dn1 * xh1; ak2 += dn2 * xh2; }
+    float dy1[2], dy2[2], x1[2], x2[2], w1[2], w2[2];
+    ld2(g + e, dy1[0], dy1[1]); ld2(g + e + 64, dy2[0], dy2[1]);
+    ld2(row + h * D + e, x1[0], x1[1]); ld2(row + h * D + e + 64, x2[0], x2[1]);
+    ld2(w + e, w1[0], w1[1]); ld2(w + e + 64, w2[0], w2[1]);
+    float dn1[2], dn2[2], xh1[2], xh2[2], g1[2], g2[2], part = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      // y1 = n1*c1 - n2*s1 ; y2 = n2*c2 + n1*s2
+      dn1[u] = dy1[u] * c1[u] + dy2[u] * s2[u];
+      dn2[u] = -dy1[u] * s1[u] + dy2[u] * c2[u];
+      xh1[u] = x1[u] * rs; xh2[u] = x2[u] * rs;
+      g1[u] = dn1[u] * w1[u]; g2[u] = dn2[u] * w2[u];
+      part += g1[u] * xh1[u] + g2[u] * xh2[u];
+    }
+    const float dot = half_sum(part) / (float)D;
+    *reinterpret_cast<uint32_t*>(drow + h * D + e) = pack2bf(rs * (g1[0] - xh1[0] * dot), rs * (g1[1] - xh1[1] * dot));
+    *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = pack2bf(rs * (g2[0] - xh2[0] * dot), rs * (g2[1] - xh2[1] * dot));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (isq) { aq1[u] += dn1[u] * xh1[u]; aq2[u] += dn2[u] * xh2[u]; } else { ak1[u] += dn1[u] * xh1[u]; ak2[u] += dn2[u] * xh2[u]; }
+    }
   }
-  atomicAdd(&dw_s[0][lane], aq1);
-  atomicAdd(&dw_s[0][lane + 64], aq2);
-  atomicAdd(&dw_s[1][lane], ak1);
-  atomicAdd(&dw_s[1][lane + 64], ak2);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    atomicAdd(&dw_s[0][e + u], aq1[u]);
+    atomicAdd(&dw_s[0][e + u + 64], aq2[u]);
+    atomicAdd(&dw_s[1][e + u], ak1[u]);
+    atomicAdd(&dw_s[1][e + u + 64], ak2[u]);
+  }
   __syncthreads();
   // plain-store partial rows [token][D] (summed by vq3_colsum_f32_to_bf16): no contended global atomics
   if (threadIdx.x < D) {
