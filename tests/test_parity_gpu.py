@@ -291,3 +291,35 @@ def test_perceiver_layer_full_width_vs_oracle():
     assert out.shape == (2, 128, 2560)
     e = relerr(out, ref)
     assert e < 1e-2, f"full-width perceiver layer rel err {e}"
+
+
+def test_dgrad_transposed_copies_match_kmajor_path():
+    """With W^T copies (Stage1Trainer enables them when grad_accum >= 4) the three dgrad GEMMs run in NT form: same
+    gradients as the k-major path to bf16 rounding, and the copies follow every weight update."""
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z = load("vlm_tiny.npz")
+    m = meta(z)
+    geom = {k: torch.from_numpy(z["geom:" + k]).cuda() for k in ("R", "t", "K", "depth_hist")}
+    batch = {"pixel_values": torch.from_numpy(z["pixel_values"].astype(np.float32)).cuda(), "geom_token": geom,
+             "input_ids": torch.from_numpy(z["input_ids"]).cuda(), "attention_mask": torch.from_numpy(z["attention_mask"]).cuda(),
+             "labels": torch.from_numpy(z["labels"]).cuda()}
+    grads = {}
+    for on in (False, True):
+        model = _build_vlm(z, m).train()
+        tm = model.text_model
+        tm.enable_dgrad_transposes(on)
+        st = model.forward_state(batch["pixel_values"], geom, batch["input_ids"], batch["attention_mask"], batch["labels"], True)
+        model._backward_text(st, 1.0, accumulate=False)
+        grads[on] = tm.flat_g.float().clone()
+    assert relerr(grads[True], grads[False]) < 2e-2
+    cos = torch.nn.functional.cosine_similarity(grads[True], grads[False], dim=0).item()
+    assert cos > 0.9995, cos
+    model = _build_vlm(z, m).train()
+    tr = Stage1Trainer(model, lr=1e-3, proj_lr=1e-3, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=4)
+    tm = model.text_model
+    assert tm._wt is not None and set(k.split(".")[1] for k in tm._wt) == {"qkv", "o", "gu"}
+    for _ in range(4):
+        tr.micro_step(batch)
+    assert tr.opt_step == 1
+    for name, wt in tm._wt.items():
+        assert torch.equal(wt, tm._w[name].t().contiguous()), name          # refreshed after the optimiser step

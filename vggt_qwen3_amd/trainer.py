@@ -11,6 +11,7 @@ stepped once per optimiser step, loss/grad_accum scaling, and `max_steps` counti
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -43,6 +44,9 @@ class Stage1Trainer:
         self.pg = process_group
         self.dist_on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.dist_on else 1
+        # W^T copies for three dgrad GEMMs cost one 2.7 ms refresh per optimiser step: on when that is amortised
+        if grad_accum >= 4 and os.environ.get("VQ3_DGRAD_NT", "1") != "0":
+            self.tm.enable_dgrad_transposes(True)
         self.micro = 0       # micro-batches seen (the reference's `step`)
         self.opt_step = 0    # optimiser / scheduler steps
         dev = self.tm.flat_w.device
@@ -119,7 +123,7 @@ class Stage1Trainer:
         gscale = 1.0 / self.world
         ops.adamw_step(self.master, self.m, self.v, tm.flat_g, tm.flat_w, self.lr * mult, self.betas[0], self.betas[1],
                        self.eps, self.wd, self.opt_step, gscale)
-        tm.requantize_fp8()      # no-op unless the fp8 forward is enabled
+        tm.refresh_derived()     # e4m3 / W^T copies of the weights (no-ops unless enabled)
         if self._geom_has_grad:
             ops.adamw_step(self.geom_master, self.geom_m, self.geom_v, ops.cast(self.geom_grad, BF16), self.geom_w16,
                            self.proj_lr * mult, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step, gscale)
