@@ -184,37 +184,62 @@ __global__ __launch_bounds__(256) void embed_splice_fwd_kernel(const int64_t* __
 }
 
 // Backward into the (tied) embedding table gradient. `order` is the argsort of ids over all B*L positions and
-// sorted_ids the sorted values: the block whose position starts a run of equal ids sums the run and adds it to the
+// sorted_ids the sorted values: the blocks whose position starts a run of equal ids sum the run and add it to the
 // bf16 gradient row once (no atomics, deterministic). Positions that were overwritten by the splice are skipped.
+// grid (T, ceil(H / 512)): a block owns 512 columns of one run; its four waves take the run's rows in interleaved
+// batches of 16 (all 16 row loads in flight; the padding id's run is ~1000 rows long) and meet in LDS.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ sorted_ids,
                                                         const int64_t* __restrict__ order,
                                                         const int32_t* __restrict__ srcmap,
                                                         const bf16_t* __restrict__ dout, bf16_t* __restrict__ dtable,
                                                         int T, int H) {
+  __shared__ float part[4][64][8];
+  __shared__ int any_s[4];
   const int i = blockIdx.x;
   const int64_t id = sorted_ids[i];
   if (i > 0 && sorted_ids[i - 1] == id) return;
-  int end = i + 1;
-  while (end < T && sorted_ids[end] == id) ++end;
-  for (int c = threadIdx.x * 8; c < H; c += 2048) {
-    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool any = false;
-    for (int k = i; k < end; ++k) {
-      const long t = order[k];
-      if (srcmap[t] >= 0) continue;
-      any = true;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dout + t * (long)H + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] += bf2f((bf16_t)v[j]);
-    }
-    if (!any) continue;
-    bf16_t* d = dtable + id * (long)H + c;
-    const bf16x8 o = *reinterpret_cast<const bf16x8*>(d);
-    bf16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(a[j] + bf2f((bf16_t)o[j]));
-    *reinterpret_cast<bf16x8*>(d) = r;
+  int lo = i + 1, hi = T;                       // first index > i whose id differs (sorted: binary search)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sorted_ids[mid] == id) lo = mid + 1; else hi = mid;
   }
+  const int end = lo;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.y * 512 + lane * 8;
+  const bool cin = c < H;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool any = false;
+  for (int k0 = i + wid * 16; k0 < end; k0 += 64) {
+    long t[16];
+    bool use[16];
+    bf16x8 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = order[k0 + u < end ? k0 + u : end - 1];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) use[u] = (k0 + u < end) && srcmap[t[u]] < 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = cin ? *reinterpret_cast<const bf16x8*>(dout + t[u] * (long)H + c) : bf16x8{};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (use[u]) {
+        any = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += bf2f((bf16_t)v[u][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[wid][lane][j] = a[j];
+  if (lane == 0) any_s[wid] = any ? 1 : 0;      // `any` is wave-uniform (it depends on the rows, not on the lane)
+  __syncthreads();
+  if (wid != 0 || !cin || !(any_s[0] | any_s[1] | any_s[2] | any_s[3])) return;
+  bf16_t* d = dtable + id * (long)H + c;
+  const bf16x8 o = *reinterpret_cast<const bf16x8*>(d);
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    r[j] = (short)f2bf(((part[0][lane][j] + part[1][lane][j]) + (part[2][lane][j] + part[3][lane][j])) + bf2f((bf16_t)o[j]));
+  *reinterpret_cast<bf16x8*>(d) = r;
 }
 // dfeat_f32[b, s, :] += dout[b, l, :] where srcmap[b,l] == s
 __global__ __launch_bounds__(256) void splice_bwd_kernel(const int32_t* __restrict__ srcmap,
@@ -276,24 +301,44 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------- cross entropy (one block per row)
-__global__ __launch_bounds__(256) void cross_entropy_kernel(bf16_t* __restrict__ logits, const int32_t* __restrict__ tgt,
-                                                            float* __restrict__ loss_sum, int V, int ldl, float gscale) {
-  __shared__ float red[4];
+// 1024 threads, 16-byte accesses: a 152k-entry row is 19 vector loads per thread and pass (three passes: max, sum of
+// exponentials, gradient written in place). Rows start 16-byte aligned (ldl % 8 == 0, checked on the host).
+__global__ __launch_bounds__(1024) void cross_entropy_kernel(bf16_t* __restrict__ logits, const int32_t* __restrict__ tgt,
+                                                             float* __restrict__ loss_sum, int V, int ldl, float gscale) {
+  __shared__ float red[16];
   bf16_t* lr = logits + (long)blockIdx.x * ldl;
   const int t = tgt[blockIdx.x];
+  const int nv = ldl / 8;
   float mx = -INFINITY;
-  for (int j = threadIdx.x; j < V; j += 256) mx = fmaxf(mx, bf2f(lr[j]));
-  mx = block_max<4>(mx, red);
+  for (int c = threadIdx.x; c < nv; c += 1024) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c * 8 + j < V) mx = fmaxf(mx, bf2f((bf16_t)v[j]));
+  }
+  mx = block_max<16>(mx, red);
   float sum = 0.f;
-  for (int j = threadIdx.x; j < V; j += 256) sum += __expf(bf2f(lr[j]) - mx);
-  sum = block_sum<4>(sum, red);
+  for (int c = threadIdx.x; c < nv; c += 1024) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c * 8 + j < V) sum += __expf(bf2f((bf16_t)v[j]) - mx);
+  }
+  sum = block_sum<16>(sum, red);
   const float lse = mx + __logf(sum);
   if (threadIdx.x == 0) atomicAdd(loss_sum, lse - bf2f(lr[t]));
-  __syncthreads();  // everyone has read lr[t]-independent data; target logit read above by thread 0 before rewrite
-  for (int j = threadIdx.x; j < ldl; j += 256) {
-    float g = 0.f;
-    if (j < V) g = (__expf(bf2f(lr[j]) - lse) - (j == t ? 1.f : 0.f)) * gscale;
-    lr[j] = f2bf(g);
+  __syncthreads();  // the target logit has been read before any thread rewrites the row
+  for (int c = threadIdx.x; c < nv; c += 1024) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + c * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = c * 8 + j;
+      float g = 0.f;
+      if (col < V) g = (__expf(bf2f((bf16_t)v[j]) - lse) - (col == t ? 1.f : 0.f)) * gscale;
+      o[j] = (short)f2bf(g);
+    }
+    *reinterpret_cast<bf16x8*>(lr + c * 8) = o;
   }
 }
 
@@ -426,7 +471,7 @@ extern "C" int vq3_embed_splice_bwd(const int64_t* sorted_ids, const int64_t* or
   VQ3_CHECK_ARG(sorted_ids && order && srcmap && dout, "embed_splice_bwd: null pointer");
   VQ3_CHECK_ARG(B > 0 && L > 0 && H > 0 && H % 8 == 0, "embed_splice_bwd: bad shape");
   if (dtable_bf16) {
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, sorted_ids, order, srcmap,
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * L, (H + 511) / 512), dim3(256), 0, (hipStream_t)stream, sorted_ids, order, srcmap,
                        (const bf16_t*)dout, (bf16_t*)dtable_bf16, B * L, H);
     VQ3_CHECK_LAUNCH("embed_bwd");
   }
@@ -461,7 +506,8 @@ extern "C" int vq3_softmax_bwd(const void* P, const float* dP, void* dS, int32_t
 extern "C" int vq3_cross_entropy_fwd_bwd(void* logits, const int32_t* targets, float* loss_sum_f32, int32_t n,
                                          int32_t V, int32_t ldl, float gscale, void* stream) {
   VQ3_CHECK_ARG(logits && targets && loss_sum_f32 && n > 0 && V > 0 && ldl >= V, "cross_entropy: bad args");
-  hipLaunchKernelGGL(cross_entropy_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (bf16_t*)logits, targets,
+  VQ3_CHECK_ARG(ldl % 8 == 0 && (uintptr_t)logits % 16 == 0, "cross_entropy: rows must be 16-byte aligned (ldl %% 8 == 0)");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, (bf16_t*)logits, targets,
                      loss_sum_f32, V, ldl, gscale);
   VQ3_CHECK_LAUNCH("cross_entropy");
   return 0;
