@@ -69,14 +69,23 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     const float rs = rstd[row];
     const bf16_t* xr = x + row * (long)cols;
     const bf16_t* gr = dy + row * (long)cols;
-    bf16x8 xv[NCH], gv[NCH];
+    bf16x8 xv[NCH], gv[NCH], rv[NCH];
+    const bf16_t* rr_ = dres ? dres + row * (long)cols : nullptr;
     float dot = 0.f;
+    // all three row operands are requested up front: the residual-gradient read otherwise waits behind the row reduction
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int c = lane * 8 + ch * 512;
       if (c < cols) {
         xv[ch] = *reinterpret_cast<const bf16x8*>(xr + c);
         gv[ch] = *reinterpret_cast<const bf16x8*>(gr + c);
+        if (rr_) rv[ch] = *reinterpret_cast<const bf16x8*>(rr_ + c);
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = lane * 8 + ch * 512;
+      if (c < cols) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = bf2f((bf16_t)xv[ch][j]) * rs;
@@ -87,21 +96,18 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
       }
     }
     dot = wave_sum(dot) / (float)cols;
-    const bf16_t* rr_ = dres ? dres + row * (long)cols : nullptr;
     bf16_t* dxr = dx + row * (long)cols;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int c = lane * 8 + ch * 512;
       if (c < cols) {
-        bf16x8 rv;
-        if (rr_) rv = *reinterpret_cast<const bf16x8*>(rr_ + c);
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = bf2f((bf16_t)xv[ch][j]) * rs;
           const float g = bf2f((bf16_t)gv[ch][j]) * bf2f((bf16_t)wv[ch][j]);
           float d = rs * (g - xh * dot);
-          if (rr_) d += bf2f((bf16_t)rv[j]);
+          if (rr_) d += bf2f((bf16_t)rv[ch][j]);
           o[j] = (short)f2bf(d);
         }
         *reinterpret_cast<bf16x8*>(dxr + c) = o;
