@@ -208,3 +208,37 @@ def test_collate_size_rules_and_plan_cpu():
     assert collate.axis_plan(640, 448)[1] is b                                              # cached
     rows = collate._max_src_rows(b, collate.crop_offset(448, 448), 448, 16)
     assert rows == int(max(b[min(y + 15, 447), 0] + b[min(y + 15, 447), 1] - b[y, 0] for y in range(0, 448, 16)))
+
+
+def test_bench_synthetic_batch_follows_survey_layout():
+    """bench.py's synthetic Stage-1 batch: [question tokens, "\\n", <image>, "\\n", answer tokens, pad...] to
+    L = 200, labels only on the answer, attention_mask = ids != pad, pixel values in [0, 1), one <image> per row, the 128-token
+    visual span fits, and the FLOP model reproduces the survey's per-sample figures."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("vq3_bench_cpu", Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    B, V, L, img, vocab, image_id, pad, nl = 6, 2, 200, 28, 151936, 151936, 151643, 198
+    b = bench.synthetic_batch(B, V, L, img, vocab, image_id, pad, nl, 1234, torch.device("cpu"), True)
+    ids, lab, mask = b["input_ids"], b["labels"], b["attention_mask"]
+    assert ids.shape == (B, L) and ids.dtype == torch.int64 and b["pixel_values"].shape == (B, V, 3, img, img)
+    assert 0.0 <= float(b["pixel_values"].min()) and float(b["pixel_values"].max()) < 1.0
+    assert torch.equal(mask, (ids != pad).long())
+    for r in range(B):
+        pos = (ids[r] == image_id).nonzero().flatten()
+        assert pos.numel() == 1 and ids[r, pos - 1] == nl and ids[r, pos + 1] == nl and 6 <= int(pos) - 1 <= 40
+        assert int(pos) + 136 <= L                                           # visual + geometry span fits (no overrun)
+        n = int(mask[r].sum())
+        ans = (lab[r] != -100).nonzero().flatten()
+        assert 1 <= ans.numel() <= 4 and int(ans[0]) == int(pos) + 2 and int(ans[-1]) == n - 1
+        assert torch.equal(lab[r, ans], ids[r, ans]) and (ids[r, n:] == pad).all()
+    g = b["geom_token"]
+    assert g["R"].shape == (B, V, 9) and g["t"].shape == (B, V, 3) and g["K"].shape == (B, V, 9) and g["depth_hist"].shape == (B, V, 16)
+    assert torch.allclose(g["depth_hist"].sum(-1), torch.ones(B, V), atol=1e-5) and (g["depth_hist"] >= 0).all()
+    # SURVEY 8(a)/(d): 2.18 TF VGGT fwd (V=1, 448 px), 0.316 TF Perceiver fwd, 1.621 TF Qwen3 fwd at L=200 -> 7.36 TF train
+    assert abs(bench.flops_vggt(1, 448) / 1e12 - 2.18) < 0.03
+    assert abs(bench.flops_perceiver() / 1e12 - 0.316) < 0.005
+    assert abs(bench.flops_qwen(200) / 1e12 - 1.621) < 0.01
+    assert abs((bench.flops_vggt(1, 448) + bench.flops_perceiver() + 3 * bench.flops_qwen(200)) / 1e12 - 7.36) < 0.05
+    assert abs(bench.flops_vggt(8, 448) / 1e12 - 23.25) < 0.3
