@@ -293,6 +293,11 @@ int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* 
                        const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t B, int32_t L, int32_t Hq,
                        int32_t Hkv, int32_t head_dim, int64_t ldo, int64_t lddo, float scale, void* stream);
 
+/* Workspace for the opt-in stream-K GEMM variant (VQ3_GEMM_STREAMK=1; csrc/gemm5.hip): `bytes` of ZERO-INITIALISED device
+ * memory that stays valid until replaced, >= n_cu * (64 KiB + 32 B) + 4 KiB. The first stream that launches an eligible
+ * GEMM becomes the only stream allowed to use it. NULL disables the variant. */
+int vq3_gemm_set_workspace(void* ptr, int64_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,6 +269,18 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3)");
     return 0;
   }
+  {
+    // stream-K for the under-filled single-round shapes (gemm5.hip): opt-in, needs vq3_gemm_set_workspace()
+    static int skmode = -1;
+    if (skmode < 0) {
+      const char* e = getenv("VQ3_GEMM_STREAMK");
+      skmode = e ? atoi(e) : 0;
+    }
+    if (skmode == 1 && nbatch == 1 && !d->out_f32 && launch_gemm_streamk(p, ncu, s) == 0) {
+      VQ3_CHECK_LAUNCH("gemm_bf16_nt(stream-K)");
+      return 0;
+    }
+  }
   const int cfg = choose_config(d->M, d->N, d->K, nbatch);
   if (cfg >= 0) {
     const int rc = launch_gemm_v2(p, cfg, nbatch, s);

@@ -226,6 +226,7 @@ inline int choose_xm(int mtiles, int ntiles) {
 }
 
 // v2 (LDS-DMA pipelined) launcher, defined in gemm2.hip. cfg: 0 = 256x128 tile, 1 = 128x256, 2 = 128x128.
+int launch_gemm_streamk(GemmParams& p, int ncu, hipStream_t stream);   // gemm5.hip; 0 = launched, 1 = not applicable
 int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream);
 // v4 (persistent producer/consumer, any layout), defined in gemm4.hip. ncu = workgroups to launch (one per CU).
 int launch_gemm_v4(GemmParams& p, int transA, int transB, int nbatch, int ncu, hipStream_t stream);

@@ -500,3 +500,19 @@ def skinny_linear_fp8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, re
     check(_lib.load().vq3_skinny_gemm_fp8(x.data_ptr(), wq.data_ptr(), ws.data_ptr(), out.data_ptr(), _p(residual), _p(ln_w),
                                           eps, xmode, M, N, K, x.shape[1], K, N, N, _stream()), "vq3_skinny_gemm_fp8")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- stream-K workspace (opt-in)
+_STREAMK_WS = None
+
+
+def enable_streamk(n_cu: int = 256) -> None:
+    """Hand the library the zeroed workspace its opt-in stream-K GEMM needs (VQ3_GEMM_STREAMK=1 selects the variant)."""
+    global _STREAMK_WS
+    if _STREAMK_WS is None:
+        _STREAMK_WS = torch.zeros(n_cu * (128 * 128 + 8) + 2048, device="cuda", dtype=F32)
+    check(_lib.load().vq3_gemm_set_workspace(_STREAMK_WS.data_ptr(), _STREAMK_WS.numel() * 4), "vq3_gemm_set_workspace")
+
+
+def disable_streamk() -> None:
+    check(_lib.load().vq3_gemm_set_workspace(None, 0), "vq3_gemm_set_workspace")
