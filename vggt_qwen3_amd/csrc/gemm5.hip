@@ -3,13 +3,15 @@
 // for 256 CUs (78 %). OPT-IN (VQ3_GEMM_STREAMK=1): a new synchronisation structure wants a long race screen before it
 // may carry the headline path.
 //
-// G persistent workgroups (one per CU) share the K steps of all tiles evenly: workgroup w owns the contiguous run
-// [U*w/G, U*(w+1)/G) of the U = tiles * nk (tile-major) K steps - at most one piece that does not start a tile, then
-// whole tiles, then at most one unfinished head. A piece that does not start its tile is computed FIRST and left as an
-// f32 partial in the workgroup's workspace slot, each compute wave releasing its own flag (epoch value, so nothing is
-// ever reset). The workgroup that owns the tile's head reaches it LAST, acquires the following workgroups' flags wave
-// by wave, adds their partials and runs the normal epilogue: no atomics on C, no cross-wave barrier in the fix-up, and
-// no circular wait (a piece that is waited for never waits itself), so residency of all G workgroups is not required.
+// Decomposition (K kept aligned): with T tiles and G = #CUs workgroups, workgroup w < T owns tile w and computes its first
+// ka = nk * T / G K steps - all tile owners walk K in lock step, so the A / W panels they share are reused out of L2 exactly
+// as in the per-tile kernel; the G - T helper workgroups compute the remaining nk - ka steps of T / (G - T) tiles each (the
+// same amount of work) and hand every tail over as an f32 partial in the tile's workspace slot, each compute wave
+// releasing its own flag (epoch value, so nothing is ever reset). The owner acquires wave by wave, adds and runs the
+// normal epilogue: no atomics on C, no cross-wave barrier in the fix-up, and no circular wait (helpers never wait), so
+// residency of all G workgroups is not required. (First form tried: contiguous runs of the tile-major K-step sequence per
+// workgroup - correct, but workgroups starting mid-tile walk K out of step, the L2 reuse is lost and it ran 1.4-1.8x
+// slower than the per-tile kernel.)
 #include "gemm_common.h"
 #include "vq3_hip.h"
 
@@ -30,6 +32,7 @@ struct SkArgs {
   float* ws;          // [G][BM*BN] f32 partials
   int* flags;         // [G][NW] epoch flags
   int epoch;
+  int ka_permille;    // owner's share of K in 1/1000 (0 = balanced T/G)
 };
 
 __global__ __launch_bounds__(64 * (NW + NLOAD), (NW + NLOAD + 3) / 4) void gemm_sk_kernel(GemmParams p, SkArgs sk) {
@@ -41,8 +44,13 @@ __global__ __launch_bounds__(64 * (NW + NLOAD), (NW + NLOAD + 3) / 4) void gemm_
   const int wm = (wid % NW) / WN, wn = wid % WN;
   const int nk = p.K / BK;
   const int G = gridDim.x, w = blockIdx.x;    // (giving each XCD one contiguous stretch of the sequence measured slower)
-  const long U = (long)p.mtiles * p.ntiles * nk;
-  const long u_begin = U * w / G, u_end = U * (w + 1) / G;
+  const int T = p.mtiles * p.ntiles;                     // T < G (launcher)
+  const int Hn = G - T;
+  int ka = sk.ka_permille > 0 ? (int)((long)nk * sk.ka_permille / 1000) : (int)(((long)nk * T + G / 2) / G);
+  ka = ka < 1 ? 1 : (ka > nk - 1 ? nk - 1 : ka);
+  const bool owner = w < T;
+  const int t_first = owner ? w : (int)((long)T * (w - T) / Hn);
+  const int t_last = owner ? w + 1 : (int)((long)T * (w - T + 1) / Hn);
   const int fr = lane & 15, fq = lane >> 4;
 
   int a_off[TM], b_off[TN];
@@ -57,14 +65,11 @@ __global__ __launch_bounds__(64 * (NW + NLOAD), (NW + NLOAD + 3) / 4) void gemm_
     b_off[j] = BM * 128 + row * 128 + ((fq ^ (row & 7)) << 4);
   }
 
-  for (long u = u_begin; u < u_end;) {
-    const int tile = (int)(u / nk);
-    const int k0 = (int)(u - (long)tile * nk);
-    const long rest = u_end - u;
-    const int k1 = (int)((long)(nk - k0) < rest ? nk : k0 + rest);
+  for (int tile = t_first; tile < t_last; ++tile) {
+    const int k0 = owner ? 0 : ka, k1 = owner ? ka : nk;
     const int nt = k1 - k0, last = nt - 1;
-    const int m0 = (tile % p.mtiles) * BM, n0 = (tile / p.mtiles) * BN;     // m fastest: neighbours share the W panel
-    u += nt;
+    int m0, n0;                       // tile id = its owner's block id: the per-tile kernels' XCD-aware order applies as is
+    tile_coords_id(p, tile, BM, BN, m0, n0);
 
     if (loader) {
       const int prow = lane >> 3;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64 * (NW + NLOAD), (NW + NLOAD + 3) / 4) void gemm_
       // same wave id / lane of another workgroup, so both sides move 16 contiguous bytes per lane.
       // Payload goes out WRITE-THROUGH (sc0 sc1: past this XCD's L2), the wave drains its own stores, then signals with a
       // relaxed agent-scope store - no release fence (a fence here writes back the whole L2: measured 150 us per launch).
-      float* slot = sk.ws + (long)w * WS_FLOATS + ((long)wid * TM * TN * 64 + lane) * 4;
+      float* slot = sk.ws + (long)tile * WS_FLOATS + ((long)wid * TM * TN * 64 + lane) * 4;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -154,28 +159,22 @@ __global__ __launch_bounds__(64 * (NW + NLOAD), (NW + NLOAD + 3) / 4) void gemm_
           asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(acc[i][j]) : "memory");
         }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(sk.flags + (long)w * NW + wid, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(sk.flags + (long)tile * NW + wid, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       continue;
     }
-    if (k1 < nk) {
-      // head of a tile that continues in the following workgroups: they computed their share first
-      const long tile_end = (long)(tile + 1) * nk;
-      for (int w2 = w + 1; w2 < G; ++w2) {
-        const long b2 = U * w2 / G, e2 = U * (w2 + 1) / G;
-        if (b2 >= tile_end) break;
-        if (e2 == b2) continue;
-        const int* f = sk.flags + (long)w2 * NW + wid;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(4);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ONE invalidate after the match, then plain loads
-        const float* slot = sk.ws + (long)w2 * WS_FLOATS + ((long)wid * TM * TN * 64 + lane) * 4;
+    {
+      // the tile's tail comes from a helper workgroup, which has nothing else to wait for
+      const int* f = sk.flags + (long)tile * NW + wid;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ONE invalidate after the match, then plain loads
+      const float* slot = sk.ws + (long)tile * WS_FLOATS + ((long)wid * TM * TN * 64 + lane) * 4;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(slot + (long)(i * TN + j) * 256);
-            acc[i][j] += v;
-          }
-      }
+        for (int j = 0; j < TN; ++j) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(slot + (long)(i * TN + j) * 256);
+          acc[i][j] += v;
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -208,14 +207,21 @@ int launch_gemm_streamk(GemmParams& p, int ncu, hipStream_t stream) {
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = (p.N + BN - 1) / BN;
   const long tiles = (long)p.mtiles * p.ntiles;
+  p.xm = choose_xm(p.mtiles, p.ntiles);
   const int G = ncu;
-  if (tiles >= G || tiles * 4 < G || (long)G * (WS_FLOATS + NW) > g_ws_floats) return 1;   // only the under-filled single-round case
+  // only the under-filled single-round case, with enough K per piece to amortise a pipeline fill
+  if (tiles * 10 < (long)G * 6 || tiles * 10 > (long)G * 9 || p.K / BK < 16 || (long)G * (WS_FLOATS + NW) > g_ws_floats) return 1;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)gemm_sk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
     attr_done = true;
   }
-  SkArgs sk{g_ws, g_flags, ++g_epoch};
+  static int ka_pm = -1;
+  if (ka_pm < 0) {
+    const char* e = getenv("VQ3_STREAMK_KA");     // owner's share of K in 1/1000; helpers pay a pipeline fill per tail
+    ka_pm = e ? atoi(e) : 0;
+  }
+  SkArgs sk{g_ws, g_flags, ++g_epoch, ka_pm};
   hipLaunchKernelGGL(gemm_sk_kernel, dim3(G), dim3(64 * (NW + NLOAD)), SMEM, stream, p, sk);
   return 0;
 }
