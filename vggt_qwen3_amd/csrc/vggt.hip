@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256) void vit_qkprep4_kernel(const bf16_t* __restri
 // Block = 4 waves x 32 query rows; KV tile = 64 keys. LDS: K tile [64][64] and V^T tile [64][64], 16-byte chunks
 // XOR-swizzled with (row >> 1) & 7 so the fragment reads (lane = row) are conflict-free / 2-way.
 constexpr int FA_KV = 64;
+#ifndef VQ3_FA_DIAG
+#define VQ3_FA_DIAG 0   // counters-only builds: 1 = no V^T reads, 2 = no K reads, 3 = no tile stores (outputs are then wrong)
+#endif
 
 __device__ __forceinline__ int fa_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * FA_KV * 128];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
+  const unsigned fa_lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the tiles
   const long nb = blockIdx.y;
   const int q0 = blockIdx.x * (128 * QB) + wid * (32 * QB);
   const bf16_t* Qb = Q + nb * (long)N * 64;
@@ -247,7 +251,10 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
     for (int i = 0; i < 2; ++i) {
       const int row = srow0 + 32 * i;
       *reinterpret_cast<u32x4*>(Ks + fa_swz(row, sch)) = kreg[i];
-      *reinterpret_cast<u32x4*>(Vs + fa_swz(row, sch)) = vreg[i];
+      // V^T is read back 8 bytes per lane by 32-lane groups on 64 banks: rows r and r+16 share a 16-byte slot (the chunk
+      // swizzle has 8 positions), so rows with bit 4 set keep their two 8-byte halves swapped and a group covers all banks
+      const u32x4 vv = (row & 16) ? u32x4{vreg[i][2], vreg[i][3], vreg[i][0], vreg[i][1]} : vreg[i];
+      *reinterpret_cast<u32x4*>(Vs + fa_swz(row, sch)) = vv;
     }
   };
   // lane-constant LDS offsets of the fragment reads (relative to the stage base)
@@ -263,8 +270,9 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
     const int kb = 16 * u + 4 * h;
 #pragma unroll
     for (int run = 0; run < 2; ++run) {
-      voffa[u][run] = FA_KV * 128 + fa_swz(r, (kb + 8 * run) >> 3) + ((kb & 7) << 1);
-      voffb[u][run] = FA_KV * 128 + fa_swz(32 + r, (kb + 8 * run) >> 3) + ((kb & 7) << 1);
+      const int hv = ((kb & 7) << 1) ^ (((r >> 4) & 1) << 3);   // 8-byte half, swapped for rows with bit 4 set (store_tile)
+      voffa[u][run] = FA_KV * 128 + fa_swz(r, (kb + 8 * run) >> 3) + hv;
+      voffb[u][run] = FA_KV * 128 + fa_swz(32 + r, (kb + 8 * run) >> 3) + hv;
     }
   }
 
@@ -284,8 +292,8 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
       for (int i = 0; i < 16; ++i) { s0[qb][i] = 0.f; s1[qb][i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sb + koff0[s]);
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sb + koff1[s]);
+      const bf16x8 k0 = VQ3_FA_DIAG == 2 ? qf[0][s] : *reinterpret_cast<const bf16x8*>(sb + koff0[s]);
+      const bf16x8 k1 = VQ3_FA_DIAG == 2 ? qf[0][s] : *reinterpret_cast<const bf16x8*>(sb + koff1[s]);
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         s0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[qb][s], s0[qb], 0, 0, 0);
@@ -326,10 +334,21 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
     // ---- O^T += V^T . P^T : B operand = packed S^T registers 8s'..8s'+7 (k order: 16s' + 8(j>>2) + 4h + (j&3))
 #pragma unroll
     for (int u = 0; u < 4; ++u) {   // u = sub*2 + sp
-      const u32x2 a0 = *reinterpret_cast<const u32x2*>(sb + voffa[u][0]);
-      const u32x2 a1 = *reinterpret_cast<const u32x2*>(sb + voffa[u][1]);
-      const u32x2 b0 = *reinterpret_cast<const u32x2*>(sb + voffb[u][0]);
-      const u32x2 b1 = *reinterpret_cast<const u32x2*>(sb + voffb[u][1]);
+      // Plain ds_read_b64 through inline asm: left to the compiler, the a/b reads (4 KiB apart) are merged into
+      // ds_read2st64_b64, which is serviced on 32 banks in 16-lane groups at half the rate and made rows r, r+1 collide
+      // (counters: every conflict cycle of this kernel, 32 % of its LDS time). The asm reads are waited for by hand.
+      u32x2 a0, a1, b0, b1;
+      if (VQ3_FA_DIAG == 1) {
+        a0 = a1 = b0 = b1 = u32x2{(unsigned)u, (unsigned)lane};
+      } else {
+        const unsigned sbase = (unsigned)(size_t)(sb - smem) + fa_lds_base;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(a0) : "v"(sbase + voffa[u][0]) : "memory");
+        asm volatile("ds_read_b64 %0, %1" : "=v"(a1) : "v"(sbase + voffa[u][1]) : "memory");
+        asm volatile("ds_read_b64 %0, %1" : "=v"(b0) : "v"(sbase + voffb[u][0]) : "memory");
+        asm volatile("ds_read_b64 %0, %1" : "=v"(b1) : "v"(sbase + voffb[u][1]) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const u32x4 ta = {a0[0], a0[1], a1[0], a1[1]};
       const u32x4 tb = {b0[0], b0[1], b1[0], b1[1]};
 #pragma unroll
@@ -341,7 +360,7 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
         o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1[qb], 0, 0, 0);
       }
     }
-    if (more) store_tile((t + 1) & 1);
+    if (more && VQ3_FA_DIAG != 3) store_tile((t + 1) & 1);
     __syncthreads();
   }
 
