@@ -180,12 +180,24 @@ int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* qn_b, const 
 int vq3_flash_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int32_t G, int32_t NH, int32_t N,
                        int32_t Np, int32_t head_dim, int64_t ldo, float scale, void* stream);
 
+/* Inverted dropout in place (the four nn.Dropout sites of a PerceiverLayer, src/models/projector_perceiver.py:33,37,42,46-49,
+ * which stay ACTIVE under `model.train()` although encode_images runs under no_grad): element i is zeroed with probability p,
+ * else scaled by 1/(1-p); the decision is a counter-based hash of (seed, offset + i). x is bf16, or f32 when is_f32. */
+int vq3_dropout(void* x, int32_t is_f32, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Optimiser (src/train/train_sft.py:147-156 torch.optim.AdamW; DeepSpeed bf16 keeps f32 master weights)
  * ---------------------------------------------------------------------------------------------------------- */
-/* master/m/v f32, grad bf16, w_bf16 (compute copy) updated in place. step >= 1. grad is scaled by gscale first. */
+/* master/m/v f32, grad bf16, w_bf16 (compute copy) updated in place. step >= 1. grad is scaled by gscale first.
+ * clip_sumsq (device f32[1], may be NULL): global-norm gradient clipping as the reference's default launch applies it
+ * (configs/deepspeed_zero3.json:15 "gradient_clipping": 1.0; formula of torch.nn.utils.clip_grad_norm_): the scaled
+ * gradient is further multiplied by min(1, max_norm / (sqrt(*clip_sumsq) * gscale + 1e-6)). */
 int vq3_adamw_step(float* master, float* m, float* v, const void* grad_bf16, void* w_bf16, int64_t n, float lr,
-                   float beta1, float beta2, float eps, float weight_decay, int32_t step, float gscale, void* stream);
+                   float beta1, float beta2, float eps, float weight_decay, int32_t step, float gscale,
+                   const float* clip_sumsq, float max_norm, void* stream);
+/* accum[0] += sum_i x[i]^2 over n elements (x bf16, or f32 when is_f32). Deterministic: <= 1024 per-block partials are written
+ * to `partials` (scratch, >= 1024 floats) and added in a fixed order by a second one-block kernel. */
+int vq3_sumsq(const void* x, int32_t is_f32, int64_t n, float* partials, float* accum, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Batch builder: the collator step right before the model (src/dataio/collate_multiview.py)
@@ -293,10 +305,10 @@ int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* 
                        const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t B, int32_t L, int32_t Hq,
                        int32_t Hkv, int32_t head_dim, int64_t ldo, int64_t lddo, float scale, void* stream);
 
-/* Workspace for the opt-in stream-K GEMM variant (VQ3_GEMM_STREAMK=1; csrc/gemm5.hip): `bytes` of ZERO-INITIALISED device
- * memory that stays valid until replaced, >= n_cu * (64 KiB + 32 B) + 4 KiB. The first stream that launches an eligible
- * GEMM becomes the only stream allowed to use it. NULL disables the variant. */
-int vq3_gemm_set_workspace(void* ptr, int64_t bytes);
+/* Benchmarking / test hook for vq3_gemm_bf16_nt's kernel choice on NT, K % 64 == 0 shapes: cfg = -3 restores the automatic
+ * choice (the default), -1 the register-staged reference kernel, 0..14 a gemm2.hip tile configuration, 20 the 256x256
+ * 8-phase kernel (gemm6.hip). Process-wide; not meant for concurrent use with launches on other threads. */
+int vq3_gemm_force_config(int32_t cfg);
 
 #ifdef __cplusplus
 }

@@ -88,7 +88,8 @@ def test_trainer_resume(tmp_path):
     z = load("vlm_tiny.npz")
     m = meta(z)
     b = _batch(z)
-    kw = dict(lr=1e-3, proj_lr=1e-3, weight_decay=0.1, warmup_ratio=0.1, max_steps=20, grad_accum=2)
+    # eps well above the bf16 noise of the gradients, so that the two runs' updates can be compared element by element
+    kw = dict(lr=1e-3, proj_lr=1e-3, weight_decay=0.1, warmup_ratio=0.1, max_steps=20, grad_accum=2, eps=1e-3)
     a = _build_vlm(z, m).train()
     ta = Stage1Trainer(a, **kw)
     for _ in range(4):
@@ -111,8 +112,9 @@ def test_trainer_resume(tmp_path):
     da = ta.master - snap["master"]
     dc = tc.master - snap["master"]
     assert da.abs().max() > 0
-    cos = torch.nn.functional.cosine_similarity(da, dc, dim=0).item()
-    assert cos > 0.99, cos
+    assert ((da - dc).norm() / da.norm()).item() < 2e-2
+    ga, gc = a.text_model.flat_g.float(), c.text_model.flat_g.float()
+    assert ((ga - gc).norm() / ga.norm()).item() < 2e-2
     assert tc.lrs() == ta.lrs()
     # mid-window state refuses to load
     ta.micro_step(b)
@@ -194,3 +196,62 @@ def test_trainer_fit_loop_like_train_sft(tmp_path):
     fresh = _build_vlm(z, m)
     assert load_checkpoint_if_available(fresh, str(tmp_path / "run"), verbose=False) is not None
     assert torch.equal(fresh.text_model.flat_w, model.text_model.flat_w)
+
+
+def test_upstream_named_vision_checkpoint_key_space(tmp_path):
+    """`vision_model.*` lives in the upstream key space (vggt_qwen3_vlm.py:87-101, qa_inference.py:84,103):
+    (1) `_load_vggt` reads a `vggt_1B_commercial.pt`-shaped file (aggregator.* under a "model" wrapper, head tensors ignored);
+    (2) state_dict() emits `vision_model.aggregator.<upstream dotted name>`; (3) a reference-written full checkpoint loads
+    those tensors through load_checkpoint_if_available and through load_state_dict(strict=False) - none lands in `unexpected`;
+    (4) save_model(include_vision=True) writes names the reference can read; (5) the loaded weights are the ones the tower
+    computes with (the fp32 compute copies are rebuilt)."""
+    from tests.golden_io import GOLDEN
+    from vggt_qwen3_amd.checkpoint import load_checkpoint_if_available, save_model
+    from vggt_qwen3_amd.perceiver import PerceiverConfig
+    from vggt_qwen3_amd.qwen3 import Qwen3Config
+    from vggt_qwen3_amd.vggt import VGGT
+    from vggt_qwen3_amd.vlm import VGGTQwen3VLM, VisionLanguageConfig
+    vkw = dict(img_size=56, depth=1, embed_dim=128, dino_depth=1)
+    donor = VGGT(patch_size=14, device="cuda", seed=123, **vkw)
+    g = torch.Generator().manual_seed(1)
+    upstream = {}
+    for n, t in donor.aggregator.named_tensors().items():
+        upstream["aggregator." + n] = (torch.randn(t.shape, generator=g) * 0.05).float()
+    upstream["camera_head.trunk.0.weight"] = torch.zeros(4, 4)          # heads exist upstream, never used by the reference
+    ck = tmp_path / "vggt"
+    ck.mkdir()
+    torch.save({"model": upstream}, ck / "vggt_1B_commercial.pt")
+    qcfg = Qwen3Config(hidden_size=256, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1, head_dim=128,
+                       intermediate_size=256, vocab_size=300)
+    pcfg = PerceiverConfig(latent_dim=128, num_latents=16, num_heads=2, num_layers=1, ffn_dim=256)
+
+    def build(ckpt_dir, seed):
+        return VGGTQwen3VLM(VisionLanguageConfig(text_model_name=str(GOLDEN / "tiny_tokenizer"), vision_ckpt_dir=str(ckpt_dir),
+                                                 num_vis_tokens=16, geom_tokens=0, projector_cfg=pcfg, text_config=qcfg,
+                                                 vision_config=vkw, seed=seed))
+    a = build(ck, 0)                                                    # (1) the reference's own vision-weight route
+    agg = a.vision_model.aggregator
+    for n in ("patch_embed.blocks.0.attn.qkv.weight", "frame_blocks.0.attn.q_norm.bias", "camera_token"):
+        assert torch.equal(agg.p(n).cpu(), upstream["aggregator." + n].to(torch.bfloat16)), n
+    sd = a.state_dict()                                                 # (2)
+    vkeys = [k for k in sd if k.startswith("vision_model.")]
+    assert vkeys and all("__" not in k for k in vkeys)
+    assert set(vkeys) == {"vision_model." + k for k in upstream if k.startswith("aggregator.")}
+    images = torch.rand(1, 2, 3, 56, 56, generator=g).cuda()
+    out_a = agg(images)[0][-1].float().clone()
+    save_model(a, tmp_path / "full", include_vision=True)               # (4)
+    shard = torch.load(next((tmp_path / "full" / "pytorch_model_fp32").glob("*.bin")), map_location="cpu")
+    assert "vision_model.aggregator.patch_embed.blocks.0.attn.qkv.weight" in shard
+    b = build(tmp_path / "none", 5)                                     # (3) different random vision weights
+    assert not torch.equal(b.vision_model.aggregator.p("camera_token"), agg.p("camera_token"))
+    _ = b.vision_model.aggregator(images)                               # builds b's compute copies from the OLD weights
+    rep = load_checkpoint_if_available(b, str(tmp_path / "full"), verbose=False)
+    assert rep is not None and not rep["unexpected"], rep["unexpected"][:4]
+    assert not [k for k in rep["missing"] if k.startswith("vision_model.")]
+    out_b = b.vision_model.aggregator(images)[0][-1].float()
+    assert torch.equal(out_a, out_b)                                    # (5)
+    c = build(tmp_path / "none", 6)
+    _ = c.vision_model.aggregator(images)
+    inc = c.load_state_dict({k: v for k, v in shard.items()}, strict=False)
+    assert not inc.unexpected_keys
+    assert torch.equal(c.vision_model.aggregator(images)[0][-1].float(), out_a)

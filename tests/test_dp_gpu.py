@@ -1,0 +1,118 @@
+"""The REAL data-parallel path with more than one rank: two processes drive Stage1Trainer.micro_step itself (forward, HIP
+backward with the bucket hooks, all-reduce from inside the backward, clipping, fused AdamW) on the one GPU of the box,
+exchanging gradients over gloo (RCCL refuses two ranks on one device; dp.allreduce_tensor stages through the host for gloo).
+Reference behaviour being matched: src/train/train_sft.py:208-220 under DDP - every rank runs its own micro-batches, the
+gradients are averaged over ranks once per accumulation window, every rank applies the same update.
+
+Checked: both ranks end with bit-identical weights; they equal a single-process run over the concatenated micro-batch
+sequence (grad_accum x world) to bf16-accumulation tolerance; the bucket hook fires exactly once per bucket and only on the
+boundary micro-batch; geom_head gradients are reduced; a rank whose micro-batch has no labelled token issues the same
+collectives as the others (no hang) and contributes zero."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.golden_io import load, meta
+
+pytestmark = pytest.mark.gpu
+KW = dict(lr=2e-3, proj_lr=2e-3, weight_decay=0.1, warmup_ratio=0.0, max_steps=50, bucket_layers=1, max_grad_norm=1.0,
+          accelerate_scheduler_rule=False, eps=1e-3)   # eps >> bf16 noise of the gradients: updates comparable element-wise
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batches(z, rank):
+    """Four micro-batches per rank; they differ between ranks (labels), and each rank has one WITHOUT any label: rank 1 on
+    the boundary micro-batch of window 1, rank 0 on the first micro-batch of window 2."""
+    geom = {k: torch.from_numpy(z["geom:" + k]).cuda() for k in ("R", "t", "K", "depth_hist")}
+    base = {"pixel_values": torch.from_numpy(z["pixel_values"].astype(np.float32)).cuda(), "geom_token": geom,
+            "input_ids": torch.from_numpy(z["input_ids"]).cuda(), "attention_mask": torch.from_numpy(z["attention_mask"]).cuda(),
+            "labels": torch.from_numpy(z["labels"]).cuda()}
+    out = []
+    for mi in range(4):
+        lab = base["labels"].clone()
+        rows = lab.shape[0]
+        lab[(rank + mi) % rows] = -100                          # drop one row's labels: different gradients per rank / step
+        if (rank, mi) in ((1, 1), (0, 2)):
+            lab[:] = -100
+        out.append(dict(base, labels=lab))
+    return out
+
+
+def _worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.test_parity_gpu import _build_vlm
+        from vggt_qwen3_amd import dp
+        from vggt_qwen3_amd.trainer import Stage1Trainer
+        z = load("vlm_tiny.npz")
+        model = _build_vlm(z, meta(z)).train()
+        tr = Stage1Trainer(model, grad_accum=2, **KW)
+        assert tr.dist_on and tr.world == 2 and len(tr.buckets) == model.text_model.config.num_hidden_layers
+        fired, spans = [], []
+        orig_done, orig_ar = tr._layer_done, dp.allreduce_tensor
+        tr._layer_done = lambda i: (fired.append((tr.micro, i)), orig_done(i))[1]
+        dp.allreduce_tensor = lambda t, group=None: (spans.append((tr.micro, t.numel())), orig_ar(t, group=group))[1]
+        losses = []
+        for b in _batches(z, rank):
+            losses.append(float(tr.micro_step(b).item()))
+        torch.cuda.synchronize()
+        torch.save({"master": tr.master.cpu(), "geom_master": tr.geom_master.cpu(), "flat_w": model.text_model.flat_w.cpu(),
+                    "fired": fired, "spans": spans, "losses": losses, "opt_step": tr.opt_step,
+                    "nbuckets": len(tr.buckets), "geom_n": tr.geom_grad.numel()}, os.path.join(outdir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stage1_trainer_two_ranks_equal_single_rank(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=False) for i in range(world)]
+    # identical replicas after two optimiser steps
+    assert r[0]["opt_step"] == r[1]["opt_step"] == 2
+    assert torch.equal(r[0]["master"], r[1]["master"]) and torch.equal(r[0]["flat_w"], r[1]["flat_w"])
+    assert torch.equal(r[0]["geom_master"], r[1]["geom_master"])
+    for i in range(world):
+        nb = r[i]["nbuckets"]
+        # hooks: only on the boundary micro-batches (micro index 1 and 3), once per layer each (bucket_layers = 1)
+        assert sorted(r[i]["fired"]) == sorted([(m, l) for m in (1, 3) for l in range(nb)]), (i, r[i]["fired"])
+        # collectives per optimiser step: one per layer bucket + embedding + geom_head (+count slot), same on both ranks
+        per_step = [s for s in r[i]["spans"] if s[0] == 1]
+        assert len(per_step) == nb + 2 and any(n == r[i]["geom_n"] for _, n in per_step), per_step
+    assert [s[1] for s in r[0]["spans"]] == [s[1] for s in r[1]["spans"]]
+    assert np.isnan(r[1]["losses"][1]) and np.isnan(r[0]["losses"][2]) and np.isfinite(r[0]["losses"][0])
+
+    # single process, same micro-batches in rank-interleaved order, grad_accum x world
+    from tests.test_parity_gpu import _build_vlm
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z = load("vlm_tiny.npz")
+    model = _build_vlm(z, meta(z)).train()
+    tr = Stage1Trainer(model, grad_accum=4, **KW)
+    w0, g0 = tr.master.clone(), tr.geom_master.clone()
+    b0, b1 = _batches(z, 0), _batches(z, 1)
+    for mi in range(4):
+        tr.micro_step(b0[mi])
+        tr.micro_step(b1[mi])
+    assert tr.opt_step == 2
+    d_single = (tr.master - w0).cpu()
+    d_dp = r[0]["master"] - w0.cpu()
+    assert d_dp.abs().max() > 0
+    e = ((d_dp - d_single).norm() / d_single.norm()).item()
+    assert e < 5e-2, f"two-rank update differs from the single-rank update: rel err {e}"
+    dg_single = (tr.geom_master - g0).cpu()
+    dg_dp = r[0]["geom_master"] - g0.cpu()
+    assert dg_dp.abs().max() > 0                                # geom_head gradients were reduced and applied
+    assert ((dg_dp - dg_single).norm() / dg_single.norm()).item() < 5e-2

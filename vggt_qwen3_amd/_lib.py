@@ -61,7 +61,9 @@ SIGNATURES = {
     "vq3_im2col_norm": [c_p, c_p, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), c_p],
     "vq3_vit_qkprep": [c_p] * 10 + [i64, i32, i32, i32, i32, i32, i32, i32, i32, f32, c_p],
     "vq3_flash_attn_fwd": [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i64, f32, c_p],
-    "vq3_adamw_step": [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p],
+    "vq3_adamw_step": [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p, f32, c_p],
+    "vq3_sumsq": [c_p, i32, i64, c_p, c_p, c_p],
+    "vq3_dropout": [c_p, i32, i64, f32, C.c_uint64, C.c_uint64, c_p],
     "vq3_resample_ksize": [i32, i32],
     "vq3_resample_plan": [i32, i32, c_p, c_p],
     "vq3_resize_crop_u8": [c_p, i32, c_p, c_p, c_p, i32, i32, i32, c_p],
@@ -75,7 +77,7 @@ SIGNATURES = {
     "vq3_gemm_fp8_nt": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i64, i64, c_p],
     "vq3_qwen_flash_fwd": [c_p] * 6 + [i32, i32, i32, i32, i32, i64, f32, c_p],
     "vq3_qwen_flash_bwd": [c_p] * 11 + [i32, i32, i32, i32, i32, i64, i64, f32, c_p],
-    "vq3_gemm_set_workspace": [c_p, i64],
+    "vq3_gemm_force_config": [i32],
     "vq3_pack_tokens": [c_p, c_p, c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p, c_p],
 }
 _RESTYPES = {"vq3_last_error": C.c_char_p, "vq3_target_arch": C.c_char_p}

@@ -78,7 +78,27 @@ def load_state_into(model, state: Dict[str, torch.Tensor]) -> Tuple[List[str], L
                                    f"the shape in current model is {tuple(dst.shape)}")
             dst.copy_(v.to(device=dst.device, dtype=dst.dtype, non_blocking=False))
             matched.append(k)
+    refresh_after_weight_load(model)
     return matched, unexpected
+
+
+def refresh_after_weight_load(model) -> None:
+    """Everything derived FROM the weights must follow a load that bypasses nn.Module.load_state_dict's post-hooks: the
+    text model's e4m3 / W^T copies, the projector's and the aggregator's compute copies, and the fp32 master weights of
+    any Stage1Trainer built on this model (otherwise its next AdamW step would write the pre-load weights back)."""
+    tm = getattr(model, "text_model", None)
+    if tm is not None and hasattr(tm, "refresh_derived"):
+        tm.refresh_derived()
+    proj = getattr(model, "projector", None)
+    if proj is not None and hasattr(proj, "_cc"):
+        proj._cc = None
+    agg = getattr(getattr(model, "vision_model", None), "aggregator", None)
+    if agg is not None and hasattr(agg, "invalidate_compute_copies"):
+        agg.invalidate_compute_copies()
+    for ref in list(getattr(model, "_trainers", [])):
+        tr = ref()
+        if tr is not None:
+            tr.resync_master_from_weights()
 
 
 def _read_file(path: Path) -> Dict[str, torch.Tensor]:
@@ -161,6 +181,7 @@ def load_trainer_state(trainer, ckpt_dir) -> None:
         getattr(trainer, name).copy_(st[name])
     from . import ops
     trainer.tm.flat_w.copy_(ops.cast(trainer.master, torch.bfloat16))
+    trainer.tm.refresh_derived()      # e4m3 / W^T copies follow the restored weights (they were built at construction)
     off = 0
     with torch.no_grad():
         for p in trainer.geom_params:

@@ -346,7 +346,12 @@ __global__ __launch_bounds__(1024) void cross_entropy_kernel(bf16_t* __restrict_
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m,
                                                     float* __restrict__ v, const bf16_t* __restrict__ grad,
                                                     bf16_t* __restrict__ w, long n, float lr, float b1, float b2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                                                    const float* __restrict__ clip_sumsq, float max_norm) {
+  if (clip_sumsq) {   // global-norm clipping: coefficient from the device-side squared norm (same value in every thread)
+    const float total = sqrtf(*clip_sumsq) * gscale;
+    gscale *= fminf(1.f, max_norm / (total + 1e-6f));
+  }
   const long n4 = n / 4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     f32x4 p = *reinterpret_cast<const f32x4*>(master + i * 4);
@@ -379,6 +384,66 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
       master[i] = p; m[i] = mi; v[i] = vi; w[i] = f2bf(p);
     }
   }
+}
+
+// inverted dropout in place: element i is kept with probability 1 - p (and scaled by 1 / (1 - p)), decided by a counter-based
+// hash of (seed, offset + i) - stateless, so a graph replay or a re-run with the same (seed, offset) repeats the mask
+__device__ __forceinline__ unsigned drop_bits(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned)((z ^ (z >> 31)) >> 40);      // 24 uniform bits
+}
+template <bool F32IO>
+__global__ __launch_bounds__(256) void dropout_kernel(void* __restrict__ xv, long n, unsigned thresh, float scale,
+                                                      unsigned long long seed, unsigned long long offset) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const bool keep = drop_bits(seed, offset + (unsigned long long)i) >= thresh;
+    if (F32IO) {
+      float* x = reinterpret_cast<float*>(xv);
+      x[i] = keep ? x[i] * scale : 0.f;
+    } else {
+      bf16_t* x = reinterpret_cast<bf16_t*>(xv);
+      x[i] = keep ? f2bf(bf2f(x[i]) * scale) : (bf16_t)0;
+    }
+  }
+}
+
+// sum of squares, stage 1: one partial per block (fixed grid => fixed summation order)
+template <bool F32IN>
+__global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ xv, long n, float* __restrict__ partials) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  if (F32IN) {
+    const float* x = reinterpret_cast<const float*>(xv);
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+      acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+      for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) acc += x[i] * x[i];
+  } else {
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(xv);
+    const long n8 = n / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = bf2f((bf16_t)v[j]); acc += f * f; }
+    }
+    if (blockIdx.x == 0)
+      for (long i = n8 * 8 + threadIdx.x; i < n; i += 256) { const float f = bf2f(x[i]); acc += f * f; }
+  }
+  const float t = block_sum<4>(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+// stage 2: one block adds the partials in a fixed tree order
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partials, int nb, float* __restrict__ accum) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += partials[i];
+  const float t = block_sum<4>(acc, red);
+  if (threadIdx.x == 0) accum[0] += t;
 }
 
 }  // namespace
@@ -515,16 +580,47 @@ extern "C" int vq3_cross_entropy_fwd_bwd(void* logits, const int32_t* targets, f
 
 extern "C" int vq3_adamw_step(float* master, float* m, float* v, const void* grad_bf16, void* w_bf16, int64_t n,
                               float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
-                              float gscale, void* stream) {
+                              float gscale, const float* clip_sumsq, float max_norm, void* stream) {
   VQ3_CHECK_ARG(master && m && v && grad_bf16 && w_bf16 && n > 0 && step >= 1, "adamw: bad args");
   VQ3_CHECK_ARG(((uintptr_t)master % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
                     ((uintptr_t)grad_bf16 % 8 == 0) && ((uintptr_t)w_bf16 % 8 == 0),
                 "adamw: buffers must be 16-byte (f32) / 8-byte (bf16) aligned");
+  VQ3_CHECK_ARG(!clip_sumsq || max_norm > 0.f, "adamw: clipping needs max_norm > 0");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, master, m, v,
                      (const bf16_t*)grad_bf16, (bf16_t*)w_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
-                     gscale);
+                     gscale, clip_sumsq, max_norm);
   VQ3_CHECK_LAUNCH("adamw");
+  return 0;
+}
+
+extern "C" int vq3_sumsq(const void* x, int32_t is_f32, int64_t n, float* partials, float* accum, void* stream) {
+  VQ3_CHECK_ARG(x && partials && accum && n > 0, "sumsq: bad args");
+  VQ3_CHECK_ARG((uintptr_t)x % 16 == 0, "sumsq: x must be 16-byte aligned");
+  const long vec = is_f32 ? n / 4 : n / 8;
+  long nb = (vec + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+  if (is_f32)
+    hipLaunchKernelGGL(sumsq_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long)n, partials);
+  else
+    hipLaunchKernelGGL(sumsq_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long)n, partials);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, (int)nb, accum);
+  VQ3_CHECK_LAUNCH("sumsq");
+  return 0;
+}
+
+extern "C" int vq3_dropout(void* x, int32_t is_f32, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+  VQ3_CHECK_ARG(x && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args (0 <= p < 1)");
+  if (p == 0.f) return 0;
+  const unsigned thresh = (unsigned)(p * 16777216.0f);
+  const float scale = 1.f / (1.f - p);
+  if (is_f32)
+    hipLaunchKernelGGL(dropout_kernel<true>, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n, thresh,
+                       scale, (unsigned long long)seed, (unsigned long long)offset);
+  else
+    hipLaunchKernelGGL(dropout_kernel<false>, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n, thresh,
+                       scale, (unsigned long long)seed, (unsigned long long)offset);
+  VQ3_CHECK_LAUNCH("dropout");
   return 0;
 }

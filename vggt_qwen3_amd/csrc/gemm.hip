@@ -155,13 +155,14 @@ bool g_attr_set = false;
 // VQ3_GEMM_CFG overrides (benchmarking; -1 = v1 register-staged kernel).
 double fill(long tiles, long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); }
 
+int g_forced_cfg = -2;   // -2 = read VQ3_GEMM_CFG on first use, -3 = automatic, >= -1 = forced
+
 int choose_config(int M, int N, int K, int nbatch) {
-  static int forced = -2;
-  if (forced == -2) {
+  if (g_forced_cfg == -2) {
     const char* e = getenv("VQ3_GEMM_CFG");
-    forced = e ? atoi(e) : -3;
+    g_forced_cfg = e ? atoi(e) : -3;
   }
-  if (forced >= -1) return forced;
+  if (g_forced_cfg >= -1) return g_forced_cfg;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
   const long t256 = (long)((M + 255) / 256) * ((N + 127) / 128) * nbatch;
   const bool shortk = K <= 1536;
@@ -239,49 +240,19 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3 split-K)");
     return 0;
   }
-  static int v4mode = -1, ncu = 0;
-  if (v4mode < 0) {
-    const char* e = getenv("VQ3_GEMM_V4");
-    v4mode = e ? atoi(e) : 0;  // opt-in: measured slower than the per-tile loader kernels
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-  }
-  {
-    // persistent producer/consumer kernel (gemm4.hip): mode 1 = wherever the 4-stage loader ring would be chosen,
-    // mode 2 = every 128x128-tile GEMM, 0 = never
-    const bool v3case = d->transA || d->transB || d->K % BK != 0;
-    bool use4 = false;
-    if (v4mode == 2) use4 = true;
-    else if (v4mode == 1) use4 = v3case ? choose_v3_stages(d->M, d->N, d->K, nbatch) == 3
-                                        : (getenv("VQ3_GEMM_CFG") == nullptr && choose_config(d->M, d->N, d->K, nbatch) == 13);
-    if (use4) {
-      const int rc = launch_gemm_v4(p, d->transA, d->transB, nbatch, ncu, s);
-      if (rc) return rc;
-      VQ3_CHECK_LAUNCH("gemm_bf16_nt(v4)");
-      return 0;
-    }
-  }
   if (d->transA || d->transB || d->K % BK != 0) {
     const int rc = launch_gemm_v3(p, d->transA, d->transB, choose_v3_stages(d->M, d->N, d->K, nbatch), nbatch, s);
     if (rc) return rc;
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3)");
     return 0;
   }
-  {
-    // stream-K for the under-filled single-round shapes (gemm5.hip): opt-in, needs vq3_gemm_set_workspace()
-    static int skmode = -1;
-    if (skmode < 0) {
-      const char* e = getenv("VQ3_GEMM_STREAMK");
-      skmode = e ? atoi(e) : 0;
-    }
-    if (skmode == 1 && nbatch == 1 && !d->out_f32 && launch_gemm_streamk(p, ncu, s) == 0) {
-      VQ3_CHECK_LAUNCH("gemm_bf16_nt(stream-K)");
-      return 0;
-    }
-  }
   const int cfg = choose_config(d->M, d->N, d->K, nbatch);
+  if (cfg == 20) {
+    const int rc = launch_gemm_v6(p, nbatch, s);
+    if (rc) return rc;
+    VQ3_CHECK_LAUNCH("gemm_bf16_nt(v6)");
+    return 0;
+  }
   if (cfg >= 0) {
     const int rc = launch_gemm_v2(p, cfg, nbatch, s);
     if (rc) return rc;
@@ -307,5 +278,11 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   else
     hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), SMEM_BYTES, s, p);
   VQ3_CHECK_LAUNCH("gemm_bf16_nt");
+  return 0;
+}
+
+extern "C" int vq3_gemm_force_config(int32_t cfg) {
+  VQ3_CHECK_ARG(cfg >= -3 && cfg <= 64 && cfg != -2, "gemm_force_config: cfg %d out of range", cfg);
+  g_forced_cfg = cfg;
   return 0;
 }

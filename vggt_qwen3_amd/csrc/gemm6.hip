@@ -1,0 +1,227 @@
+// GEMM v6 for gfx950: 256x256x64 tile, 8 waves (2 x 4), the 8-phase schedule of the CDNA4 guide (two K tiles per
+// iteration, four phases per K tile), LDS-DMA staging with a counted vmcnt, two wave groups staggered by one barrier.
+//
+// Same contract as the other NT kernels (C = epilogue(alpha * A[M,K] . B[N,K]^T), bf16 in, f32 MFMA accumulate,
+// K % 64 == 0). What is different is the schedule of the main loop:
+//
+//   * LDS = 2 buffers x {A0, A1, B0, B1} half-tiles of 128 rows x 64 k (16 KiB each, 128 KiB in all). Half-tile Xh
+//     holds tile rows h*128 .. h*128+127; inside it wave row wr owns rows wr*64..+63 (A) and wave column wc owns rows
+//     wc*32..+31 (B): a wave's 128 x 64 output is the four quadrants (i, j) = (A half, B half) of 64 x 32, and every
+//     half-tile is read in exactly one phase of the K tile:
+//         phase 1: read A0, B0   -> MFMA quadrant (0,0)        stage A1 of tile t+1
+//         phase 2: read B1       -> MFMA quadrant (0,1)        stage A0 of tile t+2   (A0 was last read in phase 1)
+//         phase 3: read A1       -> MFMA quadrant (1,1)        stage B0 of tile t+2
+//         phase 4: (B0 kept)     -> MFMA quadrant (1,0)        stage B1 of tile t+2, s_waitcnt vmcnt(6)
+//     so a slot is restaged one phase after its last read and three half-tiles stay in flight across every barrier.
+//   * A phase is  { ds_reads ; 2 x global_load_lds ; lgkmcnt(0) ; s_barrier ; 16 MFMA ; s_barrier }. Waves 4-7 run one
+//     barrier behind waves 0-3, so in every barrier interval one wave of each SIMD is in its MFMA segment and the
+//     other in its load segment. The reads are retired BEFORE the phase's first barrier: a slot restaged in phase p+1
+//     by either group is then free for both (the lagging group's reads of phase p finished before the barrier the
+//     leading group passes on its way into phase p+1).
+//   * RAW: the vmcnt(6) of phase 4 sits before that phase's first barrier and retires every half-tile of tile t+1; tile
+//     t+1 is first read in the next phase, i.e. after a barrier every issuing wave reached after its wait.
+#include "gemm_common.h"
+
+namespace vq3gemm {
+namespace {
+
+constexpr int BM6 = 256, BN6 = 256, BK6 = 64;
+constexpr int HALF = 128 * 128;          // bytes per half-tile
+constexpr int BUF = 4 * HALF;            // A0 A1 B0 B1
+constexpr int SMEM6 = 2 * BUF;
+
+#define V6_FENCE() asm volatile("" ::: "memory")
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  int m0, n0;
+  tile_coords(p, BM6, BN6, m0, n0);
+  const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
+  const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
+  const bf16_t* B = p.B + b1 * p.sB1 + (long)(b2 / p.b2divB) * p.sB2;
+  const long coff = b1 * p.sC1 + b2 * p.sC2;
+  const long roff = b1 * p.sR1 + b2 * p.sR2;
+
+  // ---- DMA sources. A half-tile is 16 pieces of 8 rows x 128 B; wave w issues pieces w and w + 8. Lane l of a piece
+  // reads k-chunk (l & 7) ^ (l >> 3) of row l >> 3 (the read-side swizzle chunk ^ (row & 7), applied to the source).
+  const int prow = lane >> 3;
+  const int kch = (lane & 7) ^ prow;
+  unsigned offA[2][2], offB[2][2];     // byte offsets from A / B, [half][piece]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = h * 128 + (wid + 8 * j) * 8 + prow;
+      int ra = m0 + r; ra = ra < p.M ? ra : p.M - 1;
+      int rb = n0 + r; rb = rb < p.N ? rb : p.N - 1;
+      offA[h][j] = (unsigned)(((long)ra * p.lda + kch * 8) * 2);
+      offB[h][j] = (unsigned)(((long)rb * p.ldb + kch * 8) * 2);
+    }
+  auto stage = [&](const bf16_t* base, const unsigned (&off)[2], int tile, char* slot) {
+    const char* g = reinterpret_cast<const char*>(base) + (long)tile * (BK6 * 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off[j]),
+                                       (__attribute__((address_space(3))) void*)(slot + (wid + 8 * j) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int a_base = (wr * 64 + fr) * 128 + ((fq ^ (fr & 7)) << 4);
+  const int b_base = (wc * 32 + fr) * 128 + ((fq ^ (fr & 7)) << 4);
+
+  bf16x8 xa[4][2], wb0[2][2], wb1[2][2];
+  auto read_a = [&](const char* slot) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) xa[mt][kh] = *reinterpret_cast<const bf16x8*>(slot + ((a_base ^ (kh << 6)) + mt * 2048));
+  };
+  auto read_b = [&](const char* slot, bf16x8 (&wb)[2][2]) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) wb[nt][kh] = *reinterpret_cast<const bf16x8*>(slot + ((b_base ^ (kh << 6)) + nt * 2048));
+  };
+#define V6_MMA(I, J, WB)                                                                                         \
+  do {                                                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                           \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
+          acc[(I) * 4 + mt][(J) * 2 + nt] =                                                                      \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[nt][kh], xa[mt][kh], acc[(I) * 4 + mt][(J) * 2 + nt], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+  } while (0)
+  // first barrier of a phase: this wave's LDS reads are retired, then everybody meets
+#define V6_SYNC_A()                                     \
+  do {                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_s_barrier();                       \
+    V6_FENCE();                                         \
+    __builtin_amdgcn_sched_barrier(0);                  \
+  } while (0)
+#define V6_SYNC_B()                     \
+  do {                                  \
+    V6_FENCE();                         \
+    __builtin_amdgcn_s_barrier();       \
+    V6_FENCE();                         \
+    __builtin_amdgcn_sched_barrier(0);  \
+  } while (0)
+
+  const int nt = p.K / BK6;
+  // ---- prologue: all of tile 0, then A0 B0 B1 of tile 1
+  stage(A, offA[0], 0, smem + 0 * HALF);
+  stage(B, offB[0], 0, smem + 2 * HALF);
+  stage(B, offB[1], 0, smem + 3 * HALF);
+  stage(A, offA[1], 0, smem + 1 * HALF);
+  if (nt > 1) {
+    stage(A, offA[0], 1, smem + BUF + 0 * HALF);
+    stage(B, offB[0], 1, smem + BUF + 2 * HALF);
+    stage(B, offB[1], 1, smem + BUF + 3 * HALF);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  V6_FENCE();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr == 1) {   // waves 4-7 run one barrier behind
+    __builtin_amdgcn_s_barrier();
+    V6_FENCE();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  auto ktile = [&](int t, char* cur, char* nxt) {
+    const bool s1 = t + 1 < nt, s2 = t + 2 < nt;
+    // phase 1
+    read_b(cur + 2 * HALF, wb0);
+    read_a(cur + 0 * HALF);
+    if (s1) stage(A, offA[1], t + 1, nxt + 1 * HALF);
+    V6_SYNC_A();
+    V6_MMA(0, 0, wb0);
+    V6_SYNC_B();
+    // phase 2
+    read_b(cur + 3 * HALF, wb1);
+    if (s2) stage(A, offA[0], t + 2, cur + 0 * HALF);
+    V6_SYNC_A();
+    V6_MMA(0, 1, wb1);
+    V6_SYNC_B();
+    // phase 3
+    read_a(cur + 1 * HALF);
+    if (s2) stage(B, offB[0], t + 2, cur + 2 * HALF);
+    V6_SYNC_A();
+    V6_MMA(1, 1, wb1);
+    V6_SYNC_B();
+    // phase 4
+    if (s2) {
+      stage(B, offB[1], t + 2, cur + 3 * HALF);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    V6_SYNC_A();
+    V6_MMA(1, 0, wb0);
+    V6_SYNC_B();
+  };
+  for (int t = 0; t < nt; t += 2) {
+    ktile(t, smem, smem + BUF);
+    if (t + 1 < nt) ktile(t + 1, smem + BUF, smem);
+  }
+  if (wr == 0) {   // balance the stagger barrier
+    __builtin_amdgcn_s_barrier();
+    V6_FENCE();
+  }
+
+  // ---- epilogue: lane owns C[m][n..n+3]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + i * 128 + wr * 64 + mt * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int nt2 = 0; nt2 < 2; ++nt2) {
+          const int n = n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq;
+          if (n >= p.N) continue;
+          store_quad<OUT_F32>(p, coff, roff, m, n, acc[i * 4 + mt][j * 2 + nt2]);
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gemm_v6(GemmParams& p, int nbatch, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM6);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM6);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      vq3_set_error("gemm v6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      return 2;
+    }
+    attr_done = true;
+  }
+  p.mtiles = (p.M + BM6 - 1) / BM6;
+  p.ntiles = (p.N + BN6 - 1) / BN6;
+  p.xm = choose_xm(p.mtiles, p.ntiles);
+  dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
+  if (p.out_f32)
+    hipLaunchKernelGGL((gemm_v6_kernel<true>), grid, dim3(512), SMEM6, stream, p);
+  else
+    hipLaunchKernelGGL((gemm_v6_kernel<false>), grid, dim3(512), SMEM6, stream, p);
+  return 0;
+}
+
+}  // namespace vq3gemm

@@ -226,10 +226,9 @@ inline int choose_xm(int mtiles, int ntiles) {
 }
 
 // v2 (LDS-DMA pipelined) launcher, defined in gemm2.hip. cfg: 0 = 256x128 tile, 1 = 128x256, 2 = 128x128.
-int launch_gemm_streamk(GemmParams& p, int ncu, hipStream_t stream);   // gemm5.hip; 0 = launched, 1 = not applicable
 int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream);
-// v4 (persistent producer/consumer, any layout), defined in gemm4.hip. ncu = workgroups to launch (one per CU).
-int launch_gemm_v4(GemmParams& p, int transA, int transB, int nbatch, int ncu, hipStream_t stream);
+// v6 (256x256 tile, 8-phase schedule, NT, K % 64 == 0), defined in gemm6.hip.
+int launch_gemm_v6(GemmParams& p, int nbatch, hipStream_t stream);
 // v3 (any operand layout, K % 8 == 0), defined in gemm3.hip. nstage: 2 or 3.
 int launch_gemm_v3(GemmParams& p, int transA, int transB, int nstage, int nbatch, hipStream_t stream);
 

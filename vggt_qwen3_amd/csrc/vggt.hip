@@ -342,11 +342,12 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
         a0 = a1 = b0 = b1 = u32x2{(unsigned)u, (unsigned)lane};
       } else {
         const unsigned sbase = (unsigned)(size_t)(sb - smem) + fa_lds_base;
-        asm volatile("ds_read_b64 %0, %1" : "=v"(a0) : "v"(sbase + voffa[u][0]) : "memory");
-        asm volatile("ds_read_b64 %0, %1" : "=v"(a1) : "v"(sbase + voffa[u][1]) : "memory");
-        asm volatile("ds_read_b64 %0, %1" : "=v"(b0) : "v"(sbase + voffb[u][0]) : "memory");
-        asm volatile("ds_read_b64 %0, %1" : "=v"(b1) : "v"(sbase + voffb[u][1]) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the four reads and their wait are ONE statement with early-clobber outputs: hipcc does not count LDS reads issued
+        // from inline asm, so nothing may sit between them and the wait that could consume a0..b1 (cdna guide 5.7 item 1 form i)
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+                     : "v"(sbase + voffa[u][0]), "v"(sbase + voffa[u][1]), "v"(sbase + voffb[u][0]), "v"(sbase + voffb[u][1])
+                     : "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
       const u32x4 ta = {a0[0], a0[1], a1[0], a1[1]};

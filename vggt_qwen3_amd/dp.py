@@ -49,8 +49,20 @@ def check_cover(buckets: Dict[int, Tuple[int, int]], embed_span: Tuple[int, int]
         raise AssertionError(f"buckets end at {pos}, buffer has {total}")
 
 
+def allreduce_tensor(t: torch.Tensor, group=None):
+    """SUM all-reduce in place. RCCL ("nccl") reduces device memory directly over xGMI; the gloo backend - used only to
+    rehearse several ranks on ONE GPU or on the CPU (tests/test_dp_gpu.py, tests/test_host_logic.py) - is given a host
+    copy of a device tensor, since its device-tensor support depends on how torch was built."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().to("cpu", copy=True)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 def allreduce_span(flat: torch.Tensor, lo: int, hi: int, group=None, async_op: bool = False):
-    return dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return allreduce_tensor(flat[lo:hi], group=group)
 
 
 def allreduce_in_backward_order(flat: torch.Tensor, buckets: Dict[int, Tuple[int, int]], embed_span: Tuple[int, int],

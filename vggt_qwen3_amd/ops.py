@@ -302,13 +302,37 @@ def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, loss_sum:
                                                 logits.stride(0), gscale, _stream()), "vq3_cross_entropy_fwd_bwd")
 
 
-def adamw_step(master, m, v, grad, w, lr, beta1, beta2, eps, wd, step, gscale=1.0) -> None:
+def adamw_step(master, m, v, grad, w, lr, beta1, beta2, eps, wd, step, gscale=1.0, clip=None) -> None:
+    """clip = (sumsq f32[1] device tensor, max_norm): global-norm clipping, coefficient computed on the device as
+    min(1, max_norm / (sqrt(sumsq) * gscale + 1e-6)) (torch.nn.utils.clip_grad_norm_'s formula on the scaled gradients)."""
     _req(master, F32, "adamw master"); _req(m, F32, "adamw m"); _req(v, F32, "adamw v")
     _req(grad, BF16, "adamw grad"); _req(w, BF16, "adamw w")
     n = master.numel()
     assert m.numel() == n and v.numel() == n and grad.numel() == n and w.numel() == n
+    sq, mx = (None, 0.0) if clip is None else clip
+    if sq is not None:
+        _req(sq, F32, "adamw clip sumsq")
     check(_lib.load().vq3_adamw_step(master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), w.data_ptr(), n,
-                                     lr, beta1, beta2, eps, wd, step, gscale, _stream()), "vq3_adamw_step")
+                                     lr, beta1, beta2, eps, wd, step, gscale, _p(sq), mx, _stream()), "vq3_adamw_step")
+
+
+def dropout_(x: torch.Tensor, p: float, seed: int, offset: int) -> torch.Tensor:
+    """In-place inverted dropout (bf16 or f32), mask = hash(seed, offset + element index)."""
+    assert x.is_contiguous() and x.is_cuda and x.dtype in (BF16, F32)
+    if p > 0.0 and x.numel():
+        check(_lib.load().vq3_dropout(x.data_ptr(), 1 if x.dtype == F32 else 0, x.numel(), float(p), seed & (2 ** 64 - 1),
+                                      offset & (2 ** 64 - 1), _stream()), "vq3_dropout")
+    return x
+
+
+def sumsq(x: torch.Tensor, partials: torch.Tensor, accum: torch.Tensor) -> None:
+    """accum[0] += sum(x^2) (bf16 or f32 x), deterministic: per-block partials (scratch, >= 1024 floats) summed in a fixed order."""
+    assert x.is_contiguous() and x.is_cuda and x.dtype in (BF16, F32)
+    _req(partials, F32, "sumsq partials"); _req(accum, F32, "sumsq accum")
+    assert partials.numel() >= 1024
+    if x.numel():
+        check(_lib.load().vq3_sumsq(x.data_ptr(), 1 if x.dtype == F32 else 0, x.numel(), partials.data_ptr(),
+                                    accum.data_ptr(), _stream()), "vq3_sumsq")
 
 
 # ----------------------------------------------------------------------------------------------- VGGT
@@ -502,17 +526,7 @@ def skinny_linear_fp8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, re
     return out
 
 
-# ---------------------------------------------------------------------------------------------- stream-K workspace (opt-in)
-_STREAMK_WS = None
-
-
-def enable_streamk(n_cu: int = 256) -> None:
-    """Hand the library the zeroed workspace its opt-in stream-K GEMM needs (VQ3_GEMM_STREAMK=1 selects the variant)."""
-    global _STREAMK_WS
-    if _STREAMK_WS is None:
-        _STREAMK_WS = torch.zeros(n_cu * (128 * 128 + 8) + 2048, device="cuda", dtype=F32)
-    check(_lib.load().vq3_gemm_set_workspace(_STREAMK_WS.data_ptr(), _STREAMK_WS.numel() * 4), "vq3_gemm_set_workspace")
-
-
-def disable_streamk() -> None:
-    check(_lib.load().vq3_gemm_set_workspace(None, 0), "vq3_gemm_set_workspace")
+# ---------------------------------------------------------------------------------------------- benchmarking hook
+def gemm_force_config(cfg: int = -3) -> None:
+    """Force vq3_gemm_bf16_nt's tile configuration for NT shapes (-3 = automatic). Benchmarks and tests only."""
+    check(_lib.load().vq3_gemm_force_config(cfg), "vq3_gemm_force_config")

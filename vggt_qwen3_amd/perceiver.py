@@ -3,7 +3,10 @@ reference's src/models/projector_perceiver.py:20-82 (PerceiverConfig, PerceiverL
 reference's checkpoints and its name-based optimiser grouping (train_sft.py:139-145) keep working.
 
 Forward only: the reference runs the projector under @torch.no_grad() (vggt_qwen3_vlm.py:128,162), so no gradient
-ever reaches it. Parameters stay fp32 like the reference's; bf16 compute copies of the matrices feed the MFMA GEMMs,
+ever reaches it. Its four nn.Dropout sites per layer (projector_perceiver.py:33,37,42,46-49: attention weights, attention
+output, after GELU, MLP output) are nevertheless ACTIVE whenever the module is in train mode - no_grad does not switch
+dropout off - so they are applied here under the same condition (`self.training and cfg.dropout > 0`), with a
+counter-based mask (statistically, not bitwise, torch's). `.eval()` (the inference scripts) disables them. Parameters stay fp32 like the reference's; bf16 compute copies of the matrices feed the MFMA GEMMs,
 while the residual / LayerNorm stream stays fp32."""
 from __future__ import annotations
 
@@ -85,6 +88,8 @@ class PerceiverProjector(nn.Module):
                                      for _ in range(config.num_layers)])
         self.out_proj = _Lin(D, out_dim)
         self._cc = None  # bf16 compute copies
+        self._drop_seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+        self._drop_offset = 0
 
     # ------------------------------------------------------------------
     def refresh_compute_copies(self) -> None:
@@ -124,6 +129,13 @@ class PerceiverProjector(nn.Module):
         hd = D // Hh
         Tp = round_up(T, 64)
         dev = tokens.device
+        pdrop = float(cfg.dropout) if self.training else 0.0
+
+        def drop(t):
+            if pdrop > 0.0:
+                ops.dropout_(t, pdrop, self._drop_seed, self._drop_offset)
+                self._drop_offset += t.numel()
+            return t
         kin = cc["in"].shape[1]
         x = torch.zeros((B * T, kin), device=dev, dtype=BF16)
         x[:, :Cin] = tokens.reshape(B * T, Cin).to(BF16)
@@ -138,7 +150,7 @@ class PerceiverProjector(nn.Module):
             S = torch.empty((B * Hh, N, Tp), device=dev, dtype=F32)
             ops.gemm_raw(q, kv, S, N, T, hd, D, 2 * D, Tp, nb1=B, nb2=Hh, sA=(N * D, hd), sB=(T * 2 * D, hd),
                          sC=(Hh * N * Tp, N * Tp), alpha=hd ** -0.5)
-            P = ops.softmax_fwd(S, None, 1, T, Tp, False)
+            P = drop(ops.softmax_fwd(S, None, 1, T, Tp, False))                      # MHA's attention-weight dropout
             o = torch.empty((B * N, D), device=dev, dtype=BF16)
             if T % 8 == 0:
                 # O[b,h] = P[b,h] . V[b,h]: V (columns D + h*hd .. of kv) is read in place as the k-major B operand
@@ -150,6 +162,15 @@ class PerceiverProjector(nn.Module):
                                   d=(0, Hh * hd * Tp, hd * Tp), src_off=D)
                 ops.gemm_raw(P, Vt, o, N, hd, Tp, Tp, Tp, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp),
                              sB=(Hh * hd * Tp, hd * Tp), sC=(N * D, hd))
+            if pdrop > 0.0:
+                # x = LN1(x + drop(attn)) ; x = LN2(x + drop(W2 drop(gelu(W1 x)))): the residual add moves out of the GEMM
+                # epilogue into the LayerNorm kernel so that the dropout sits between them
+                a = drop(ops.linear(o, w["o"], bias=l.self_attn.out_proj.bias, out_dtype=F32))
+                lat16, lat32 = ops.layernorm_fwd(a, l.norm1.weight, l.norm1.bias, 1e-5, res=lat32, want_bf16=True, want_f32=True)
+                h = drop(ops.linear(lat16, w["f1"], bias=l.mlp[0].bias, act=ops.ACT_GELU))
+                mo = drop(ops.linear(h, w["f2"], bias=l.mlp[3].bias, out_dtype=F32))
+                lat16, lat32 = ops.layernorm_fwd(mo, l.norm2.weight, l.norm2.bias, 1e-5, res=lat32, want_bf16=True, want_f32=True)
+                continue
             x1 = ops.linear(o, w["o"], bias=l.self_attn.out_proj.bias, residual=lat32, out_dtype=F32)
             lat16, lat32 = ops.layernorm_fwd(x1, l.norm1.weight, l.norm1.bias, 1e-5, want_bf16=True, want_f32=True)
             h = ops.linear(lat16, w["f1"], bias=l.mlp[0].bias, act=ops.ACT_GELU)

@@ -7,11 +7,18 @@ is a SUM all-reduce of the flat bf16 gradient buffer over RCCL/xGMI, issued buck
 hand-written backward (layers 35 -> 0) on a side stream so it overlaps the remaining backward; the 1/world factor is
 folded into the fused AdamW kernel. Semantics kept from the reference: two LR groups selected by parameter NAME
 ("projector"/"geom_head" -> proj_lr, else lr), AdamW(weight_decay) on every parameter, cosine schedule with warm-up
-stepped once per optimiser step, loss/grad_accum scaling, and `max_steps` counting micro-batches."""
+stepped once per optimiser step, loss/grad_accum scaling, and `max_steps` counting micro-batches.
+
+Two things the reference's default launch has and a plain AdamW loop does not (both on by default here):
+  * global-norm gradient clipping at 1.0 (configs/deepspeed_zero3.json:15 "gradient_clipping": 1.0): the squared norm of the
+    reduced gradients is summed on the device (vq3_sumsq) and the clip coefficient is applied inside the fused AdamW kernel;
+  * Accelerate's scheduler rule (accelerate/scheduler.py:73-82, reached from train_sft.py:219): without `split_batches` the
+    LR schedule advances `num_processes` times per optimiser step, so at N GPUs the cosine runs N times faster."""
 from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -30,10 +37,18 @@ def cosine_with_warmup(step: int, warmup: int, total: int) -> float:
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
 
 
+def schedule_multiplier(opt_step: int, sched_ticks: int, warmup: int, total: int) -> float:
+    """LR multiplier applied BY optimiser step `opt_step` (1-based). Before it the schedule has been ticked
+    (opt_step - 1) * sched_ticks times: sched_ticks = 1 is a plain `optimizer.step(); scheduler.step()` loop, sched_ticks =
+    num_processes is what the reference gets from Accelerate (accelerate/scheduler.py:73-82 steps the wrapped LambdaLR once
+    per process after every real optimiser step; skipped micro-batches only bump `_step_count`, which LambdaLR ignores)."""
+    return cosine_with_warmup((opt_step - 1) * sched_ticks, warmup, total)
+
+
 class Stage1Trainer:
     def __init__(self, model: VGGTQwen3VLM, *, lr=5e-6, proj_lr=1e-4, weight_decay=0.1, warmup_ratio=0.03,
                  max_steps=30000, grad_accum=32, betas=(0.9, 0.999), eps=1e-8, bucket_layers: int = 4,
-                 process_group=None):
+                 process_group=None, max_grad_norm: Optional[float] = 1.0, accelerate_scheduler_rule: bool = True):
         self.model = model
         self.tm = model.text_model
         self.lr, self.proj_lr, self.wd = lr, proj_lr, weight_decay
@@ -44,6 +59,9 @@ class Stage1Trainer:
         self.pg = process_group
         self.dist_on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.dist_on else 1
+        self.max_grad_norm = max_grad_norm
+        # scheduler ticks per optimiser step: `world` under Accelerate's rule (the reference), 1 for a plain loop
+        self.sched_ticks = self.world if accelerate_scheduler_rule else 1
         # W^T copies for three dgrad GEMMs cost one 2.7 ms refresh per optimiser step: on when that is amortised
         if grad_accum >= 4 and os.environ.get("VQ3_DGRAD_NT", "1") != "0":
             self.tm.enable_dgrad_transposes(True)
@@ -60,15 +78,34 @@ class Stage1Trainer:
         self.geom_master = torch.cat([p.detach().reshape(-1).float() for p in self.geom_params]).contiguous()
         self.geom_m = torch.zeros(gn, device=dev, dtype=F32)
         self.geom_v = torch.zeros(gn, device=dev, dtype=F32)
-        self.geom_grad = torch.zeros(gn, device=dev, dtype=F32)
+        # geom_grad carries one extra slot: the number of micro-batches of this window that produced a geom_head gradient
+        # (summed over ranks by the same all-reduce, so every rank takes the same "step geom_head or not" decision)
+        self.geom_on = model.geom_tokens > 0
+        self.geom_grad = torch.zeros(gn + 1, device=dev, dtype=F32)
         self.geom_w16 = torch.zeros(gn, device=dev, dtype=BF16)
-        self._geom_has_grad = False
+        self._gn = gn
+        self.norm_sq = torch.zeros(1, device=dev, dtype=F32)
+        self.norm_part = torch.zeros(1024, device=dev, dtype=F32)
+        self.last_grad_norm = None      # device scalar of the last optimiser step (pre-clip), for logging / tests
         # all-reduce buckets over flat_g: groups of `bucket_layers` layers (contiguous), norm with the last group,
         # the tied embedding last (its gradient is completed by the embedding backward at the very end)
         self.buckets, self.embed_span = dp.plan_buckets(self.tm.table, self.tm.config.num_hidden_layers, bucket_layers)
         dp.check_cover(self.buckets, self.embed_span, n)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.dist_on else None
         self._works: List = []
+        self._fired: List[int] = []     # buckets all-reduced from inside the backward of the current boundary micro-batch
+        if not hasattr(model, "_trainers"):
+            model._trainers = []
+        model._trainers.append(weakref.ref(self))
+
+    def resync_master_from_weights(self) -> None:
+        """The bf16 weights were replaced behind the trainer's back (a checkpoint load): re-derive the fp32 master copy, or
+        the next AdamW step would write the old weights back. Adam moments are kept."""
+        self.master.copy_(ops.cast(self.tm.flat_w, F32))
+        off = 0
+        for p in self.geom_params:
+            self.geom_master[off:off + p.numel()].copy_(p.detach().reshape(-1).float())
+            off += p.numel()
 
     # ------------------------------------------------------------------ communication
     def _allreduce_span(self, lo: int, hi: int):
@@ -80,6 +117,7 @@ class Stage1Trainer:
 
     def _layer_done(self, i: int):
         if i in self.buckets:
+            self._fired.append(i)
             self._allreduce_span(*self.buckets[i])
 
     # ------------------------------------------------------------------ one micro-batch
@@ -96,43 +134,64 @@ class Stage1Trainer:
         st = model.forward_state(batch["pixel_values"], batch.get("geom_token"), batch["input_ids"],
                                  batch["attention_mask"], batch["labels"], need_grad=True)
         hook = self._layer_done if (boundary and self.dist_on) else None
+        self._fired = []
+        if not accumulate:
+            self.geom_grad.zero_()
+        # A micro-batch without any labelled token (the answer truncated away) has no gradient: _backward_text then zeroes
+        # flat_g on the first micro-batch of a window and still fires every layer_done hook, so the ranks' collectives match.
         d_geom = model._backward_text(st, 1.0 / self.grad_accum, accumulate, layer_done=hook)
         if d_geom is not None:
             g = model.geom_head_backward(st, d_geom)
-            flat = torch.cat([g["0.weight"].reshape(-1), g["0.bias"].reshape(-1), g["2.weight"].reshape(-1),
-                              g["2.bias"].reshape(-1)])
-            if accumulate and self._geom_has_grad:
-                self.geom_grad += flat
-            else:
-                self.geom_grad.copy_(flat)
-            self._geom_has_grad = True
+            self.geom_grad[: self._gn] += torch.cat([g["0.weight"].reshape(-1), g["0.bias"].reshape(-1),
+                                                     g["2.weight"].reshape(-1), g["2.bias"].reshape(-1)])
+            self.geom_grad[self._gn:] += 1.0
         if boundary:
             self._optimizer_step()
         self.micro += 1
         return st["loss"]
 
+    def lr_mult(self, opt_step: int) -> float:
+        """Schedule multiplier used BY optimiser step `opt_step` (1-based): the schedule has been ticked
+        (opt_step - 1) * sched_ticks times before it."""
+        return schedule_multiplier(opt_step, self.sched_ticks, self.warmup, self.max_steps)
+
     def _optimizer_step(self):
         tm = self.tm
         if self.dist_on:
+            for g0 in sorted(self.buckets, reverse=True):     # buckets the backward did not reach (no hook fired)
+                if g0 not in self._fired:
+                    self._allreduce_span(*self.buckets[g0])
             self._allreduce_span(*self.embed_span)
-            if self._geom_has_grad:
-                dist.all_reduce(self.geom_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.geom_on:                                   # unconditional: identical collective sequence on every rank
+                self.comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm_stream):
+                    dp.allreduce_tensor(self.geom_grad, group=self.pg)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.opt_step += 1
-        mult = cosine_with_warmup(self.opt_step - 1, self.warmup, self.max_steps)
+        mult = self.lr_mult(self.opt_step)
         gscale = 1.0 / self.world
+        geom_step = self.geom_on and float(self.geom_grad[self._gn].item()) > 0   # one host read per optimiser step
+        clip = None
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            # global L2 norm over every trainable gradient (text model + geom_head), as DeepSpeed / clip_grad_norm_ take it
+            self.norm_sq.zero_()
+            ops.sumsq(tm.flat_g, self.norm_part, self.norm_sq)
+            if geom_step:
+                ops.sumsq(self.geom_grad[: self._gn], self.norm_part, self.norm_sq)
+            clip = (self.norm_sq, float(self.max_grad_norm))
+            self.last_grad_norm = self.norm_sq.sqrt() * gscale
         ops.adamw_step(self.master, self.m, self.v, tm.flat_g, tm.flat_w, self.lr * mult, self.betas[0], self.betas[1],
-                       self.eps, self.wd, self.opt_step, gscale)
+                       self.eps, self.wd, self.opt_step, gscale, clip=clip)
         tm.refresh_derived()     # e4m3 / W^T copies of the weights (no-ops unless enabled)
-        if self._geom_has_grad:
-            ops.adamw_step(self.geom_master, self.geom_m, self.geom_v, ops.cast(self.geom_grad, BF16), self.geom_w16,
-                           self.proj_lr * mult, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step, gscale)
+        if geom_step:
+            ops.adamw_step(self.geom_master, self.geom_m, self.geom_v, ops.cast(self.geom_grad[: self._gn].contiguous(), BF16),
+                           self.geom_w16, self.proj_lr * mult, self.betas[0], self.betas[1], self.eps, self.wd,
+                           self.opt_step, gscale, clip=clip)
             off = 0
             with torch.no_grad():
                 for p in self.geom_params:
                     p.copy_(self.geom_master[off:off + p.numel()].view_as(p))
                     off += p.numel()
-            self._geom_has_grad = False
 
     # ------------------------------------------------------------------ the reference's loop
     def fit(self, batches, *, log_every_steps: int = 10, save_every_steps: Optional[int] = None, output_dir=None,
@@ -185,5 +244,5 @@ class Stage1Trainer:
             dist.barrier(group=self.pg)
 
     def lrs(self):
-        mult = cosine_with_warmup(max(0, self.opt_step - 1), self.warmup, self.max_steps)
+        mult = self.lr_mult(max(1, self.opt_step))
         return self.lr * mult, self.proj_lr * mult

@@ -96,6 +96,26 @@ class Aggregator(nn.Module):
         self._cc = None
         self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
         self._rope_cache: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        # Checkpoint key space: a parameter is REGISTERED as `patch_embed__blocks__0__attn__qkv__weight`
+        # (nn.Module forbids dots in names) but state_dict() / load_state_dict() speak the upstream dotted names, so a
+        # reference-written `vision_model.aggregator.patch_embed.blocks.0.attn.qkv.weight` round-trips by name.
+        self._register_state_dict_hook(Aggregator._dotted_keys_hook)
+        self._register_load_state_dict_pre_hook(self._internal_keys_pre_hook)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_compute_copies())
+
+    @staticmethod
+    def _dotted_keys_hook(module, state_dict, prefix, local_metadata):
+        for name in module._names:
+            k = prefix + name.replace(".", "__")
+            if k in state_dict:
+                state_dict[prefix + name] = state_dict.pop(k)
+        return state_dict
+
+    def _internal_keys_pre_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for name in self._names:
+            k = prefix + name
+            if k in state_dict and "." in name:
+                state_dict[prefix + name.replace(".", "__")] = state_dict.pop(k)
 
     # state-dict keys use the upstream dotted names
     def p(self, name: str) -> torch.Tensor:
@@ -115,6 +135,10 @@ class Aggregator(nn.Module):
         self._cc = None
         self._pos_cache.clear()
         return missing
+
+    def invalidate_compute_copies(self) -> None:
+        self._cc = None
+        self._pos_cache.clear()
 
     # ------------------------------------------------------------------ compute copies (fp32 vectors)
     def _prepare(self):

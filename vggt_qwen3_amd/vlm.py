@@ -105,12 +105,17 @@ class _TextLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         model, st = ctx.model, ctx.state
+        tm = model.text_model
         gscale = float(grad_out.item())
-        d_geom = model._backward_text(st, gscale, accumulate=False)
-        grads = []
-        for n in model._text_param_names:
-            grads.append(model.text_model.grad_views[n].clone() if n in model.text_model.grad_views else None)
-        return (None, None, d_geom if ctx.has_geom else None, *grads)
+        # The parameters' .grad ARE views of the flat gradient buffer (no 8 GB copy per backward): autograd gets None for
+        # them and the HIP backward accumulates in place, exactly when .grad is still our view from an earlier backward
+        # (optimizer.zero_grad(set_to_none=True) drops the views -> the next backward overwrites; set_to_none=False zeroes
+        # the buffer through the views -> accumulation into zeros).
+        first = next(iter(tm.parameters()))
+        live = first.grad is not None and first.grad.data_ptr() == tm.grad_views["model.embed_tokens.weight"].data_ptr()
+        d_geom = model._backward_text(st, gscale, accumulate=live)
+        tm.publish_grads()
+        return (None, None, d_geom if ctx.has_geom else None, *([None] * len(model._text_param_names)))
 
 
 class VGGTQwen3VLM(nn.Module):
@@ -313,6 +318,15 @@ class VGGTQwen3VLM(nn.Module):
         H = tm.config.hidden_size
         B, L, S = st["B"], st["L"], st["S"]
         if st["head"] is None:
+            # No labelled token in this micro-batch (the collator truncated the answer away): the reference's mean over zero
+            # targets is NaN and would poison every weight; here the micro-batch contributes a ZERO gradient. The window's
+            # first micro-batch still has to overwrite flat_g, and the DP hooks still have to fire once per layer so that
+            # every rank issues the same sequence of bucket all-reduces.
+            if not accumulate:
+                tm.zero_grad_flat()
+            if layer_done is not None:
+                for i in reversed(range(tm.config.num_hidden_layers)):
+                    layer_done(i)
             return None
         Lp = st["saved"]["L"]                                   # forward_hidden pads L to a multiple of 8
         dh = tm.backward_loss_head(st["head"], B * Lp, gscale, accumulate)
