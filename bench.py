@@ -38,9 +38,10 @@ def flops_vggt(S, img=448, p=14, depth=24):
     return S * (depth * (dl + da) + pe + depth * (fl + fa) + depth * (gl + ga))
 def flops_perceiver(T=128, N=128, i=2048, D=4096, F=16384, L=6, o=2560):
     return 2 * T * i * D + L * (2 * N * D * D + 4 * T * D * D + 4 * N * T * D + 2 * N * D * D + 4 * N * D * F) + 2 * N * D * o
-def flops_qwen(L, H=2560, nq=32, nkv=8, hd=128, I=9728, n=36, V=151937):
+def flops_qwen(L, H=2560, nq=32, nkv=8, hd=128, I=9728, n=36, V=151937, head_rows=None):
+    """head_rows: rows the lm_head actually runs on (None = all L positions, as the reference materialises them)."""
     lin = 2 * (H * nq * hd + 2 * H * nkv * hd + nq * hd * H + 3 * H * I)
-    return n * (L * lin + 4 * L * L * nq * hd / 2) + 2 * L * H * V
+    return n * (L * lin + 4 * L * L * nq * hd / 2) + 2 * (L if head_rows is None else head_rows) * H * V
 
 
 def synthetic_batch(B, V, L, img, vocab, image_id, pad_id, nl_id, seed, device, geom: bool):
@@ -152,6 +153,9 @@ def main():
                          "on a saturated GPU; off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trim-variant", action="store_true", help="skip the second timed window (exact padding shortcut)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra result objects (forward_only, c4_variant, c5_variant); they run at --gpus 1 only")
+    ap.add_argument("--variant-steps", type=int, default=4, help="timed steps of the 8-view C4 / C5 variant windows")
     ap.add_argument("--layers", type=int, default=36, help="debug only; anything but 36 marks the line invalid")
     args = ap.parse_args()
 
@@ -200,6 +204,9 @@ def main():
     batch = synthetic_batch(B, V, L, args.image_size, 151936, model.image_id, 151643, 198, 1234 + rank, dev, args.geom)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
+    # labelled rows per sample: the lm_head + CE run on these rows only (identical loss and gradients),
+    # so utilisation figures count 2*rows*H*V for the head, not the reference's 2*L*H*V
+    head_rows = float((batch["labels"][:, 1:] != -100).sum().item()) / B
 
     use_dist = world > 1 or force_dist
 
@@ -258,9 +265,65 @@ def main():
         trimmed = {"value": round(world * B * args.steps / dtt, 3), "unit": "samples/s", "ms_per_step": round(dtt / args.steps * 1e3, 2),
                    "executed_seq_len": L_eff, "loss": round(float(loss_t.item()), 4),
                    "executed_tflop_per_sample": None if L_eff is None else round(
-                       (flops_vggt(V, args.image_size) + flops_perceiver() + 3 * flops_qwen(L_eff)) / 1e12, 3),
+                       (flops_vggt(V, args.image_size) + flops_perceiver() + 3 * flops_qwen(L_eff, head_rows=head_rows)) / 1e12, 3),
                    "note": "exact: columns that are padding for every row of the batch are not computed; same loss and gradients"}
         model.trim_padding = False
+
+    def timed(fn, n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        sync()
+        return (time.perf_counter() - t0) / n, out
+
+    tf_exec_train = (flops_vggt(V, args.image_size) + flops_perceiver() + 3 * flops_qwen(L, head_rows=head_rows)) / 1e12
+    tf_exec_fwd = (flops_vggt(V, args.image_size) + flops_perceiver() + flops_qwen(L, head_rows=head_rows)) / 1e12
+
+    # ---- forward-only window (the north-star's ">= 40 % bf16 MFMA utilisation on the fused VGGT+Perceiver+
+    # Qwen3-4B forward"): the reference's unit is VGGTQwen3VLM.forward under no_grad / eval (vggt_qwen3_vlm.py:179-201)
+    forward_only = None
+    variants = {}
+    if world == 1 and not args.no_variants:
+        def fwd():
+            with torch.no_grad():
+                return model(images=batch["pixel_values"], geom_token=batch["geom_token"], input_ids=batch["input_ids"],
+                             attention_mask=batch["attention_mask"], labels=batch["labels"])
+        model.eval()
+        fwd()
+        dtf, lf = timed(fwd, max(4, min(args.steps, 16)))
+        model.train()
+        fps = B / dtf
+        forward_only = {"forward_samples_per_s": round(fps, 2), "ms_per_forward": round(dtf * 1e3, 2), "loss": round(float(lf.item()), 4),
+                        "executed_tflop_per_sample": round(tf_exec_fwd, 3),
+                        "reference_algorithmic_tflop_per_sample": round((flops_vggt(V, args.image_size) + flops_perceiver() + flops_qwen(L)) / 1e12, 3),
+                        "forward_mfma_frac": round(fps * tf_exec_fwd / BF16_DENSE_PEAK_TFLOPS, 4),
+                        "note": "eval mode, no_grad, dense L (no padding trimmed); MFMA fraction counts executed FLOPs only "
+                                "(lm_head on the %.1f labelled rows per sample)" % head_rows}
+
+        # ---- configs C4 (8 views + geometry tokens) and C5 (C4 with the e4m3 forward) on this one GPU, same B and L
+        if not args.geom and V == 1:
+            b8 = synthetic_batch(B, 8, L, args.image_size, 151936, model.image_id, 151643, 198, 4321, dev, True)
+            hr8 = float((b8["labels"][:, 1:] != -100).sum().item()) / B
+            tf8 = (flops_vggt(8, args.image_size) + flops_perceiver() + 3 * flops_qwen(L, head_rows=hr8)) / 1e12
+            model.geom_tokens, trainer.geom_on = 8, True
+            for key, fp8 in (("c4_variant", False), ("c5_variant", True)):
+                model.text_model.enable_fp8_forward(fp8)
+                trainer.grad_accum, trainer.micro = 1, 0
+                trainer.micro_step(b8)                                   # warm the 8-view shapes
+                n8 = max(1, args.variant_steps)
+                trainer.grad_accum, trainer.micro = n8, 0                # one accumulation cycle: n8 micro-batches + one AdamW
+                dt8, l8 = timed(lambda: trainer.micro_step(b8), n8)
+                variants[key] = {"value": round(B / dt8, 3), "unit": "samples/s", "ms_per_step": round(dt8 * 1e3, 2), "steps": n8,
+                                 "views": 8, "geom_tokens": 8, "fp8_text_forward": fp8, "batch_per_gpu": B, "loss": round(float(l8.item()), 4),
+                                 "executed_tflop_per_sample": round(tf8, 3),
+                                 "executed_flops_utilisation_vs_bf16_peak": round(B / dt8 * tf8 / BF16_DENSE_PEAK_TFLOPS, 4),
+                                 "workload": ("BASELINE config %s on 1 GPU: VGGT aggregator @%dpx x 8 views (8 232-token global attention) "
+                                              "+ 8 geometry tokens + Perceiver + Qwen3-4B fwd+bwd + AdamW%s"
+                                              % ("C5" if fp8 else "C4", args.image_size, "; Qwen3 forward projections in e4m3" if fp8 else ""))}
+            model.text_model.enable_fp8_forward(args.fp8)
+            model.geom_tokens, trainer.geom_on = (8 if args.geom else 0), bool(args.geom)
+            trainer.geom_grad.zero_()
 
     # ---- live roofline of the dominant kernel (gemm_nt_kernel): one extra instrumented step, HIP events per launch
     roof = None
@@ -285,13 +348,18 @@ def main():
                 print(f"  {k}: {c:4d} {m_:8.3f} ms {f_ / m_ / 1e9:8.1f} TF/s", file=sys.stderr)
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12
-        traffic = None
-        tj = ROOT / "profiles" / "r1c_pmc_traffic.json"
-        if tj.exists():  # PMC counters cannot be read from inside the run: this is the committed rocprofv3 --pmc result
-            traffic = round(json.loads(tj.read_text())["traffic_bytes_per_launch"])
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (vq3_gemm_bf16_nt)", "achieved": round(ach, 1),
+        # PMC counters cannot be read from inside the run: `traffic` is the rocprofv3 --pmc result of THIS command at the
+        # commit named beside it (tools/summarize_pmc.py writes the file); null when no such profile has been committed
+        traffic, traffic_src = None, None
+        tj = ROOT / "profiles" / "r2_pmc_traffic.json"
+        if tj.exists():
+            tjd = json.loads(tj.read_text())
+            traffic = round(tjd["traffic_bytes_per_launch"])
+            traffic_src = {"file": "profiles/r2_pmc_traffic.json", "measured_at_commit": tjd.get("commit"), "command": tjd.get("command")}
+        roof = {"bound": "mfma", "kernel": "gemm kernels behind vq3_gemm_bf16_nt (gemm_v2 / gemm_v3 / gemm_v6)", "achieved": round(ach, 1),
                 "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
+                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_unit": "bytes/launch (L2<->fabric, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
                 "algorithmic_bytes_per_launch": round(by / nlaunch), "launches_per_step": nlaunch, "avg_launch_us": round(ms * 1e3 / nlaunch, 2),
                 "gemm_ms_per_step": round(ms, 2), "gemm_tflop_per_step": round(fl / 1e12, 3)}
     elif world > 1:
@@ -314,12 +382,17 @@ def main():
                        "grad_accum": accum, "optimizer_steps_timed": len(cycles), "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
                        "trim_padding": bool(args.trim_pad), "fp8_text_forward": bool(args.fp8), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),
-            "algorithmic_tflop_per_sample": round(tf_train, 3),
-            "model_flops_utilisation": round(value * tf_train / (world * BF16_DENSE_PEAK_TFLOPS), 4),
+            # utilisation counts EXECUTED FLOPs: the lm_head + CE run on the labelled rows only (same loss and gradients);
+            # the reference's figure (logits for all L positions) is kept beside it, never used for a utilisation number
+            "executed_tflop_per_sample": round(tf_exec_train, 3),
+            "reference_algorithmic_tflop_per_sample": round(tf_train, 3),
+            "model_flops_utilisation": round(value * tf_exec_train / (world * BF16_DENSE_PEAK_TFLOPS), 4),
             "build_s": round(t_build, 1),
             "roofline": roof,
+            "forward_only": forward_only,
             "trimmed_padding_variant": trimmed,
         }
+        out.update(variants)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, batch, L)

@@ -24,8 +24,10 @@ def main():
     cfgs = [int(a) for a in args] or [-3, 20]
     warm = "--warm" in sys.argv
     only = [a[7:] for a in sys.argv if a.startswith("--only=")]
+    extra = [tuple(int(x) for x in a[8:].split(",")) for a in sys.argv if a.startswith("--shape=")]
+    shapes = [("custom", *e) for e in extra] if extra else SHAPES
     torch.manual_seed(0)
-    for name, M, N, K in SHAPES:
+    for name, M, N, K in shapes:
         if only and not any(o in name for o in only):
             continue
         a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
