@@ -175,10 +175,10 @@ int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* qn_b, const 
                    const void* cos, const void* sin, void* Q, void* K, void* V, int64_t T, int32_t N, int32_t NH,
                    int32_t head_dim, int32_t tokens_per_frame, int32_t patch_start, int32_t Wp, int32_t use_norm,
                    int32_t use_rope, float eps, void* stream);
-/* F.scaled_dot_product_attention(q, k, v), non-causal, head_dim 64: Q,K bf16 [G*NH, N, 64], Vt bf16 [G*NH, 64, Np]
- * (V transposed, zero padded, Np % 64 == 0) -> O bf16 token-major O[(g*N + n)*ldo + h*64 + d]. */
-int vq3_flash_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int32_t G, int32_t NH, int32_t N,
-                       int32_t Np, int32_t head_dim, int64_t ldo, float scale, void* stream);
+/* F.scaled_dot_product_attention(q, k, v), non-causal, head_dim 64: Q, K, V bf16 [G*NH, N, 64] (V as stored: the kernel
+ * reads it transposed out of LDS) -> O bf16 token-major O[(g*N + n)*ldo + h*64 + d]. */
+int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N,
+                       int32_t head_dim, int64_t ldo, float scale, void* stream);
 
 /* Inverted dropout in place (the four nn.Dropout sites of a PerceiverLayer, src/models/projector_perceiver.py:33,37,42,46-49,
  * which stay ACTIVE under `model.train()` although encode_images runs under no_grad): element i is zeroed with probability p,

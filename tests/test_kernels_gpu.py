@@ -79,6 +79,49 @@ def test_gemm_epilogues(ops):
     assert _relerr(C, base + C0) < 1e-5
 
 
+@pytest.mark.parametrize("cfg", [20, 11, 13, 7, 9])
+def test_gemm_forced_configs_with_epilogues(ops, cfg):
+    """Every tile configuration behind vq3_gemm_bf16_nt (20 = the 256x256 8-phase kernel; 11 / 13 / 7 / 9 = loader-wave and
+    2-stage kernels) through the whole epilogue surface - bias, GELU, LayerScale, residual, accumulate, f32 output - with M and N
+    edges inside a tile, an odd number of K tiles, strided C and batches: all must agree with the automatic choice's contract."""
+    try:
+        ops.gemm_force_config(cfg)
+        for (M, N, K) in ((300, 520, 192), (1029, 1024, 1024), (257, 264, 64)):
+            A = _rand((M, K), 0.5, seed=3); W = _rand((N, K), 0.5, seed=4)
+            bias = _rand((N,), 1.0, F32, seed=5); cs = _rand((N,), 1.0, F32, seed=6)
+            R16 = _rand((M, N), 1.0, seed=7)
+            base = A.float() @ W.float().t()
+            out = ops.linear(A, W)
+            assert _relerr(out, base) < 4e-3, (cfg, M, N, K, _relerr(out, base))
+            out = ops.linear(A, W, bias=bias, colscale=cs, residual=R16, act=ops.ACT_GELU, alpha=0.5)
+            t = (base * 0.5 + bias).to(BF16)
+            t = torch.nn.functional.gelu(t.float()).to(BF16)
+            t = (t.float() * cs).to(BF16)
+            ref = (t.float() + R16.float()).to(BF16)
+            # 2 bf16 ulps at the largest magnitude: a 1-ulp flip of the GEMM result can survive the two later roundings
+            assert _relerr(out, ref) < 4e-3 and _maxerr(out, ref) <= 2 ** -6 * ref.float().abs().max().item(), \
+                (cfg, M, N, K, _relerr(out, ref), _maxerr(out, ref))
+            C = _rand((M, N), 1.0, seed=8); C0 = C.clone()
+            ops.linear(A, W, out=C, accumulate=True)
+            assert _relerr(C, base + C0.float()) < 4e-3
+            out32 = ops.linear(A, W, bias=bias, out_dtype=F32)
+            assert _relerr(out32, base + bias) < 1e-5
+            # strided output (ldc > N) with a guard band that must stay untouched, in-place residual (R is C)
+            big = torch.full((M, N + 24), 7.0, device="cuda", dtype=BF16)
+            view = big[:, 8:8 + N]
+            view.copy_(R16)
+            ops.gemm_raw(A, W, view, M, N, K, K, K, N + 24, R=view, ldr=N + 24, c_off=0, r_off=0)
+            assert _relerr(view, (base.to(BF16).float() + R16.float())) < 4e-3
+            assert bool((big[:, :8] == 7).all()) and bool((big[:, 8 + N:] == 7).all())
+        # batched: 3 x [200, 256] . [256, 128]^T
+        A = _rand((3, 200, 128), 1.0, seed=20); W = _rand((3, 256, 128), 1.0, seed=21)
+        C = torch.empty((3, 200, 256), device="cuda", dtype=BF16)
+        ops.gemm_raw(A, W, C, 200, 256, 128, 128, 128, 256, nb1=3, sA=(200 * 128, 0), sB=(256 * 128, 0), sC=(200 * 256, 0))
+        assert _relerr(C, torch.einsum("bmk,bnk->bmn", A.float(), W.float())) < 4e-3
+    finally:
+        ops.gemm_force_config(-3)
+
+
 def test_gemm_batched_strided(ops):
     """Attention-shaped use: batch (b, h) with K/V shared by groups of heads and a strided output."""
     Bz, Hq, Hkv, L, D = 2, 8, 2, 200, 128

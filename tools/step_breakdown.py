@@ -10,8 +10,8 @@ import sys
 
 def short(name: str) -> str:
     name = name.replace("(anonymous namespace)::", "").replace("vq3gemm::", "").replace("void ", "")
-    if "gemm_v2_kernel" in name or "gemm_nt_kernel" in name:
-        return "gemm<" + name.split("<")[1].split(">")[0].replace(" ", "") + ">"
+    if "gemm_v2_kernel" in name or "gemm_nt_kernel" in name or "gemm_v3_kernel" in name or "gemm_v6_kernel" in name:
+        return name.split("<")[0].split("::")[-1] + "<" + name.split("<")[1].split(">")[0].replace(" ", "") + ">"
     if name.startswith("at::native::"):
         return "torch:" + name.split("<")[0].split("::")[-1] + ":" + (name.split("at::native::")[2].split("<")[0] if name.count("at::native::") > 1 else "")
     return name.split("(")[0][:48]

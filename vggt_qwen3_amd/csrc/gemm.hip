@@ -10,7 +10,12 @@
 // ds_read_b128 fragment reads). One barrier per K tile; next tile's global loads are issued before the MFMAs.
 // The MFMA is issued with W as the A operand and x as the B operand so each lane ends up with 4 consecutive
 // output columns of one output row -> 8/16-byte epilogue stores and row-wise epilogues without shuffles.
+#include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 #include "gemm_common.h"
 #include "vq3_hip.h"
@@ -189,6 +194,101 @@ int choose_v3_stages(int M, int N, int K, int nbatch) {
   return s3 >= s2 ? 3 : 2;
 }
 
+// ---- measured kernel choice -------------------------------------------------------------------------------------------
+// The heuristics above rank tile configurations by fill; what a shape really gets also depends on K depth, epilogue and
+// cache state, and the ranking is wrong often enough to matter (Perceiver ffn1: 130 us chosen, 94 us available). So the
+// FIRST call with a new (shape, layout, epilogue kind) times every candidate on the caller's stream - on scratch output, with
+// a 320 MB fill between launches so that the weights come from HBM as they do inside a training step - and the winner
+// is remembered for the life of the process. Never while the stream is being captured into a graph (the heuristic answers
+// then), never when VQ3_GEMM_AUTOTUNE=0 or a configuration is forced. The first call of a shape therefore synchronises
+// the stream and may allocate scratch; every later call only enqueues.
+typedef std::tuple<int, int, int, int, int> TuneKey;   // M, N, K, nbatch, flags
+std::map<TuneKey, int> g_tuned;
+std::mutex g_tune_mutex;
+void* g_scratch_c = nullptr;
+size_t g_scratch_c_bytes = 0;
+void* g_flush = nullptr;
+constexpr size_t FLUSH_BYTES = 320u << 20;
+int g_autotune = -1;
+
+bool autotune_on(hipStream_t s) {
+  if (g_autotune < 0) {
+    const char* e = getenv("VQ3_GEMM_AUTOTUNE");
+    g_autotune = e ? atoi(e) : 1;
+  }
+  if (!g_autotune) return false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+  return true;
+}
+
+// launches one candidate; cand < 100: NT config (v2 cfg id or 20 = v6); cand >= 100: v3 with (cand - 100) stages
+int launch_candidate(GemmParams p, int cand, int transA, int transB, int nbatch, hipStream_t s) {
+  if (cand >= 100) return launch_gemm_v3(p, transA, transB, cand - 100, nbatch, s);
+  if (cand == 20) return launch_gemm_v6(p, nbatch, s);
+  return launch_gemm_v2(p, cand, nbatch, s);
+}
+
+// returns the fastest candidate, or -1 when tuning could not run (allocation failure, ...)
+int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int transB, int nbatch, hipStream_t s) {
+  GemmParams p = p0;
+  const size_t esz = p.out_f32 ? 4 : 2;
+  const size_t need = (size_t)p.M * p.N * esz * (size_t)nbatch + 256;
+  if (need > g_scratch_c_bytes) {
+    if (g_scratch_c) (void)hipFree(g_scratch_c);
+    g_scratch_c = nullptr; g_scratch_c_bytes = 0;
+    if (hipMalloc(&g_scratch_c, need) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    g_scratch_c_bytes = need;
+  }
+  if (!g_flush && hipMalloc(&g_flush, FLUSH_BYTES) != hipSuccess) { (void)hipGetLastError(); g_flush = nullptr; return -1; }
+  // trial output: dense scratch, no read-modify-write operands (an in-place residual or accumulate target must not be touched)
+  p.C = g_scratch_c; p.ldc = p.N; p.R = nullptr; p.ldr = 0; p.accumulate = 0;
+  p.sC1 = (long)p.M * p.N * p.nb2; p.sC2 = (long)p.M * p.N; p.sR1 = p.sR2 = 0;
+  p.vec_ok = (p.N % 4 == 0) ? 1 : 0;
+  (void)hipDeviceSynchronize();   // measure alone: work queued on other streams (the wgrad stream) would skew the ranking
+  (void)hipGetLastError();
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  int best = -1;
+  float best_ms = 1e30f;
+  const int reps = 3;
+  for (int cand : cands) {
+    if (launch_candidate(p, cand, transA, transB, nbatch, s) != 0) continue;      // warm-up (attribute set-up, code load)
+    float tmin = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+      (void)hipMemsetAsync(g_flush, r, FLUSH_BYTES, s);
+      (void)hipEventRecord(e0, s);
+      if (launch_candidate(p, cand, transA, transB, nbatch, s) != 0) { tmin = 1e30f; break; }
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) { tmin = 1e30f; break; }
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      tmin = std::min(tmin, ms);
+    }
+    if (tmin < best_ms) { best_ms = tmin; best = cand; }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (hipGetLastError() != hipSuccess) return -1;
+  if (getenv("VQ3_GEMM_AUTOTUNE_LOG"))
+    fprintf(stderr, "[vq3 gemm autotune] M=%d N=%d K=%d batch=%d tA=%d tB=%d -> %d (%.1f us)\n", p.M, p.N, p.K, nbatch, transA, transB,
+            best, best_ms * 1e3f);
+  return best;
+}
+
+int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStream_t s, const std::vector<int>& cands, int fallback) {
+  const int flags = (transA ? 1 : 0) | (transB ? 2 : 0) | (p.out_f32 ? 4 : 0) | (p.accumulate ? 8 : 0) | (p.R ? 16 : 0) |
+                    (p.bias ? 32 : 0) | (p.act << 6) | (p.colscale ? 256 : 0);
+  const TuneKey key(p.M, p.N, p.K, nbatch, flags);
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  auto it = g_tuned.find(key);
+  if (it != g_tuned.end()) return it->second;
+  if (!autotune_on(s)) return fallback;                   // not remembered: a later, tunable call may still measure
+  int best = tune(p, cands, transA, transB, nbatch, s);
+  if (best < 0) best = fallback;
+  g_tuned[key] = best;
+  return best;
+}
+
 }  // namespace
 
 extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
@@ -241,12 +341,22 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
     return 0;
   }
   if (d->transA || d->transB || d->K % BK != 0) {
-    const int rc = launch_gemm_v3(p, d->transA, d->transB, choose_v3_stages(d->M, d->N, d->K, nbatch), nbatch, s);
+    int nstage = choose_v3_stages(d->M, d->N, d->K, nbatch);
+    if (getenv("VQ3_GEMM_V3_STAGES") == nullptr && (long)d->M * d->N * d->K >= (1L << 24))
+      nstage = tuned_choice(p, d->transA, d->transB, nbatch, s, {102, 103}, 100 + nstage) - 100;
+    const int rc = launch_gemm_v3(p, d->transA, d->transB, nstage, nbatch, s);
     if (rc) return rc;
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3)");
     return 0;
   }
-  const int cfg = choose_config(d->M, d->N, d->K, nbatch);
+  int cfg = choose_config(d->M, d->N, d->K, nbatch);
+  if (g_forced_cfg == -3 && (long)d->M * d->N * d->K >= (1L << 24)) {
+    // candidates: 2-stage x 2 workgroups (7), 256x128 / 128x128 loader rings (11, 13), 8-wave 128x128 ring (9), and the
+    // 256x256 8-phase kernel (20) once the tile grid can feed it
+    std::vector<int> cands = {7, 11, 13, 9};
+    if ((long)((d->M + 255) / 256) * ((d->N + 255) / 256) * nbatch >= 64) cands.push_back(20);
+    cfg = tuned_choice(p, 0, 0, nbatch, s, cands, cfg);
+  }
   if (cfg == 20) {
     const int rc = launch_gemm_v6(p, nbatch, s);
     if (rc) return rc;

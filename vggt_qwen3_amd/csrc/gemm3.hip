@@ -210,7 +210,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
   // Read-modify-write operands of the epilogue (the gradient being accumulated into, a residual) are fetched before the
   // last K tile's MFMAs, so their L2 round trip is not paid between the last MFMA and the first store.
   u32x2 pre_r[TM][TN];     // one operand only (registers): the accumulation target, else the residual
-  const bool pre_ok = !OUT_F32 && p.vec_ok && p.nsplit == 1 && !p.bias && !p.colscale && (p.accumulate != 0) != (p.R != nullptr);
+  const bool staged = !OUT_F32 && staged_ok(p, coff, roff);     // LDS-staged epilogue (whole-row stores): gemm_common.h
+  const bool pre_ok = !staged && !OUT_F32 && p.vec_ok && p.nsplit == 1 && !p.bias && !p.colscale && (p.accumulate != 0) != (p.R != nullptr);
   auto prefetch_epilogue = [&]() {
     if (!pre_ok) return;
 #pragma unroll
@@ -306,6 +307,25 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     compute(last & 1);
   }
 
+  if (!OUT_F32 && staged) {
+    f32x4 bias_v[TN], cs_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int n = n0 + wn * (BN / WN) + j * 16 + 4 * fq;
+      n = n + 3 < p.N ? n : (p.N >= 4 ? p.N - 4 : 0);
+      if (p.bias) bias_v[j] = *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.colscale) cs_v[j] = *reinterpret_cast<const f32x4*>(p.colscale + n);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        stage_quad<BN>(p, smem, wm * (BM / WM) + i * 16 + fr, wn * (BN / WN) + j * 16 + 4 * fq, acc[i][j], bias_v[j], cs_v[j]);
+    __syncthreads();
+    staged_store<BM, BN>(p, smem, coff, roff, m0, n0, tid, 64 * NW);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / WM) + i * 16 + fr;

@@ -182,7 +182,33 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
     V6_FENCE();
   }
 
-  // ---- epilogue: lane owns C[m][n..n+3]
+  // ---- epilogue
+  if (!OUT_F32 && staged_ok(p, coff, roff)) {
+    // through LDS (the operand buffers are dead: every wave passed the last phase's barrier), out as whole 512-byte rows
+    f32x4 bias_r[2][2], cs_r[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int nt2 = 0; nt2 < 2; ++nt2) {
+        int n = n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq;
+        n = n + 3 < p.N ? n : (p.N >= 4 ? p.N - 4 : 0);          // columns past N are never stored
+        if (p.bias) bias_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.colscale) cs_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.colscale + n);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int nt2 = 0; nt2 < 2; ++nt2)
+            stage_quad<BN6>(p, smem, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq,
+                            acc[i * 4 + mt][j * 2 + nt2], bias_r[j][nt2], cs_r[j][nt2]);
+    __syncthreads();
+    staged_store<BM6, BN6>(p, smem, coff, roff, m0, n0, tid, 512);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

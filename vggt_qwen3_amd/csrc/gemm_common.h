@@ -214,6 +214,104 @@ __device__ __forceinline__ void store_quad_pre(const GemmParams& p, long coff, i
   *reinterpret_cast<u32x2*>(cp) = o;
 }
 
+// ---- LDS-staged bf16 epilogue ------------------------------------------------------------------------------------------------
+// The MFMA accumulator layout gives a lane 4 consecutive columns of one row: stored straight from registers a wave
+// instruction writes 16 rows x 32 B - four times the L2 requests of a coalesced store, and at short K (the VGGT GEMMs:
+// 16 K steps per tile) the output write is what the tile waits for (a 4096 x 4096 x 128 launch ran at 1.2 TB/s of C).
+// Instead the finished values (alpha, bias, activation, LayerScale applied, rounded to bf16 where PyTorch rounds) go to an
+// LDS image of the C tile - rows of BN bf16, 16-byte chunks XOR (row & 15): conflict-free for the 8-byte quad writes
+// (16 lanes = 16 rows, one column group) and for the 16-byte row reads - and leave as whole rows: 16 B per lane,
+// BN * 2 contiguous bytes per row, with the residual / accumulate operand read the same coalesced way.
+template <int BN>
+__device__ __forceinline__ int cstage_off(int row, int chunk) {
+  constexpr int MASK = BN / 8 >= 16 ? 15 : BN / 8 - 1;     // rows of fewer than 16 chunks (BN = 64): 2-way on the quad writes
+  return row * (BN * 2) + ((chunk ^ (row & MASK)) << 4);
+}
+
+// phase 1, per lane-owned quad (tile-local row ml, column nl..nl+3): same arithmetic and rounding points as store_quad_pre up
+// to (and including) LayerScale; bias_v / cs_v are the lane's column vectors (prefetched), ignored when p.bias / p.colscale is null
+template <int BN>
+__device__ __forceinline__ void stage_quad(const GemmParams& p, char* smem, int ml, int nl, const f32x4& a, const f32x4& bias_v,
+                                           const f32x4& cs_v) {
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += bias_v[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+  if (p.act) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rbf(apply_act(v[r], p.act));
+  }
+  if (p.colscale) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = rbf(v[r] * cs_v[r]);
+  }
+  u32x2 o;
+  o[0] = pack2bf(v[0], v[1]);
+  o[1] = pack2bf(v[2], v[3]);
+  *reinterpret_cast<u32x2*>(smem + cstage_off<BN>(ml, nl >> 3) + ((nl & 4) << 1)) = o;
+}
+
+// phase 2 (after a workgroup barrier): `nthreads` threads (tid 0 .. nthreads-1) move the BM x BN image out as whole rows,
+// adding the residual (rounded, as PyTorch's bf16 add) and / or the old C (accumulate) on the way. Needs p.vec_ok, ldc % 8 == 0
+// and a 16-byte aligned C (checked by staged_ok on the host side of the kernel).
+template <int BM, int BN>
+__device__ __forceinline__ void staged_store(const GemmParams& p, const char* smem, long coff, long roff, int m0, int n0, int tid,
+                                             int nthreads) {
+  constexpr int CPR = BN / 8;                  // 16-byte chunks per row
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff;
+  const bf16_t* R = p.R ? reinterpret_cast<const bf16_t*>(p.R) + roff : nullptr;
+  const int rpp = nthreads / CPR;              // rows per pass
+  const int c = tid % CPR;
+  const int n = n0 + c * 8;
+  if (n >= p.N) return;
+  const bool fulln = n + 7 < p.N;
+  for (int row = tid / CPR; row < BM; row += rpp) {
+    const int m = m0 + row;
+    if (m >= p.M) break;
+    const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
+    bf16_t* cp = C + (long)m * p.ldc + n;
+    if (fulln) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(sv[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(sv[k] >> 16)); }
+      if (R) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(R + (long)m * p.ldr + n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[2 * k] = rbf(v[2 * k] + bf2f((bf16_t)(rv[k] & 0xffff)));
+          v[2 * k + 1] = rbf(v[2 * k + 1] + bf2f((bf16_t)(rv[k] >> 16)));
+        }
+      }
+      if (p.accumulate) {
+        const u32x4 cv = *reinterpret_cast<const u32x4*>(cp);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] += bf2f((bf16_t)(cv[k] & 0xffff)); v[2 * k + 1] += bf2f((bf16_t)(cv[k] >> 16)); }
+      }
+      u32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = pack2bf(v[2 * k], v[2 * k + 1]);
+      *reinterpret_cast<u32x4*>(cp) = o;
+    } else {
+      for (int k = 0; k < 8 && n + k < p.N; ++k) {
+        float x = bf2f((bf16_t)((sv[k >> 1] >> ((k & 1) * 16)) & 0xffff));
+        if (R) x = rbf(x + bf2f(R[(long)m * p.ldr + n + k]));
+        if (p.accumulate) x += bf2f(cp[k]);
+        cp[k] = f2bf(x);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bool staged_ok(const GemmParams& p, long coff, long roff) {
+  return !p.out_f32 && p.nsplit == 1 && p.vec_ok && (p.ldc % 8 == 0) && (coff % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+         (!p.R || ((p.ldr % 8 == 0) && (roff % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.R) & 15) == 0)));
+}
+
 // host: pick the XCD blocking for a tile grid
 inline int choose_xm(int mtiles, int ntiles) {
   int best = 1;

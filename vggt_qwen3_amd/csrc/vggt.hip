@@ -185,63 +185,77 @@ __global__ __launch_bounds__(256) void vit_qkprep4_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ flash attention
-// Q,K bf16 [NB, N, 64]; Vt bf16 [NB, 64, Np] (V transposed, zero-padded to Np % 64 == 0); O bf16 token-major:
+// Q, K, V bf16 [NB, N, 64] as the q/k-prep kernel writes them (no transposed copy of V exists); O bf16 token-major:
 // O[(g*N + q) * ldo + h*64 + d] with NB = G*NH, g = nb / NH, h = nb % NH.
-// Block = 4 waves x 32 query rows; KV tile = 64 keys. LDS: K tile [64][64] and V^T tile [64][64], 16-byte chunks
-// XOR-swizzled with (row >> 1) & 7 so the fragment reads (lane = row) are conflict-free / 2-way.
+//
+// Workgroup = 4 waves x QB 32-query blocks; K/V tiles of 64 keys, register-staged (loads issued before the tile's MFMAs,
+// LDS stores after them), two LDS stages, one barrier per tile. Per wave and tile:
+//   S^T = K . Q'^T - m        32x32x16 MFMA, key on the row, QUERY ON THE LANE. Q' = Q * (scale * log2 e), rounded to bf16
+//                             once per workgroup, and the accumulator starts at -m (the lane's running max), so the
+//                             exponentiation is ONE v_exp_f32 per score: no multiply, no subtraction.
+//   rel = max_k S^T           how far this tile's scores exceed the running max (lane-local + one cross-half exchange).
+//   P^T = exp2(S^T)           in the STALE scale m; packed to bf16 it is the B operand of the next product as it stands
+//                             (accumulator-as-operand: k order 16s + 8(j>>2) + 4h + (j&3), matched on the V side).
+//   O^T += V^T . P^T          the V^T fragment (A operand) comes from the ROW-MAJOR V tile through ds_read_b64_tr_b16:
+//                             lane group (h, g16) reads keys 16u + 4h .. +3 (and +8) x d-columns 32db + 16 g16 .. +15.
+//   deferred rescale          only when some lane's rel exceeds THR (2^THR of head-room in P, bf16 keeps f32's exponent)
+//                             are O, l multiplied by 2^-rel and m advanced; tile 0 and rel > 100 (overflow guard) take
+//                             the textbook order (rescale first, subtract, then exponentiate).
+// LDS images: K rows of 128 B with 16-byte chunks XOR (row >> 1) & 7 (ds_read_b128, lane = key row: conflict-free);
+// V rows of 128 B with chunk bit 2 XOR (row >> 1) & 1, so the 4 key rows x 64 B a 32-lane half reads cover all 64 banks.
 constexpr int FA_KV = 64;
-#ifndef VQ3_FA_DIAG
-#define VQ3_FA_DIAG 0   // counters-only builds: 1 = no V^T reads, 2 = no K reads, 3 = no tile stores (outputs are then wrong)
-#endif
+constexpr float FA_THR = 6.0f;
 
 __device__ __forceinline__ int fa_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int fa_vswz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
 
-// QB = 32-row query blocks per wave (1 or 2): with 2, every K / V^T fragment read from LDS feeds two MFMAs.
 template <int QB>
-__global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                              const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
-                                                              int N, int Np, int NH, long ldo, float scale_log2e) {
-  // two stages of (K tile | V^T tile): tile t+1 is written while tile t is read -> one barrier per tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * FA_KV * 128];
+__global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                 const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                                 int N, int NH, long ldo, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * FA_KV * 128];   // 2 stages x (K tile | V tile)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const unsigned fa_lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the tiles
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const long nb = blockIdx.y;
   const int q0 = blockIdx.x * (128 * QB) + wid * (32 * QB);
   const bf16_t* Qb = Q + nb * (long)N * 64;
   const bf16_t* Kb = K + nb * (long)N * 64;
-  const bf16_t* Vb = Vt + nb * 64L * Np;
+  const bf16_t* Vb = V + nb * (long)N * 64;
 
-  // Q fragments: B operand, lane (r,h) holds Q[q0 + 32*qb + r][16s + 8h .. +8]
+  // Q' fragments (B operand): lane (r,h) holds Q'[q0 + 32 qb + r][16 s + 8 h .. +8]
   bf16x8 qf[QB][4];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     int qr = q0 + 32 * qb + r;
     qr = qr < N ? qr : N - 1;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 16 * s + 8 * h);
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 raw = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 16 * s + 8 * h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[qb][s][j] = (short)f2bf(bf2f((bf16_t)raw[j]) * scale_log2e);
+    }
   }
   f32x16 o0[QB], o1[QB];
-  float m_run[QB], l_run[QB];   // running max in the scaled (log2) domain
+  float m_run[QB], l_run[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[qb][i] = 0.f; o1[qb][i] = 0.f; }
-    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+    m_run[qb] = 0.f; l_run[qb] = 0.f;
   }
 
-  // staging: 512 16-byte chunks per tile, 2 per thread: chunk id c = tid + 256*i -> row c>>3, chunk c&7
+  // staging: 512 16-byte chunks per tile and operand, 2 per thread: row = tid >> 3 (+32), chunk = tid & 7
   const int srow0 = tid >> 3, sch = tid & 7;
   const int nt = (N + FA_KV - 1) / FA_KV;
   u32x4 kreg[2], vreg[2];
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = srow0 + 32 * i;
-      int kr = t * FA_KV + row;
+      int kr = t * FA_KV + srow0 + 32 * i;
       kr = kr < N ? kr : N - 1;
       kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (long)kr * 64 + sch * 8);
-      vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (long)row * Np + t * FA_KV + sch * 8);
+      vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (long)kr * 64 + sch * 8);
     }
   };
   auto store_tile = [&](int buf) {
@@ -251,29 +265,23 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
     for (int i = 0; i < 2; ++i) {
       const int row = srow0 + 32 * i;
       *reinterpret_cast<u32x4*>(Ks + fa_swz(row, sch)) = kreg[i];
-      // V^T is read back 8 bytes per lane by 32-lane groups on 64 banks: rows r and r+16 share a 16-byte slot (the chunk
-      // swizzle has 8 positions), so rows with bit 4 set keep their two 8-byte halves swapped and a group covers all banks
-      const u32x4 vv = (row & 16) ? u32x4{vreg[i][2], vreg[i][3], vreg[i][0], vreg[i][1]} : vreg[i];
-      *reinterpret_cast<u32x4*>(Vs + fa_swz(row, sch)) = vv;
+      *reinterpret_cast<u32x4*>(Vs + fa_vswz(row, sch)) = vreg[i];
     }
   };
-  // lane-constant LDS offsets of the fragment reads (relative to the stage base)
   int koff0[4], koff1[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     koff0[s] = fa_swz(r, 2 * s + h);
     koff1[s] = fa_swz(32 + r, 2 * s + h);
   }
-  int voffa[4][2], voffb[4][2];   // [sub*2+sp][run]
+  // transposed V reads: lane li = lane & 15 of its 16-lane group supplies row q = li >> 2, columns 4 p .. 4 p + 3 (p = li & 3)
+  // of the block [keys 16u + 4h .. +3] x [d 32 db + 16 g16 .. +15]; +8 keys = +1024 B, +16 keys (next u) = +2048 B
+  unsigned voff[2];
+  {
+    const int li = lane & 15, g16 = (lane >> 4) & 1, vq = li >> 2, vp = li & 3;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int kb = 16 * u + 4 * h;
-#pragma unroll
-    for (int run = 0; run < 2; ++run) {
-      const int hv = ((kb & 7) << 1) ^ (((r >> 4) & 1) << 3);   // 8-byte half, swapped for rows with bit 4 set (store_tile)
-      voffa[u][run] = FA_KV * 128 + fa_swz(r, (kb + 8 * run) >> 3) + hv;
-      voffb[u][run] = FA_KV * 128 + fa_swz(32 + r, (kb + 8 * run) >> 3) + hv;
-    }
+    for (int db = 0; db < 2; ++db)
+      voff[db] = FA_KV * 128 + fa_vswz(4 * h + vq, 4 * db + 2 * g16 + (vp >> 1)) + 8 * (vp & 1);
   }
 
   load_tile(0);
@@ -283,28 +291,47 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
   for (int t = 0; t < nt; ++t) {
     const bool more = t + 1 < nt;
     const char* sb = smem + (t & 1) * (2 * FA_KV * 128);
+    const unsigned sbase = lds_base + (unsigned)((t & 1) * (2 * FA_KV * 128));
     if (more) load_tile(t + 1);
-    // ---- S^T = K . Q^T for the two 32-key sub-tiles (each K fragment feeds QB query blocks)
+    // ---- S^T = K . Q'^T - m
     f32x16 s0[QB], s1[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s0[qb][i] = 0.f; s1[qb][i] = 0.f; }
+      for (int i = 0; i < 16; ++i) { s0[qb][i] = -m_run[qb]; s1[qb][i] = -m_run[qb]; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bf16x8 k0 = VQ3_FA_DIAG == 2 ? qf[0][s] : *reinterpret_cast<const bf16x8*>(sb + koff0[s]);
-      const bf16x8 k1 = VQ3_FA_DIAG == 2 ? qf[0][s] : *reinterpret_cast<const bf16x8*>(sb + koff1[s]);
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sb + koff0[s]);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sb + koff1[s]);
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         s0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[qb][s], s0[qb], 0, 0, 0);
         s1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[qb][s], s1[qb], 0, 0, 0);
       }
     }
-    // ---- online softmax (per query column = per lane pair (lane, lane^32)); masking only on the last tile
     const int kbase = t * FA_KV;
+    // first V^T fragments: issued now, waited for after the exponentials (the reads hide under the softmax chain)
+    u32x2 va[2][2], vb[2][2];
+#define FA_VISSUE(U, BUFI)                                                                                              \
+  asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"                        \
+               "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"                            \
+               : "=v"(va[BUFI][0]), "=v"(va[BUFI][1]), "=v"(vb[BUFI][0]), "=v"(vb[BUFI][1])                             \
+               : "v"(sbase + voff[0]), "v"(sbase + voff[1]), "i"((U) * 2048), "i"((U) * 2048 + 1024)                    \
+               : "memory")
+    // wait until all but the newest NEWER LDS operations of this wave are done; names the destinations so that no use of them
+    // can be scheduled above the wait (cdna guide 5.7 item 1, form ii)
+#define FA_VWAIT(BUFI, NEWER)                                                                                          \
+  do {                                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(%4)"                                                                              \
+                 : "+v"(va[BUFI][0]), "+v"(va[BUFI][1]), "+v"(vb[BUFI][0]), "+v"(vb[BUFI][1])                          \
+                 : "n"(NEWER));                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+  } while (0)
+    float rel[QB];
+    bool slow = (t == 0);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      if (kbase + FA_KV > N) {   // wave-uniform
+      if (kbase + FA_KV > N) {   // wave-uniform: key tail of the last tile
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key0 = kbase + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -312,56 +339,96 @@ __global__ __launch_bounds__(256) void flash_attn_hd64_kernel(const bf16_t* __re
           if (key0 + 32 >= N) s1[qb][i] = -INFINITY;
         }
       }
-      float mx = fmaxf(s0[qb][0], s1[qb][0]);
+      if (t == 0) {
+        // exact float maximum (may be negative): the first tile sets the scale
+        float mx = fmaxf(s0[qb][0], s1[qb][0]);
 #pragma unroll
-      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[qb][i], s1[qb][i]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qb], mx * scale_log2e);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[qb][i], s1[qb][i]));
+        rel[qb] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      } else {
+        // steady state: only growth above the stale max matters, and for that the INTEGER order of the bit patterns is
+        // enough (positive floats order like ints, every negative float - and -inf - is a negative int). Integer max
+        // needs no canonicalising v_max per MFMA output the way fmaxf does.
+        // (__float_as_int, not __builtin_bit_cast: hipcc 7.2 folds a bit_cast of a vector ELEMENT to element 0)
+        int mi = max(__float_as_int(s0[qb][0]), __float_as_int(s1[qb][0]));
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mi = max(mi, max(__float_as_int(s0[qb][i]), __float_as_int(s1[qb][i])));
+        const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);   // [0] = lower half's value, [1] = upper half's
+        mi = max((int)sw[0], (int)sw[1]);
+        rel[qb] = mi > 0 ? __int_as_float(mi) : 0.f;
+        slow = slow || !(rel[qb] <= 100.f);                                        // also catches NaN
+      }
+    }
+    if (__any(slow)) {
+      // textbook order (first tile; overflow guard): advance the max first, rescale, subtract, then exponentiate
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const float adv = (t == 0 || rel[qb] > FA_THR) ? rel[qb] : 0.f;
+        const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-adv);   // tile 0: O = l = 0, and 0 * 2^+big would be NaN
+        m_run[qb] += adv;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          o0[qb][i] *= alpha; o1[qb][i] *= alpha;
+          s0[qb][i] -= adv; s1[qb][i] -= adv;
+        }
+        rel[qb] = 0.f;
+      }
+    }
+    FA_VISSUE(0, 0);
+    // ---- P^T = exp2(S^T), row sums
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
       float ps = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        s0[qb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[qb][i], scale_log2e, -m_new));
-        s1[qb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[qb][i], scale_log2e, -m_new));
+        s0[qb][i] = __builtin_amdgcn_exp2f(s0[qb][i]);
+        s1[qb][i] = __builtin_amdgcn_exp2f(s1[qb][i]);
         ps += s0[qb][i] + s1[qb][i];
       }
-      ps += __shfl_xor(ps, 32, 64);
-      l_run[qb] = l_run[qb] * alpha + ps;
-      m_run[qb] = m_new;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; }
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps), __float_as_uint(ps), false, false);
+      l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
-    // ---- O^T += V^T . P^T : B operand = packed S^T registers 8s'..8s'+7 (k order: 16s' + 8(j>>2) + 4h + (j&3))
+    // ---- O^T += V^T . P^T, the V^T fragments of step u + 1 in flight while step u multiplies
+#define FA_PV(U, BUFI)                                                                                                  \
+  do {                                                                                                                  \
+    const u32x4 ta = {va[BUFI][0][0], va[BUFI][0][1], va[BUFI][1][0], va[BUFI][1][1]};                                  \
+    const u32x4 tb = {vb[BUFI][0][0], vb[BUFI][0][1], vb[BUFI][1][0], vb[BUFI][1][1]};                                  \
+    _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                                 \
+      bf16x8 pf;                                                                                                        \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                     \
+        pf[j] = (short)f2bf((U) < 2 ? s0[qb][8 * ((U) & 1) + j] : s1[qb][8 * ((U) & 1) + j]);                            \
+      o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), pf, o0[qb], 0, 0, 0);            \
+      o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1[qb], 0, 0, 0);            \
+    }                                                                                                                   \
+  } while (0)
+    FA_VISSUE(1, 1);
+    FA_VWAIT(0, 4);
+    FA_PV(0, 0);
+    FA_VISSUE(2, 0);
+    FA_VWAIT(1, 4);
+    FA_PV(1, 1);
+    FA_VISSUE(3, 1);
+    FA_VWAIT(0, 4);
+    FA_PV(2, 0);
+    FA_VWAIT(1, 0);
+    FA_PV(3, 1);
+    // ---- deferred rescale: only when some lane's scores outgrew the stale max by more than THR
+    bool grow = false;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {   // u = sub*2 + sp
-      // Plain ds_read_b64 through inline asm: left to the compiler, the a/b reads (4 KiB apart) are merged into
-      // ds_read2st64_b64, which is serviced on 32 banks in 16-lane groups at half the rate and made rows r, r+1 collide
-      // (counters: every conflict cycle of this kernel, 32 % of its LDS time). The asm reads are waited for by hand.
-      u32x2 a0, a1, b0, b1;
-      if (VQ3_FA_DIAG == 1) {
-        a0 = a1 = b0 = b1 = u32x2{(unsigned)u, (unsigned)lane};
-      } else {
-        const unsigned sbase = (unsigned)(size_t)(sb - smem) + fa_lds_base;
-        // the four reads and their wait are ONE statement with early-clobber outputs: hipcc does not count LDS reads issued
-        // from inline asm, so nothing may sit between them and the wait that could consume a0..b1 (cdna guide 5.7 item 1 form i)
-        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
-                     : "v"(sbase + voffa[u][0]), "v"(sbase + voffa[u][1]), "v"(sbase + voffb[u][0]), "v"(sbase + voffb[u][1])
-                     : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      const u32x4 ta = {a0[0], a0[1], a1[0], a1[1]};
-      const u32x4 tb = {b0[0], b0[1], b1[0], b1[1]};
+    for (int qb = 0; qb < QB; ++qb) grow = grow || (rel[qb] > FA_THR);
+    if (__any(grow)) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        bf16x8 pf;
+        const float adv = rel[qb] > FA_THR ? rel[qb] : 0.f;
+        const float alpha = __builtin_amdgcn_exp2f(-adv);
+        m_run[qb] += adv;
+        l_run[qb] *= alpha;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(u < 2 ? s0[qb][8 * (u & 1) + j] : s1[qb][8 * (u & 1) + j]);
-        o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), pf, o0[qb], 0, 0, 0);
-        o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1[qb], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; }
       }
     }
-    if (more && VQ3_FA_DIAG != 3) store_tile((t + 1) & 1);
+    if (more) store_tile((t + 1) & 1);
     __syncthreads();
   }
 
@@ -427,26 +494,25 @@ extern "C" int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* q
   return 0;
 }
 
-extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* Vt, void* O, int32_t G, int32_t NH,
-                                  int32_t N, int32_t Np, int32_t head_dim, int64_t ldo, float scale, void* stream) {
-  VQ3_CHECK_ARG(Q && K && Vt && O, "flash_attn_fwd: null pointer");
+extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH,
+                                  int32_t N, int32_t head_dim, int64_t ldo, float scale, void* stream) {
+  VQ3_CHECK_ARG(Q && K && V && O, "flash_attn_fwd: null pointer");
   VQ3_CHECK_ARG(head_dim == 64, "flash_attn_fwd: head_dim must be 64, got %d", head_dim);
-  VQ3_CHECK_ARG(G > 0 && NH > 0 && N > 0 && Np >= N && Np % 64 == 0, "flash_attn_fwd: bad shape (Np %% 64)");
+  VQ3_CHECK_ARG(G > 0 && NH > 0 && N > 0, "flash_attn_fwd: bad shape");
   VQ3_CHECK_ARG((long)G * NH <= 65535, "flash_attn_fwd: too many (group, head) pairs");
   VQ3_CHECK_ARG(ldo >= (long)NH * 64 && ldo % 4 == 0, "flash_attn_fwd: bad ldo");
-    static int qb_forced = -1;
+  VQ3_CHECK_ARG(((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) % 16 == 0 && (uintptr_t)O % 8 == 0, "flash_attn_fwd: misaligned operand");
+  static int qb_forced = -1;
   if (qb_forced < 0) { const char* e = getenv("VQ3_FLASH_QB"); qb_forced = e ? atoi(e) : 0; }
-  // measured (tools/bench_flash.py): QB=2 +3 % at N = 1029 (fewer, fuller workgroups), -11 % at N = 8232 (occupancy 2 vs 3)
-  const int qb = qb_forced ? qb_forced : ((N >= 512 && N < 4096) ? 2 : 1);
+  // two query blocks per wave (every K / V fragment read feeds two MFMA chains) once there are enough rows to fill them
+  const int qb = qb_forced ? qb_forced : (N >= 512 ? 2 : 1);
   dim3 grid((N + 128 * qb - 1) / (128 * qb), G * NH);
   if (qb == 2)
     hipLaunchKernelGGL(flash_attn_hd64_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, N, Np, NH, (long)ldo,
-                       scale * 1.44269504088896340736f);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, scale * 1.44269504088896340736f);
   else
     hipLaunchKernelGGL(flash_attn_hd64_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, N, Np, NH, (long)ldo,
-                       scale * 1.44269504088896340736f);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, scale * 1.44269504088896340736f);
   VQ3_CHECK_LAUNCH("flash_attn_fwd");
   return 0;
 }

@@ -373,14 +373,12 @@ def vit_qkprep(qkv, N, NH, *, qn=None, kn=None, cos=None, sin=None, tokens_per_f
 
 def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(Q K^T / 8) V for Q,K,V bf16 [G, NH, N, 64] -> token-major [G*N, NH*64]."""
-    _req(Q, BF16, "flash Q"); assert Q.is_contiguous() and K.is_contiguous() and V.is_contiguous()
+    _req(Q, BF16, "flash Q"); _req(K, BF16, "flash K"); _req(V, BF16, "flash V")
+    assert Q.is_contiguous() and K.is_contiguous() and V.is_contiguous() and K.shape == Q.shape and V.shape == Q.shape
     G, NH, N, D = Q.shape
-    Np = round_up(N, 64)
-    Vt = torch.empty((G, NH, D, Np), device=Q.device, dtype=BF16)
-    transpose_raw(V, Vt, N, D, Np, D, Np, n=(1, 1, G * NH), s=(0, 0, N * D), d=(0, 0, D * Np))
     if out is None:
         out = torch.empty((G * N, NH * D), device=Q.device, dtype=BF16)
-    check(_lib.load().vq3_flash_attn_fwd(Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr(), G, NH, N, Np, D,
+    check(_lib.load().vq3_flash_attn_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), G, NH, N, D,
                                          out.stride(0), D ** -0.5, _stream()), "vq3_flash_attn_fwd")
     return out
 
