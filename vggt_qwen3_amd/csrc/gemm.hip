@@ -225,7 +225,7 @@ bool autotune_on(hipStream_t s) {
 // launches one candidate; cand < 100: NT config (v2 cfg id or 20 = v6); cand >= 100: v3 with (cand - 100) stages
 int launch_candidate(GemmParams p, int cand, int transA, int transB, int nbatch, hipStream_t s) {
   if (cand >= 100) return launch_gemm_v3(p, transA, transB, cand - 100, nbatch, s);
-  if (cand == 20) return launch_gemm_v6(p, nbatch, s);
+  if (cand >= 20 && cand <= 22) return launch_gemm_v6(p, cand - 20, nbatch, s);
   return launch_gemm_v2(p, cand, nbatch, s);
 }
 
@@ -355,10 +355,12 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
     // 256x256 8-phase kernel (20) once the tile grid can feed it
     std::vector<int> cands = {7, 11, 13, 9};
     if ((long)((d->M + 255) / 256) * ((d->N + 255) / 256) * nbatch >= 64) cands.push_back(20);
+    if ((long)((d->M + 255) / 256) * ((d->N + 127) / 128) * nbatch >= 64) cands.push_back(21);
+    if ((long)((d->M + 127) / 128) * ((d->N + 255) / 256) * nbatch >= 64) cands.push_back(22);
     cfg = tuned_choice(p, 0, 0, nbatch, s, cands, cfg);
   }
-  if (cfg == 20) {
-    const int rc = launch_gemm_v6(p, nbatch, s);
+  if (cfg >= 20 && cfg <= 22) {
+    const int rc = launch_gemm_v6(p, cfg - 20, nbatch, s);
     if (rc) return rc;
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v6)");
     return 0;

@@ -25,21 +25,24 @@
 namespace vq3gemm {
 namespace {
 
-constexpr int BM6 = 256, BN6 = 256, BK6 = 64;
-constexpr int HALF = 128 * 128;          // bytes per half-tile
-constexpr int BUF = 4 * HALF;            // A0 A1 B0 B1
-constexpr int SMEM6 = 2 * BUF;
+constexpr int BK6 = 64;
+constexpr int HALF = 128 * 128;          // bytes per half-tile (128 rows x 64 k)
 
 #define V6_FENCE() asm volatile("" ::: "memory")
 
-template <bool OUT_F32>
+// AH / BH = number of 128-row half-tiles of A / B per K tile: (2,2) = 256x256 (4 phases per K tile), (2,1) = 256x128 and
+// (1,2) = 128x256 (2 phases per K tile, same 16 MFMAs per phase and wave).
+template <int AH, int BH, bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
+  constexpr int BM = 128 * AH, BN = 128 * BH;
+  constexpr int NSLOT = AH + BH;
+  constexpr int BUF = NSLOT * HALF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
   int m0, n0;
-  tile_coords(p, BM6, BN6, m0, n0);
+  tile_coords(p, BM, BN, m0, n0);
   const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
   const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
   const bf16_t* B = p.B + b1 * p.sB1 + (long)(b2 / p.b2divB) * p.sB2;
@@ -50,17 +53,21 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   // reads k-chunk (l & 7) ^ (l >> 3) of row l >> 3 (the read-side swizzle chunk ^ (row & 7), applied to the source).
   const int prow = lane >> 3;
   const int kch = (lane & 7) ^ prow;
-  unsigned offA[2][2], offB[2][2];     // byte offsets from A / B, [half][piece]
+  unsigned offA[AH][2], offB[BH][2];     // byte offsets from A / B, [half][piece]
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wid + 8 * j) * 8 + prow;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = h * 128 + (wid + 8 * j) * 8 + prow;
-      int ra = m0 + r; ra = ra < p.M ? ra : p.M - 1;
-      int rb = n0 + r; rb = rb < p.N ? rb : p.N - 1;
+    for (int h = 0; h < AH; ++h) {
+      int ra = m0 + h * 128 + r; ra = ra < p.M ? ra : p.M - 1;
       offA[h][j] = (unsigned)(((long)ra * p.lda + kch * 8) * 2);
+    }
+#pragma unroll
+    for (int h = 0; h < BH; ++h) {
+      int rb = n0 + h * 128 + r; rb = rb < p.N ? rb : p.N - 1;
       offB[h][j] = (unsigned)(((long)rb * p.ldb + kch * 8) * 2);
     }
+  }
   auto stage = [&](const bf16_t* base, const unsigned (&off)[2], int tile, char* slot) {
     const char* g = reinterpret_cast<const char*>(base) + (long)tile * (BK6 * 2);
 #pragma unroll
@@ -69,11 +76,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
                                        (__attribute__((address_space(3))) void*)(slot + (wid + 8 * j) * 1024), 16, 0, 0);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[AH * 4][BH * 2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < AH * 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < BH * 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
   const int a_base = (wr * 64 + fr) * 128 + ((fq ^ (fr & 7)) << 4);
@@ -119,18 +126,41 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   } while (0)
 
   const int nt = p.K / BK6;
-  // ---- prologue: all of tile 0, then A0 B0 B1 of tile 1
-  stage(A, offA[0], 0, smem + 0 * HALF);
-  stage(B, offB[0], 0, smem + 2 * HALF);
-  stage(B, offB[1], 0, smem + 3 * HALF);
-  stage(A, offA[1], 0, smem + 1 * HALF);
-  if (nt > 1) {
-    stage(A, offA[0], 1, smem + BUF + 0 * HALF);
-    stage(B, offB[0], 1, smem + BUF + 2 * HALF);
-    stage(B, offB[1], 1, smem + BUF + 3 * HALF);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  // ---- prologue: all of tile 0, then the half-tiles of tile 1 that the steady state stages ahead of a tile's last phase
+  if constexpr (AH == 2 && BH == 2) {
+    stage(A, offA[0], 0, smem + 0 * HALF);
+    stage(B, offB[0], 0, smem + 2 * HALF);
+    stage(B, offB[1], 0, smem + 3 * HALF);
+    stage(A, offA[1], 0, smem + 1 * HALF);
+    if (nt > 1) {
+      stage(A, offA[0], 1, smem + BUF + 0 * HALF);
+      stage(B, offB[0], 1, smem + BUF + 2 * HALF);
+      stage(B, offB[1], 1, smem + BUF + 3 * HALF);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // two-phase variants keep THREE K-tile buffers (3 x 48 KiB): tile t+2 is staged whole while tile t is multiplied, into the
+    // buffer tile t-1 left a full tile ago. Slots: A0 A1 B (256 x 128) or A B0 B1 (128 x 256).
+    auto stage_tile = [&](int t, char* buf) {
+      if constexpr (AH == 2) {
+        stage(A, offA[0], t, buf + 0 * HALF);
+        stage(B, offB[0], t, buf + 2 * HALF);
+        stage(A, offA[1], t, buf + 1 * HALF);
+      } else {
+        stage(A, offA[0], t, buf + 0 * HALF);
+        stage(B, offB[0], t, buf + 1 * HALF);
+        stage(B, offB[1], t, buf + 2 * HALF);
+      }
+    };
+    stage_tile(0, smem);
+    if (nt > 1) {
+      stage_tile(1, smem + BUF);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __builtin_amdgcn_s_barrier();
   V6_FENCE();
@@ -143,39 +173,92 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
 
   auto ktile = [&](int t, char* cur, char* nxt) {
     const bool s1 = t + 1 < nt, s2 = t + 2 < nt;
-    // phase 1
-    read_b(cur + 2 * HALF, wb0);
-    read_a(cur + 0 * HALF);
-    if (s1) stage(A, offA[1], t + 1, nxt + 1 * HALF);
-    V6_SYNC_A();
-    V6_MMA(0, 0, wb0);
-    V6_SYNC_B();
-    // phase 2
-    read_b(cur + 3 * HALF, wb1);
-    if (s2) stage(A, offA[0], t + 2, cur + 0 * HALF);
-    V6_SYNC_A();
-    V6_MMA(0, 1, wb1);
-    V6_SYNC_B();
-    // phase 3
-    read_a(cur + 1 * HALF);
-    if (s2) stage(B, offB[0], t + 2, cur + 2 * HALF);
-    V6_SYNC_A();
-    V6_MMA(1, 1, wb1);
-    V6_SYNC_B();
-    // phase 4
-    if (s2) {
-      stage(B, offB[1], t + 2, cur + 3 * HALF);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (AH == 2 && BH == 2) {
+      // phase 1
+      read_b(cur + 2 * HALF, wb0);
+      read_a(cur + 0 * HALF);
+      if (s1) stage(A, offA[1], t + 1, nxt + 1 * HALF);
+      V6_SYNC_A();
+      V6_MMA(0, 0, wb0);
+      V6_SYNC_B();
+      // phase 2
+      read_b(cur + 3 * HALF, wb1);
+      if (s2) stage(A, offA[0], t + 2, cur + 0 * HALF);
+      V6_SYNC_A();
+      V6_MMA(0, 1, wb1);
+      V6_SYNC_B();
+      // phase 3
+      read_a(cur + 1 * HALF);
+      if (s2) stage(B, offB[0], t + 2, cur + 2 * HALF);
+      V6_SYNC_A();
+      V6_MMA(1, 1, wb1);
+      V6_SYNC_B();
+      // phase 4
+      if (s2) {
+        stage(B, offB[1], t + 2, cur + 3 * HALF);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      V6_SYNC_A();
+      V6_MMA(1, 0, wb0);
+      V6_SYNC_B();
+    } else if constexpr (AH == 2) {
+      // 256 x 128: { A0, B -> quadrant (0,0) ; stage A0, B of t+2 }  { A1 -> quadrant (1,0) ; stage A1 of t+2 ; vmcnt }
+      // (`nxt` is the buffer of tile t+2 here: last read a whole tile ago, so no slot is restaged near its readers)
+      read_b(cur + 2 * HALF, wb0);
+      read_a(cur + 0 * HALF);
+      if (s2) {
+        stage(A, offA[0], t + 2, nxt + 0 * HALF);
+        stage(B, offB[0], t + 2, nxt + 2 * HALF);
+      }
+      V6_SYNC_A();
+      V6_MMA(0, 0, wb0);
+      V6_SYNC_B();
+      read_a(cur + 1 * HALF);
+      if (s2) {
+        stage(A, offA[1], t + 2, nxt + 1 * HALF);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile t+1 (staged during tile t-1) has landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      V6_SYNC_A();
+      V6_MMA(1, 0, wb0);
+      V6_SYNC_B();
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // 128 x 256: { A, B0 -> (0,0) ; stage A, B0 of t+2 }  { B1 -> (0,1) ; stage B1 of t+2 ; vmcnt }
+      read_b(cur + 1 * HALF, wb0);
+      read_a(cur + 0 * HALF);
+      if (s2) {
+        stage(A, offA[0], t + 2, nxt + 0 * HALF);
+        stage(B, offB[0], t + 2, nxt + 1 * HALF);
+      }
+      V6_SYNC_A();
+      V6_MMA(0, 0, wb0);
+      V6_SYNC_B();
+      read_b(cur + 2 * HALF, wb1);
+      if (s2) {
+        stage(B, offB[1], t + 2, nxt + 2 * HALF);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      V6_SYNC_A();
+      V6_MMA(0, 1, wb1);
+      V6_SYNC_B();
     }
-    V6_SYNC_A();
-    V6_MMA(1, 0, wb0);
-    V6_SYNC_B();
   };
-  for (int t = 0; t < nt; t += 2) {
-    ktile(t, smem, smem + BUF);
-    if (t + 1 < nt) ktile(t + 1, smem + BUF, smem);
+  if constexpr (AH == 2 && BH == 2) {
+    for (int t = 0; t < nt; t += 2) {
+      ktile(t, smem, smem + BUF);
+      if (t + 1 < nt) ktile(t + 1, smem + BUF, smem);
+    }
+  } else {
+    for (int t = 0; t < nt; t += 3) {
+      ktile(t, smem, smem + 2 * BUF);
+      if (t + 1 < nt) ktile(t + 1, smem + BUF, smem);
+      if (t + 2 < nt) ktile(t + 2, smem + 2 * BUF, smem + BUF);
+    }
   }
   if (wr == 0) {   // balance the stagger barrier
     __builtin_amdgcn_s_barrier();
@@ -184,10 +267,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
 
   // ---- epilogue
   if (!OUT_F32 && staged_ok(p, coff, roff)) {
-    // through LDS (the operand buffers are dead: every wave passed the last phase's barrier), out as whole 512-byte rows
-    f32x4 bias_r[2][2], cs_r[2][2];
+    // through LDS (the operand buffers are dead: every wave passed the last phase's barrier), out as whole rows
+    f32x4 bias_r[BH][2], cs_r[BH][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < BH; ++j)
 #pragma unroll
       for (int nt2 = 0; nt2 < 2; ++nt2) {
         int n = n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq;
@@ -196,27 +279,27 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
         if (p.colscale) cs_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.colscale + n);
       }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < AH; ++i)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < BH; ++j)
 #pragma unroll
           for (int nt2 = 0; nt2 < 2; ++nt2)
-            stage_quad<BN6>(p, smem, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq,
-                            acc[i * 4 + mt][j * 2 + nt2], bias_r[j][nt2], cs_r[j][nt2]);
+            stage_quad<BN>(p, smem, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq,
+                           acc[i * 4 + mt][j * 2 + nt2], bias_r[j][nt2], cs_r[j][nt2]);
     __syncthreads();
-    staged_store<BM6, BN6>(p, smem, coff, roff, m0, n0, tid, 512);
+    staged_store<BM, BN>(p, smem, coff, roff, m0, n0, tid, 512);
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < AH; ++i)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int m = m0 + i * 128 + wr * 64 + mt * 16 + fr;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < BH; ++j)
 #pragma unroll
         for (int nt2 = 0; nt2 < 2; ++nt2) {
           const int n = n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq;
@@ -226,28 +309,37 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
     }
 }
 
-}  // namespace
-
-int launch_gemm_v6(GemmParams& p, int nbatch, hipStream_t stream) {
+template <int AH, int BH>
+int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
+  constexpr int SMEM = (AH + BH == 4 ? 2 : 3) * (AH + BH) * HALF;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM6);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM6);
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       vq3_set_error("gemm v6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
       return 2;
     }
     attr_done = true;
   }
-  p.mtiles = (p.M + BM6 - 1) / BM6;
-  p.ntiles = (p.N + BN6 - 1) / BN6;
+  p.mtiles = (p.M + 128 * AH - 1) / (128 * AH);
+  p.ntiles = (p.N + 128 * BH - 1) / (128 * BH);
   p.xm = choose_xm(p.mtiles, p.ntiles);
   dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
   if (p.out_f32)
-    hipLaunchKernelGGL((gemm_v6_kernel<true>), grid, dim3(512), SMEM6, stream, p);
+    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, true>), grid, dim3(512), SMEM, stream, p);
   else
-    hipLaunchKernelGGL((gemm_v6_kernel<false>), grid, dim3(512), SMEM6, stream, p);
+    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false>), grid, dim3(512), SMEM, stream, p);
   return 0;
+}
+
+}  // namespace
+
+// shape: 0 = 256 x 256, 1 = 256 x 128, 2 = 128 x 256
+int launch_gemm_v6(GemmParams& p, int shape, int nbatch, hipStream_t stream) {
+  if (shape == 1) return launch_v6<2, 1>(p, nbatch, stream);
+  if (shape == 2) return launch_v6<1, 2>(p, nbatch, stream);
+  return launch_v6<2, 2>(p, nbatch, stream);
 }
 
 }  // namespace vq3gemm

@@ -326,7 +326,7 @@ inline int choose_xm(int mtiles, int ntiles) {
 // v2 (LDS-DMA pipelined) launcher, defined in gemm2.hip. cfg: 0 = 256x128 tile, 1 = 128x256, 2 = 128x128.
 int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream);
 // v6 (256x256 tile, 8-phase schedule, NT, K % 64 == 0), defined in gemm6.hip.
-int launch_gemm_v6(GemmParams& p, int nbatch, hipStream_t stream);
+int launch_gemm_v6(GemmParams& p, int shape, int nbatch, hipStream_t stream);   // shape: 0 = 256x256, 1 = 256x128, 2 = 128x256
 // v3 (any operand layout, K % 8 == 0), defined in gemm3.hip. nstage: 2 or 3.
 int launch_gemm_v3(GemmParams& p, int transA, int transB, int nstage, int nbatch, hipStream_t stream);
 

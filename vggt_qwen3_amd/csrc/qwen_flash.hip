@@ -63,12 +63,62 @@ __device__ __forceinline__ unsigned key_bits(const uint8_t* km, int kb, int r, i
   return (unsigned)(__ballot(ok) & 0xffffffffull);
 }
 
+// The attended-key bits of every tile a wave will walk, computed ONCE into the wave's own LDS words (a keymask byte load inside
+// the tile loop is a dependent global load, and its s_waitcnt vmcnt(0) sits on the tile's critical path). 256 keys = 8 tiles per
+// round trip: four independent byte loads per lane.
+constexpr int MAX_TILES = 256;     // L <= 8192
+__device__ __forceinline__ void key_bits_all(const uint8_t* km, int ntiles, int L, unsigned* mine) {
+  const int lane = threadIdx.x & 63;
+  for (int base = 0; base < ntiles * 32; base += 256) {
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = base + 64 * j + lane;
+      ok[j] = key < L && km[key < L ? key : L - 1] != 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned long long m = __ballot(ok[j]);
+      if (lane == 0) {
+        mine[(base >> 5) + 2 * j] = (unsigned)m;
+        mine[(base >> 5) + 2 * j + 1] = (unsigned)(m >> 32);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave reads back what it wrote (same wave: no barrier needed)
+}
+// Tiles without a single attended key contribute exact zeros (every probability is 0): they are dropped from the walk - as the
+// causal upper triangle always was. With the reference's collator the attention mask covers only the ~20-50 text positions of a
+// 200-column row, so most key tiles of a padded batch go. Returns the number of tiles kept; `list` (the wave's own LDS words)
+// receives their indices in ascending order.
+__device__ __forceinline__ int compact_tiles(const unsigned* bits, int ntiles, unsigned* list) {
+  int n = 0;
+  for (int kb = 0; kb < ntiles; ++kb) {
+    if (bits[kb] != 0u) {
+      if ((threadIdx.x & 63) == 0) list[n] = (unsigned)kb;
+      ++n;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  return n;
+}
+// One dword per 128-byte line of a 32-row x 256-byte tile (64 lanes = its 64 lines): pulls the NEXT tile of the walk into this
+// XCD's L2 a whole tile ahead, so that its real loads are L2 hits instead of a ~2 us cross-XCD round trip. Costs one register.
+__device__ __forceinline__ unsigned touch_tile(const bf16_t* base, long rowstride, int row0, int maxrow) {
+  const int lane = threadIdx.x & 63;
+  int row = row0 + (lane >> 1);
+  row = row < maxrow ? row : maxrow;
+  return *reinterpret_cast<const unsigned*>(base + (long)row * rowstride + (lane & 1) * 64);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // grid: B * Hkv * nqb blocks of 4 waves; wave g = query head hk*G + g (G = Hq / Hkv <= 4; spare waves idle)
 __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                             const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
                                                             bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Hq,
                                                             int Hkv, long ldo, float scale) {
+  __shared__ unsigned sbits[4][MAX_TILES];
+  __shared__ unsigned slist[4][MAX_TILES];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nqb = (L + 31) / 32;
@@ -79,11 +129,12 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
   const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
   const int G = Hq / Hkv, hq = hk * G + g;
   if (g >= G) return;
+  key_bits_all(keymask + (long)b * L, qb + 1, L, sbits[g]);
+  const int nlist = compact_tiles(sbits[g], qb + 1, slist[g]);
   const int q = qb * 32 + r, qc = q < L ? q : L - 1;
   const bf16_t* Qr = Q + (((long)b * Hq + hq) * L + qc) * D + 8 * h;
   const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
   const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
-  const uint8_t* km = keymask + (long)b * L;
   bf16x8 qf[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) qf[s] = ld8(Qr + 16 * s);
@@ -94,8 +145,12 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
     for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const float sl2e = scale * LOG2E;
-  for (int kb = 0; kb <= qb; ++kb) {
-    // every load of the tile is issued before its first use: one memory round trip per tile
+  for (int li = 0; li < nlist; ++li) {
+    const int kb = (int)slist[g][li];
+    // every load of the tile is issued before its first use: one memory round trip per tile; the next attended tile is touched
+    // into L2 meanwhile
+    const int nkb = (int)slist[g][li + 1 < nlist ? li + 1 : li];
+    const unsigned tk = touch_tile(Kb, D, nkb * 32, L - 1), tv = touch_tile(Vb, D, nkb * 32, L - 1);
     bf16x8 kc[8];
     u32x2 vc[2][8];
     rows_load(Kb, D, kb * 32 + r, h, L - 1, kc);
@@ -105,7 +160,7 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
     for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[t], qf[t], s, 0, 0, 0);
-    const unsigned bits = key_bits(km, kb, r, L);
+    const unsigned bits = sbits[g][kb];
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -139,6 +194,7 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
 #pragma unroll
       for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db], pf, o[db], 0, 0, 0);
     }
+    asm volatile("" ::"v"(tk), "v"(tv));   // keeps the touch loads alive; their wait lands here, after the tile's MFMAs
   }
   if (q >= L) return;
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -160,6 +216,8 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
                                                                const float* __restrict__ LSE, float* __restrict__ Delta,
                                                                bf16_t* __restrict__ dQ, int L, int Hq, int Hkv, long ldo,
                                                                long lddo, float scale) {
+  __shared__ unsigned sbits[4][MAX_TILES];
+  __shared__ unsigned slist[4][MAX_TILES];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nqb = (L + 31) / 32;
@@ -168,13 +226,14 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
   const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
   const int G = Hq / Hkv, hq = hk * G + g;
   if (g >= G) return;
+  key_bits_all(keymask + (long)b * L, qb + 1, L, sbits[g]);
+  const int nlist = compact_tiles(sbits[g], qb + 1, slist[g]);
   const int q = qb * 32 + r, qc = q < L ? q : L - 1;
   const bf16_t* Qr = Q + (((long)b * Hq + hq) * L + qc) * D + 8 * h;
   const bf16_t* Or = O + ((long)b * L + qc) * ldo + (long)hq * D + 8 * h;
   const bf16_t* dOr = dO + ((long)b * L + qc) * lddo + (long)hq * D + 8 * h;
   const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
   const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
-  const uint8_t* km = keymask + (long)b * L;
   bf16x8 qf[8], dof[8];
   float delta = 0.f;
 #pragma unroll
@@ -193,7 +252,10 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
 #pragma unroll
     for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
   const float sl2e = scale * LOG2E;
-  for (int kb = 0; kb <= qb; ++kb) {
+  for (int li = 0; li < nlist; ++li) {
+    const int kb = (int)slist[g][li];
+    const int nkb = (int)slist[g][li + 1 < nlist ? li + 1 : li];
+    const unsigned tk = touch_tile(Kb, D, nkb * 32, L - 1), tv = touch_tile(Vb, D, nkb * 32, L - 1);
     bf16x8 kc[8], vc[8];
     u32x2 gc[2][8];
     rows_load(Kb, D, kb * 32 + r, h, L - 1, kc);
@@ -207,7 +269,7 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[t], qf[t], s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc[t], dof[t], dp, 0, 0, 0);
     }
-    const unsigned bits = key_bits(km, kb, r, L);
+    const unsigned bits = sbits[g][kb];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int kl = rho(i, h);
@@ -223,6 +285,7 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
 #pragma unroll
       for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[db], dsf, dq[db], 0, 0, 0);
     }
+    asm volatile("" ::"v"(tk), "v"(tv));
   }
   if (q >= L) return;
   bf16_t* dQr = dQ + (((long)b * Hq + hq) * L + q) * D;
@@ -257,6 +320,20 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* _
   const bf16_t* Kr = K + (((long)b * Hkv + hk) * L + kc) * D + 8 * h;
   const bf16_t* Vr = V + (((long)b * Hkv + hk) * L + kc) * D + 8 * h;
   const bool key_ok = key < L && keymask[(long)b * L + kc] != 0;
+  if (__ballot(key_ok) == 0ull) {
+    // no attended key in this tile (padding): dK = dV = 0 exactly, for every head of the group - same answer in all four waves
+    if (key < L && g == 0) {
+      bf16_t* dKz = dK + (((long)b * Hkv + hk) * L + key) * D + 64 * h;
+      bf16_t* dVz = dV + (((long)b * Hkv + hk) * L + key) * D + 64 * h;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        *reinterpret_cast<u32x4*>(dKz + 8 * c) = z;
+        *reinterpret_cast<u32x4*>(dVz + 8 * c) = z;
+      }
+    }
+    return;
+  }
   bf16x8 kf[8], vf[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) { kf[s] = ld8(Kr + 16 * s); vf[s] = ld8(Vr + 16 * s); }
@@ -272,7 +349,10 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* _
     const float* lse_h = LSE + ((long)b * Hq + hq) * L;
     const float* del_h = Delta + ((long)b * Hq + hq) * L;
     for (int qb = kb; qb < nkb; ++qb) {
-      // every load of the tile is issued before its first use: one memory round trip per tile instead of four
+      // every load of the tile is issued before its first use: one memory round trip per tile instead of four; the next
+      // q-block's Q and dO tiles are touched into L2 meanwhile
+      const int nq = qb + 1 < nkb ? qb + 1 : qb;
+      const unsigned tq = touch_tile(Qh, D, nq * 32, L - 1), tdo = touch_tile(dOh, lddo, nq * 32, L - 1);
       bf16x8 qrow[8], dorow[8];
       u32x2 gdo[2][8], gq[2][8];
       f32x4 lse4[4], del4[4];
@@ -319,6 +399,7 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* _
 #pragma unroll
         for (int db = 0; db < 4; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[db], dsf, dk[db], 0, 0, 0);
       }
+      asm volatile("" ::"v"(tq), "v"(tdo));
     }
   }
   // sum the G query heads: 8 accumulator blocks (dk[0..3], dv[0..3]), each reduced through LDS; wave (blk & 3) keeps blk
@@ -353,6 +434,7 @@ static int flash_check(const char* who, int B, int L, int Hq, int Hkv, int Dh) {
   VQ3_CHECK_ARG(B > 0 && L > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 4,
                 "%s: need 1..4 query heads per kv head (B=%d L=%d Hq=%d Hkv=%d)", who, B, L, Hq, Hkv);
   VQ3_CHECK_ARG((long)B * Hkv * ((L + 31) / 32) < (1l << 31), "%s: grid too large", who);
+  VQ3_CHECK_ARG(L <= 32 * MAX_TILES, "%s: L=%d exceeds %d", who, L, 32 * MAX_TILES);
   return 0;
 }
 

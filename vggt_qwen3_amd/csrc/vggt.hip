@@ -238,11 +238,20 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
   }
   f32x16 o0[QB], o1[QB];
   float m_run[QB], l_run[QB];
+  // -m replicated over an accumulator-shaped vector: the first QK MFMA of a tile takes it as C and writes the scores to
+  // other registers, so no per-tile fill of the accumulator is needed (m only changes on the rare deferred rescale).
+  // One query block per wave only: with two the 16 extra registers per block would push the kernel past 256 VGPRs.
+  constexpr bool NEGM = (QB == 1);
+  f32x16 negm[NEGM ? QB : 1];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[qb][i] = 0.f; o1[qb][i] = 0.f; }
     m_run[qb] = 0.f; l_run[qb] = 0.f;
+    if (NEGM) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[qb][i] = 0.f;
+    }
   }
 
   // staging: 512 16-byte chunks per tile and operand, 2 per thread: row = tid >> 3 (+32), chunk = tid & 7
@@ -295,18 +304,25 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
     if (more) load_tile(t + 1);
     // ---- S^T = K . Q'^T - m
     f32x16 s0[QB], s1[QB];
+    if (!NEGM) {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s0[qb][i] = -m_run[qb]; s1[qb][i] = -m_run[qb]; }
+        for (int i = 0; i < 16; ++i) { s0[qb][i] = -m_run[qb]; s1[qb][i] = -m_run[qb]; }
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sb + koff0[s]);
       const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(sb + koff1[s]);
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        s0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[qb][s], s0[qb], 0, 0, 0);
-        s1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[qb][s], s1[qb], 0, 0, 0);
+        if (NEGM && s == 0) {
+          s0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[qb][s], negm[qb], 0, 0, 0);
+          s1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[qb][s], negm[qb], 0, 0, 0);
+        } else {
+          s0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[qb][s], s0[qb], 0, 0, 0);
+          s1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[qb][s], s1[qb], 0, 0, 0);
+        }
       }
     }
     const int kbase = t * FA_KV;
@@ -372,6 +388,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
           o0[qb][i] *= alpha; o1[qb][i] *= alpha;
           s0[qb][i] -= adv; s1[qb][i] -= adv;
         }
+        if (NEGM) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) negm[qb][i] = -m_run[qb];
+        }
         rel[qb] = 0.f;
       }
     }
@@ -426,6 +446,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
         l_run[qb] *= alpha;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; }
+        if (NEGM) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) negm[qb][i] = -m_run[qb];
+        }
       }
     }
     if (more) store_tile((t + 1) & 1);
