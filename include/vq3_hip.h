@@ -65,6 +65,21 @@ typedef struct vq3_gemm_desc {
 
 int vq3_gemm_bf16_nt(const vq3_gemm_desc* desc, void* stream);
 
+/* The qkv projection of a VGGT / DINOv2 attention block with its consumer fused into the epilogue (layers/attention.py of the
+ * published model, reached from vggt_qwen3_vlm.py:144): qkv = x Wqkv^T + b is never written; the tile leaves as head-major
+ * Q, K, V bf16 [M / N, NH, N, 64] with, on q and k, the per-head LayerNorm(64) (use_norm: the aggregator's q_norm / k_norm) and the
+ * 2-D rotate-half RoPE (use_rope; token t of a frame of `tokens_per_frame` tokens sits at (y, x) = ((t - patch_start) / Wp + 1,
+ * (t - patch_start) % Wp + 1), special tokens at (0, 0); cos / sin bf16 [maxpos + 1, 32]) - same arithmetic and bf16 rounding
+ * points as vq3_vit_qkprep on the materialised qkv. desc: plain NT bf16 GEMM (bias allowed), N = 3 * NH * 64, K % 64 == 0, C ignored. */
+typedef struct vq3_vit_qkv_epilogue {
+  void *Q, *K, *V;
+  const float *qn_w, *qn_b, *kn_w, *kn_b;
+  const void *cos, *sin;
+  int32_t N, NH, tokens_per_frame, patch_start, Wp, use_norm, use_rope;
+  float eps;
+} vq3_vit_qkv_epilogue;
+int vq3_gemm_vit_qkv(const vq3_gemm_desc* desc, const vq3_vit_qkv_epilogue* epi, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Normalisation
  * ---------------------------------------------------------------------------------------------------------- */

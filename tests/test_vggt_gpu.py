@@ -139,3 +139,40 @@ def test_dino_backbone_vs_transformers_golden():
         ref = torch.from_numpy(z[f"{name}:tokens"])
         assert got.shape == ref.shape
         assert relerr(got, ref) < 2e-2, (name, relerr(got, ref))
+
+
+@pytest.mark.parametrize("use_norm,use_rope", [(True, True), (False, False)])
+@pytest.mark.parametrize("cfg", [-3, 20, 11, 7])
+def test_fused_qkv_epilogue_equals_linear_plus_vit_qkprep(use_norm, use_rope, cfg):
+    """vq3_gemm_vit_qkv (head split + q/k LayerNorm + 2-D RoPE in the GEMM epilogue, qkv never materialised) against the two-launch
+    form it replaces - vq3_gemm_bf16_nt followed by vq3_vit_qkprep - on the same inputs, for every tile configuration that can be
+    chosen, with M not a multiple of any tile height (3 frames of 5 + 6x7 tokens, two groups)."""
+    from vggt_qwen3_amd import ops
+    torch.manual_seed(1)
+    NH, C, Wp, ps = 4, 256, 7, 5
+    P = ps + 6 * Wp                                      # 47 tokens per frame
+    G, N = 2, 3 * P                                      # global attention over 3 frames
+    T = G * N
+    x = torch.randn(T, C, device="cuda").to(BF16)
+    w = (torch.randn(3 * C, C, device="cuda") * 0.06).to(BF16)
+    bias = torch.randn(3 * C, device="cuda") * 0.1
+    qn = (torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1)
+    kn = (torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1)
+    ang = torch.rand(8, 16, device="cuda") * 3.0
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(BF16).contiguous(), emb.sin().to(BF16).contiguous()
+    kw = dict(qn=qn if use_norm else None, kn=kn if use_norm else None, cos=cos if use_rope else None,
+              sin=sin if use_rope else None, tokens_per_frame=P, patch_start=ps, Wp=Wp, eps=1e-5)
+    try:
+        ops.gemm_force_config(cfg)
+        qkv = ops.linear(x, w, bias=bias)
+        ref = ops.vit_qkprep(qkv, N, NH, **kw)
+        got = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
+    finally:
+        ops.gemm_force_config(-3)
+    for name, a, b in zip("QKV", got, ref):
+        assert a.shape == b.shape == (G, NH, N, 64)
+        # same inputs and rounding points; only the LayerNorm sums associate differently (one bf16 ulp at most)
+        assert (a.float() - b.float()).abs().max() <= 2 ** -6 * b.float().abs().max(), name
+        assert ((a.float() - b.float()).norm() / b.float().norm()).item() < 2e-3, name
+    assert torch.equal(got[2], ref[2])                   # V is a pure copy

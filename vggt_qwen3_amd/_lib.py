@@ -29,6 +29,12 @@ class GemmDesc(C.Structure):
     ]
 
 
+class VitQkvEpilogue(C.Structure):
+    _fields_ = [("Q", c_p), ("K", c_p), ("V", c_p), ("qn_w", c_p), ("qn_b", c_p), ("kn_w", c_p), ("kn_b", c_p),
+                ("cos", c_p), ("sin", c_p), ("N", i32), ("NH", i32), ("tokens_per_frame", i32), ("patch_start", i32),
+                ("Wp", i32), ("use_norm", i32), ("use_rope", i32), ("eps", f32)]
+
+
 class ImageDesc(C.Structure):
     _fields_ = [("src", c_p), ("h", i32), ("w", i32), ("pitch", i32), ("ksize_h", i32), ("ksize_v", i32),
                 ("kh_off", i32), ("kv_off", i32), ("bh_off", i32), ("bv_off", i32), ("crop_x", i32), ("crop_y", i32)]
@@ -40,6 +46,7 @@ SIGNATURES = {
     "vq3_last_error": [],
     "vq3_target_arch": [],
     "vq3_gemm_bf16_nt": [C.POINTER(GemmDesc), c_p],
+    "vq3_gemm_vit_qkv": [C.POINTER(GemmDesc), C.POINTER(VitQkvEpilogue), c_p],
     "vq3_rmsnorm_fwd": [c_p, c_p, c_p, c_p, i64, i32, i64, i64, f32, c_p],
     "vq3_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "vq3_colsum_f32_to_bf16": [c_p, i32, i32, c_p, i32, c_p],

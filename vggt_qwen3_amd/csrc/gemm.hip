@@ -242,7 +242,8 @@ int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int tr
   }
   if (!g_flush && hipMalloc(&g_flush, FLUSH_BYTES) != hipSuccess) { (void)hipGetLastError(); g_flush = nullptr; return -1; }
   // trial output: dense scratch, no read-modify-write operands (an in-place residual or accumulate target must not be touched)
-  p.C = g_scratch_c; p.ldc = p.N; p.R = nullptr; p.ldr = 0; p.accumulate = 0;
+  if (p.epi == 0) p.C = g_scratch_c;      // (epi == 1 writes Q / K / V: idempotent, no read-modify-write)
+  p.ldc = p.N; p.R = nullptr; p.ldr = 0; p.accumulate = 0;
   p.sC1 = (long)p.M * p.N * p.nb2; p.sC2 = (long)p.M * p.N; p.sR1 = p.sR2 = 0;
   p.vec_ok = (p.N % 4 == 0) ? 1 : 0;
   (void)hipDeviceSynchronize();   // measure alone: work queued on other streams (the wgrad stream) would skew the ranking
@@ -277,7 +278,7 @@ int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int tr
 
 int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStream_t s, const std::vector<int>& cands, int fallback) {
   const int flags = (transA ? 1 : 0) | (transB ? 2 : 0) | (p.out_f32 ? 4 : 0) | (p.accumulate ? 8 : 0) | (p.R ? 16 : 0) |
-                    (p.bias ? 32 : 0) | (p.act << 6) | (p.colscale ? 256 : 0);
+                    (p.bias ? 32 : 0) | (p.act << 6) | (p.colscale ? 256 : 0) | (p.epi << 9);
   const TuneKey key(p.M, p.N, p.K, nbatch, flags);
   std::lock_guard<std::mutex> lock(g_tune_mutex);
   auto it = g_tuned.find(key);
@@ -291,9 +292,9 @@ int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStr
 
 }  // namespace
 
-extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
+static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve, void* stream) {
   VQ3_CHECK_ARG(d != nullptr, "gemm: null descriptor");
-  VQ3_CHECK_ARG(d->A && d->B && d->C, "gemm: null operand pointer");
+  VQ3_CHECK_ARG(d->A && d->B && (d->C || ve), "gemm: null operand pointer");
   VQ3_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
   VQ3_CHECK_ARG(d->K % 8 == 0 && d->K >= 8, "gemm: K=%d must be a positive multiple of 8", d->K);
   VQ3_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm: lda=%d / ldb=%d must be multiples of 8", d->lda, d->ldb);
@@ -304,7 +305,7 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   VQ3_CHECK_ARG(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0), "gemm: A/B must be 16-byte aligned");
   VQ3_CHECK_ARG(d->sA1 % 8 == 0 && d->sA2 % 8 == 0 && d->sB1 % 8 == 0 && d->sB2 % 8 == 0,
                 "gemm: batch strides of A/B must be multiples of 8 elements");
-  VQ3_CHECK_ARG(d->ldc >= d->N, "gemm: ldc=%d < N=%d", d->ldc, d->N);
+  VQ3_CHECK_ARG(ve || d->ldc >= d->N, "gemm: ldc=%d < N=%d", d->ldc, d->N);
   VQ3_CHECK_ARG(d->nb1 >= 1 && d->nb2 >= 1 && d->b2divB >= 1, "gemm: bad batch dims");
   VQ3_CHECK_ARG((long)d->nb1 * d->nb2 <= 65535, "gemm: too many batches");
   VQ3_CHECK_ARG(d->act >= 0 && d->act <= 2, "gemm: bad activation %d", d->act);
@@ -321,8 +322,28 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
   p.nb2 = d->nb2; p.b2divB = d->b2divB;
   p.act = d->act; p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.alpha = d->alpha;
   p.kper = d->K; p.nsplit = 1;
+  p.epi = 0;
+  if (ve) {
+    VQ3_CHECK_ARG(ve->Q && ve->K && ve->V, "gemm_vit_qkv: null output pointer");
+    VQ3_CHECK_ARG(!d->transA && !d->transB && d->K % BK == 0 && !d->out_f32 && !d->accumulate && !d->R && !d->colscale && d->act == 0 &&
+                      d->ksplit <= 1 && d->nb1 == 1 && d->nb2 == 1,
+                  "gemm_vit_qkv: plain NT bf16 GEMM with K %% 64 == 0 and at most a bias");
+    VQ3_CHECK_ARG(ve->NH > 0 && d->N == 3 * ve->NH * 64 && ve->N > 0 && d->M % ve->N == 0, "gemm_vit_qkv: N must be 3*NH*64 and M a multiple of the group length");
+    VQ3_CHECK_ARG(!ve->use_norm || (ve->qn_w && ve->qn_b && ve->kn_w && ve->kn_b), "gemm_vit_qkv: norm weights missing");
+    VQ3_CHECK_ARG(!ve->use_rope || (ve->cos && ve->sin && ve->tokens_per_frame > 0 && ve->Wp > 0), "gemm_vit_qkv: rope tables missing");
+    VQ3_CHECK_ARG(((uintptr_t)ve->Q | (uintptr_t)ve->K | (uintptr_t)ve->V | (uintptr_t)ve->cos | (uintptr_t)ve->sin) % 16 == 0,
+                  "gemm_vit_qkv: Q/K/V and the rope tables must be 16-byte aligned");
+    p.epi = 1;
+    p.vit.Q = (bf16_t*)ve->Q; p.vit.K = (bf16_t*)ve->K; p.vit.V = (bf16_t*)ve->V;
+    p.vit.qn_w = ve->qn_w; p.vit.qn_b = ve->qn_b; p.vit.kn_w = ve->kn_w; p.vit.kn_b = ve->kn_b;
+    p.vit.cos = (const bf16_t*)ve->cos; p.vit.sin = (const bf16_t*)ve->sin;
+    p.vit.N = ve->N; p.vit.NH = ve->NH; p.vit.P = ve->tokens_per_frame; p.vit.patch_start = ve->patch_start; p.vit.Wp = ve->Wp;
+    p.vit.use_norm = ve->use_norm; p.vit.use_rope = ve->use_rope; p.vit.eps = ve->eps;
+    p.C = ve->Q; p.ldc = d->N;          // placeholders: the staged epilogue checks their alignment, nothing is stored through them
+    p.sC1 = p.sC2 = 0;
+  }
   const int esz = d->out_f32 ? 4 : 2;
-  bool vec = (d->ldc % 4 == 0) && (d->sC1 % 4 == 0) && (d->sC2 % 4 == 0) && ((uintptr_t)d->C % (4 * esz) == 0);
+  bool vec = (p.ldc % 4 == 0) && (p.sC1 % 4 == 0) && (p.sC2 % 4 == 0) && ((uintptr_t)p.C % (4 * esz) == 0);
   if (d->R) vec = vec && (d->ldr % 4 == 0) && (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0) && ((uintptr_t)d->R % (4 * esz) == 0);
   p.vec_ok = vec ? 1 : 0;
 
@@ -371,6 +392,7 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v2)");
     return 0;
   }
+  VQ3_CHECK_ARG(p.epi == 0, "gemm_vit_qkv: not available on the register-staged reference kernel (cfg -1)");
   if (!g_attr_set) {
     hipError_t e1 = hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     hipError_t e2 = hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
@@ -391,6 +413,13 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) {
     hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), SMEM_BYTES, s, p);
   VQ3_CHECK_LAUNCH("gemm_bf16_nt");
   return 0;
+}
+
+extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) { return gemm_dispatch(d, nullptr, stream); }
+
+extern "C" int vq3_gemm_vit_qkv(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* epi, void* stream) {
+  VQ3_CHECK_ARG(epi != nullptr, "gemm_vit_qkv: null epilogue descriptor");
+  return gemm_dispatch(d, epi, stream);
 }
 
 extern "C" int vq3_gemm_force_config(int32_t cfg) {

@@ -6,6 +6,16 @@
 
 namespace vq3gemm {
 
+// Fused epilogue of the VGGT qkv projection (vq3_gemm_vit_qkv): instead of C the tile is written as head-major Q, K, V with the
+// per-head LayerNorm and 2-D RoPE of the attention applied on the way (what vq3_vit_qkprep does in a pass of its own).
+struct VitQkvEpi {
+  bf16_t *Q, *K, *V;                       // [T / N, NH, N, 64]
+  const float *qn_w, *qn_b, *kn_w, *kn_b;  // [64] each (use_norm)
+  const bf16_t *cos, *sin;                 // [maxpos + 1, 32] (use_rope)
+  int N, NH, P, patch_start, Wp, use_norm, use_rope;
+  float eps;
+};
+
 struct GemmParams {
   const bf16_t* A;
   const bf16_t* B;
@@ -25,6 +35,8 @@ struct GemmParams {
   int accumulate;  // C += result
   int vec_ok;      // C (and R) rows are 16B (f32) / 8B (bf16) aligned for 4-wide stores
   float alpha;
+  int epi;         // 0 = C / R epilogue; 1 = VitQkvEpi (staged path only)
+  VitQkvEpi vit;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -256,6 +268,9 @@ __device__ __forceinline__ void stage_quad(const GemmParams& p, char* smem, int 
   *reinterpret_cast<u32x2*>(smem + cstage_off<BN>(ml, nl >> 3) + ((nl & 4) << 1)) = o;
 }
 
+template <int BM, int BN>
+__device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* smem, int m0, int n0, int tid, int nthreads);
+
 // phase 2 (after a workgroup barrier): `nthreads` threads (tid 0 .. nthreads-1) move the BM x BN image out as whole rows,
 // adding the residual (rounded, as PyTorch's bf16 add) and / or the old C (accumulate) on the way. Needs p.vec_ok, ldc % 8 == 0
 // and a 16-byte aligned C (checked by staged_ok on the host side of the kernel).
@@ -263,6 +278,10 @@ template <int BM, int BN>
 __device__ __forceinline__ void staged_store(const GemmParams& p, const char* smem, long coff, long roff, int m0, int n0, int tid,
                                              int nthreads) {
   constexpr int CPR = BN / 8;                  // 16-byte chunks per row
+  if (p.epi == 1) {
+    vit_qkv_store<BM, BN>(p, smem, m0, n0, tid, nthreads);
+    return;
+  }
   bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff;
   const bf16_t* R = p.R ? reinterpret_cast<const bf16_t*>(p.R) + roff : nullptr;
   const int rpp = nthreads / CPR;              // rows per pass
@@ -304,6 +323,78 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
         cp[k] = f2bf(x);
       }
     }
+  }
+}
+
+// epi == 1: the rows of the staged tile leave as Q / K / V [g, head, token, 64]. A thread owns 8 consecutive features of one
+// head; the head's 64 features are the 8 consecutive lanes around it (CPR is a multiple of 8 and tiles start at multiples of
+// 64 columns), so the LayerNorm sums are three xor-shuffles and the rotate-half partner (feature e ^ 16) is lane ^ 2.
+// Arithmetic and rounding points are those of vit_qkprep4_kernel (vggt.hip).
+template <int BM, int BN>
+__device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* smem, int m0, int n0, int tid, int nthreads) {
+  constexpr int CPR = BN / 8;
+  const VitQkvEpi& e = p.vit;
+  const int C = e.NH * 64;
+  const int rpp = nthreads / CPR;
+  const int c = tid % CPR;
+  const int n = n0 + c * 8;
+  if (n >= p.N) return;                                  // N = 3 C is a multiple of 64: a head is in or out as a whole
+  const int which = n / C, rem = n - which * C, head = rem >> 6, d0 = rem & 63;
+  const bool norm = which < 2 && e.use_norm, rope = which < 2 && e.use_rope;
+  float w8[8], b8[8];
+  if (norm) {
+    const float* wp = (which == 0 ? e.qn_w : e.kn_w) + d0;
+    const float* bp = (which == 0 ? e.qn_b : e.kn_b) + d0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w8[j] = wp[j]; b8[j] = bp[j]; }
+  }
+  bf16_t* base = which == 0 ? e.Q : (which == 1 ? e.K : e.V);
+  const bool neg = (d0 & 16) == 0;                       // (e & 16) == 0 -> rotate-half takes -x[e + 16]
+  for (int row = tid / CPR; row < BM; row += rpp) {
+    const int m = m0 + row;
+    if (m >= p.M) break;
+    const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { x[2 * k] = bf2f((bf16_t)(sv[k] & 0xffff)); x[2 * k + 1] = bf2f((bf16_t)(sv[k] >> 16)); }
+    const int g = m / e.N, tok = m - g * e.N;
+    if (norm) {
+      float sum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const float mean = sum * (1.f / 64.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { x[j] -= mean; sq = fmaf(x[j], x[j], sq); }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+      const float rs = rsqrtf(sq * (1.f / 64.f) + e.eps);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = rbf(x[j] * rs * w8[j] + b8[j]);
+    }
+    if (rope) {
+      const int tp = tok % e.P;
+      int py = 0, px = 0;
+      if (tp >= e.patch_start) {
+        py = (tp - e.patch_start) / e.Wp + 1;
+        px = (tp - e.patch_start) % e.Wp + 1;
+      }
+      const int pos = d0 < 32 ? py : px;
+      const u32x4 cr = *reinterpret_cast<const u32x4*>(e.cos + pos * 32 + (d0 & 31));
+      const u32x4 sr = *reinterpret_cast<const u32x4*>(e.sin + pos * 32 + (d0 & 31));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float cj = bf2f((bf16_t)((cr[j >> 1] >> ((j & 1) * 16)) & 0xffff));
+        const float sj = bf2f((bf16_t)((sr[j >> 1] >> ((j & 1) * 16)) & 0xffff));
+        const float pj = __shfl_xor(x[j], 2, 64);
+        const float rj = neg ? -pj : pj;
+        x[j] = rbf(rbf(x[j] * cj) + rbf(rj * sj));
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack2bf(x[2 * k], x[2 * k + 1]);
+    *reinterpret_cast<u32x4*>(base + (((long)g * e.NH + head) * e.N + tok) * 64 + d0) = o;
   }
 }
 

@@ -371,6 +371,43 @@ def vit_qkprep(qkv, N, NH, *, qn=None, kn=None, cos=None, sin=None, tokens_per_f
     return Q, K, V
 
 
+def linear_vit_qkv(x: torch.Tensor, w: torch.Tensor, bias, N: int, NH: int, *, qn=None, kn=None, cos=None, sin=None,
+                   tokens_per_frame=0, patch_start=0, Wp=0, eps=1e-5):
+    """vit_qkprep(linear(x, w, bias)) in ONE launch: x bf16 [T, C] @ w[3*NH*64, C]^T (+ bias) -> Q, K, V bf16 [T/N, NH, N, 64]
+    with the per-head LayerNorm / 2-D RoPE applied in the GEMM epilogue (vq3_gemm_vit_qkv); qkv is never materialised."""
+    _req(x, BF16, "vit_qkv x"); _req(w, BF16, "vit_qkv w")
+    assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] == w.shape[1]
+    T, K = x.shape
+    assert w.shape[0] == 3 * NH * 64 and T % N == 0
+    G = T // N
+    Q = torch.empty((G, NH, N, 64), device=x.device, dtype=BF16)
+    Kt = torch.empty_like(Q); V = torch.empty_like(Q)
+    d = GemmDesc()
+    d.A = x.data_ptr(); d.B = w.data_ptr(); d.C = None
+    d.bias = _p(bias); d.colscale = None; d.R = None
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = T, 3 * NH * 64, K, x.stride(0), w.stride(0), 3 * NH * 64, 0
+    d.nb1 = d.nb2 = d.b2divB = 1
+    d.alpha = 1.0
+    e = _lib.VitQkvEpilogue()
+    e.Q, e.K, e.V = Q.data_ptr(), Kt.data_ptr(), V.data_ptr()
+    use_norm, use_rope = qn is not None, cos is not None
+    if use_norm:
+        e.qn_w, e.qn_b, e.kn_w, e.kn_b = qn[0].data_ptr(), qn[1].data_ptr(), kn[0].data_ptr(), kn[1].data_ptr()
+    if use_rope:
+        e.cos, e.sin = cos.data_ptr(), sin.data_ptr()
+    e.N, e.NH, e.tokens_per_frame, e.patch_start, e.Wp = N, NH, tokens_per_frame, patch_start, Wp
+    e.use_norm, e.use_rope, e.eps = int(use_norm), int(use_rope), eps
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().vq3_gemm_vit_qkv(d, e, _stream()), "vq3_gemm_vit_qkv")
+        e1.record()
+        GEMM_PROFILE.append((2.0 * T * d.N * K, 2.0 * T * K + 2.0 * d.N * K + 2.0 * T * d.N, e0, e1, (T, d.N, K, 1)))
+    else:
+        check(_lib.load().vq3_gemm_vit_qkv(d, e, _stream()), "vq3_gemm_vit_qkv")
+    return Q, Kt, V
+
+
 def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(Q K^T / 8) V for Q,K,V bf16 [G, NH, N, 64] -> token-major [G*N, NH*64]."""
     _req(Q, BF16, "flash Q"); _req(K, BF16, "flash K"); _req(V, BF16, "flash V")

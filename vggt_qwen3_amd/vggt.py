@@ -205,12 +205,12 @@ class Aggregator(nn.Module):
     def _block(self, x, w, N, *, rope, eps, P, Wp):
         NH = self.num_heads
         xn, _ = ops.layernorm_fwd(x, w["n1"][0], w["n1"][1], eps)
-        qkv = ops.linear(xn, w["qkv_w"], bias=w["qkv_b"])
+        # qkv projection with the head split, q/k LayerNorm and 2-D RoPE fused into the GEMM epilogue (one launch, no [T, 3C] tensor)
         if rope is not None:
-            Q, K, V = ops.vit_qkprep(qkv, N, NH, qn=w["qn"], kn=w["kn"], cos=rope[0], sin=rope[1], tokens_per_frame=P,
-                                     patch_start=self.patch_start_idx, Wp=Wp, eps=1e-5)
+            Q, K, V = ops.linear_vit_qkv(xn, w["qkv_w"], w["qkv_b"], N, NH, qn=w["qn"], kn=w["kn"], cos=rope[0], sin=rope[1],
+                                         tokens_per_frame=P, patch_start=self.patch_start_idx, Wp=Wp, eps=1e-5)
         else:
-            Q, K, V = ops.vit_qkprep(qkv, N, NH)
+            Q, K, V = ops.linear_vit_qkv(xn, w["qkv_w"], w["qkv_b"], N, NH)
         o = ops.flash_attn(Q, K, V)
         x = ops.linear(o, w["proj_w"], bias=w["proj_b"], colscale=w["ls1"], residual=x)
         xn2, _ = ops.layernorm_fwd(x, w["n2"][0], w["n2"][1], eps)
