@@ -95,6 +95,13 @@ int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* r
 /* out_bf16[c] (+)= sum_{r < nrows} part[r*cols + c]: column sum of a partial slab into a (bf16) gradient vector. */
 int vq3_colsum_f32_to_bf16(const float* part, int32_t nrows, int32_t cols, void* out_bf16, int32_t accumulate,
                            void* stream);
+/* Up to 8 of the above in one launch (a decoder layer's four norm-weight gradients). `jobs` is a HOST array. */
+typedef struct vq3_colsum_job {
+  const float* part;
+  void* out_bf16;
+  int32_t nrows, cols, accumulate;
+} vq3_colsum_job;
+int vq3_colsum_multi(const vq3_colsum_job* jobs, int32_t njobs, void* stream);
 
 /* torch.nn.LayerNorm (projector_perceiver.py:39-40; VGGT Block.norm1/norm2, q_norm/k_norm).
  * x: bf16 (x_f32=0) or f32 (x_f32=1) [rows, cols]; w,b f32 [cols]; y_bf16 and/or y_f32 may be NULL.
@@ -132,11 +139,12 @@ int vq3_qwen_qkprep_fwd(const void* qkv, const void* q_w, const void* k_w, const
                         void* K, void* V, float* q_rstd, float* k_rstd, int32_t B, int32_t L, int32_t Hq, int32_t Hkv,
                         int32_t D, float eps, void* stream);
 /* Backward: dQ,dK,dV (layouts as above) + saved qkv, rstd -> dqkv bf16 [B*L,(Hq+2Hkv)*D];
- * dq_w_part, dk_w_part f32 [B*L, D]: one partial row per token (plain stores); reduce with vq3_colsum_f32_to_bf16. */
+ * dq_w_part, dk_w_part f32 [B*L, D]: one partial row per token (plain stores); reduce with vq3_colsum_f32_to_bf16.
+ * kv_parts: dK and dV are [kv_parts, B, Hkv, L, D] partial slabs (vq3_qwen_flash_bwd), summed here in f32. */
 int vq3_qwen_qkprep_bwd(const void* dQ, const void* dK, const void* dV, const void* qkv, const void* q_w,
                         const void* k_w, const void* cos, const void* sin, const float* q_rstd, const float* k_rstd,
-                        void* dqkv, float* dq_w_part, float* dk_w_part, int32_t B, int32_t L, int32_t Hq, int32_t Hkv,
-                        int32_t D, void* stream);
+                        void* dqkv, float* dq_w_part, float* dk_w_part, int32_t kv_parts, int32_t B, int32_t L, int32_t Hq,
+                        int32_t Hkv, int32_t D, void* stream);
 
 /* Masked softmax over the last dim. S f32 [nb, Lq, ldS] -> P bf16 [nb, Lq, ldP]; columns >= Lk (up to ldP) zeroed.
  * causal != 0: key j visible to query i iff j <= i. keymask u8 [nb / heads_per_mask, Lk] or NULL (1 = visible).
@@ -314,11 +322,13 @@ int vq3_gemm_fp8_nt(const void* Xq, const float* x_scale, const void* Wq, const 
  * log2-domain log-sum-exp of the scaled scores (+inf for rows with no visible key; their O is 0). */
 int vq3_qwen_flash_fwd(const void* Q, const void* K, const void* V, const void* keymask, void* O, float* LSE, int32_t B,
                        int32_t L, int32_t Hq, int32_t Hkv, int32_t head_dim, int64_t ldo, float scale, void* stream);
-/* dQ [B,Hq,L,128], dK/dV [B,Hkv,L,128] bf16 (summed over the query heads of each kv head in registers/LDS, no atomics).
- * Delta f32 [B,Hq,L] is scratch (rowsum(dO * O), written by the dQ pass, read by the dK/dV pass). */
+/* dQ [B,Hq,L,128]; dK/dV bf16 [kv_parts, B,Hkv,L,128]: kv_parts (1..4) workgroups share a key tile, each walking every
+ * kv_parts-th query block and writing its own partial slab (summed over the query heads of each kv head in registers/LDS, no
+ * atomics); the consumer (vq3_qwen_qkprep_bwd) adds the slabs. Key tiles without an attended key are skipped in all passes
+ * (exact zeros). Delta f32 [B,Hq,L] is scratch (rowsum(dO * O), written by the dQ pass, read by the dK/dV pass). */
 int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* keymask, const void* O, const void* dO,
-                       const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t B, int32_t L, int32_t Hq,
-                       int32_t Hkv, int32_t head_dim, int64_t ldo, int64_t lddo, float scale, void* stream);
+                       const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t kv_parts, int32_t B, int32_t L,
+                       int32_t Hq, int32_t Hkv, int32_t head_dim, int64_t ldo, int64_t lddo, float scale, void* stream);
 
 /* Benchmarking / test hook for vq3_gemm_bf16_nt's kernel choice on NT, K % 64 == 0 shapes: cfg = -3 restores the automatic
  * choice (the default), -1 the register-staged reference kernel, 0..14 a gemm2.hip tile configuration, 20 / 21 / 22 the

@@ -285,6 +285,11 @@ def test_qkprep_fwd_bwd(ops):
     dqkv = ops.qwen_qkprep_bwd(dQ, dK, dV, qkv, qw, kw, cos, sin, qr, kr, dqw, dkw, False, B, L, Hq, Hkv, D)
     assert _relerr(dqkv, xa.grad) < 4e-3, _relerr(dqkv, xa.grad)
     assert _relerr(dqw, qwa.grad) < 4e-3 and _relerr(dkw, kwa.grad) < 4e-3
+    # dK / dV handed over as two partial slabs (what the split dK/dV attention pass writes): same result
+    half = lambda t: torch.stack([(t.float() * 0.5).to(BF16), (t.float() - (t.float() * 0.5).to(BF16).float()).to(BF16)])
+    dqw2 = torch.zeros(D, device="cuda", dtype=BF16); dkw2 = torch.zeros(D, device="cuda", dtype=BF16)
+    dqkv2 = ops.qwen_qkprep_bwd(dQ, half(dK), half(dV), qkv, qw, kw, cos, sin, qr, kr, dqw2, dkw2, False, B, L, Hq, Hkv, D)
+    assert _relerr(dqkv2, dqkv) < 4e-3 and _relerr(dkw2, dkw) < 4e-3
 
 
 def test_softmax_fwd_bwd(ops):
@@ -452,7 +457,13 @@ def test_qwen_flash_attention_fwd_bwd(ops, B, Hkv, L, pad, G):
             mask[b, : 2 + 5 * b] = 0
     scale = D ** -0.5
     O, lse = ops.qwen_flash_fwd(Q, K, V, mask, B, L, Hq, Hkv, D, scale)
-    dQ, dK, dV = ops.qwen_flash_bwd(Q, K, V, mask, O, dO, lse, B, L, Hq, Hkv, D, scale)
+    dQ, dK, dV = ops.qwen_flash_bwd(Q, K, V, mask, O, dO, lse, B, L, Hq, Hkv, D, scale, kv_parts=1)
+    # the split form (partial dK / dV slabs, one per group of query blocks) must add up to the same gradients
+    for parts in (2, 3):
+        dQp, dKp, dVp = ops.qwen_flash_bwd(Q, K, V, mask, O, dO, lse, B, L, Hq, Hkv, D, scale, kv_parts=parts)
+        assert dKp.shape == (parts, B, Hkv, L, D) and torch.equal(dQp, dQ)
+        for a, b in ((dKp, dK), (dVp, dV)):
+            assert ((a.float().sum(0) - b.float()).norm() / (b.float().norm() + 1e-9)).item() < 1e-2
     q, k, v = (t.float().detach().requires_grad_(True) for t in (Q, K, V))
     ke, ve = k.repeat_interleave(G, dim=1), v.repeat_interleave(G, dim=1)
     s = (q @ ke.transpose(2, 3)) * scale

@@ -35,6 +35,10 @@ class VitQkvEpilogue(C.Structure):
                 ("Wp", i32), ("use_norm", i32), ("use_rope", i32), ("eps", f32)]
 
 
+class ColsumJob(C.Structure):
+    _fields_ = [("part", c_p), ("out_bf16", c_p), ("nrows", i32), ("cols", i32), ("accumulate", i32)]
+
+
 class ImageDesc(C.Structure):
     _fields_ = [("src", c_p), ("h", i32), ("w", i32), ("pitch", i32), ("ksize_h", i32), ("ksize_v", i32),
                 ("kh_off", i32), ("kv_off", i32), ("bh_off", i32), ("bv_off", i32), ("crop_x", i32), ("crop_y", i32)]
@@ -50,6 +54,7 @@ SIGNATURES = {
     "vq3_rmsnorm_fwd": [c_p, c_p, c_p, c_p, i64, i32, i64, i64, f32, c_p],
     "vq3_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "vq3_colsum_f32_to_bf16": [c_p, i32, i32, c_p, i32, c_p],
+    "vq3_colsum_multi": [C.POINTER(ColsumJob), i32, c_p],
     "vq3_layernorm_fwd": [c_p, c_p, i32, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "vq3_silu_mul_fwd": [c_p, c_p, i64, i32, c_p],
     "vq3_silu_mul_bwd": [c_p, c_p, c_p, i64, i32, c_p],
@@ -57,7 +62,7 @@ SIGNATURES = {
     "vq3_cast": [c_p, c_p, i64, i32, c_p],
     "vq3_f32_to_bf16_acc": [c_p, c_p, i64, i32, c_p],
     "vq3_qwen_qkprep_fwd": [c_p] * 10 + [i32, i32, i32, i32, i32, f32, c_p],
-    "vq3_qwen_qkprep_bwd": [c_p] * 13 + [i32, i32, i32, i32, i32, c_p],
+    "vq3_qwen_qkprep_bwd": [c_p] * 13 + [i32, i32, i32, i32, i32, i32, c_p],
     "vq3_softmax_fwd": [c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, i32, c_p],
     "vq3_softmax_bwd": [c_p, c_p, c_p, i32, i32, i32, i32, i32, f32, c_p],
     "vq3_embed_splice_fwd": [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p],
@@ -83,7 +88,7 @@ SIGNATURES = {
     "vq3_quant_fp8_rows": [c_p, i64, i64, i32, c_p, i64, c_p, c_p],
     "vq3_gemm_fp8_nt": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i64, i64, c_p],
     "vq3_qwen_flash_fwd": [c_p] * 6 + [i32, i32, i32, i32, i32, i64, f32, c_p],
-    "vq3_qwen_flash_bwd": [c_p] * 11 + [i32, i32, i32, i32, i32, i64, i64, f32, c_p],
+    "vq3_qwen_flash_bwd": [c_p] * 11 + [i32, i32, i32, i32, i32, i32, i64, i64, f32, c_p],
     "vq3_gemm_force_config": [i32],
     "vq3_pack_tokens": [c_p, c_p, c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p, c_p],
 }

@@ -157,6 +157,44 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
   }
 }
 
+// Several column sums in ONE launch (blockIdx.y = job): a decoder layer's backward leaves four partial slabs (two RMSNorm
+// weights, q_norm, k_norm) - four 6 us launches and their boundaries become one.
+struct ColsumJobs {
+  const float* part[8];
+  bf16_t* out[8];
+  int nrows[8], cols[8], accumulate[8];
+};
+__global__ __launch_bounds__(1024) void colsum_multi_kernel(ColsumJobs jobs) {
+  __shared__ float red[16][64];
+  const int job = blockIdx.y;
+  const float* __restrict__ part = jobs.part[job];
+  const int nrows = jobs.nrows[job], cols = jobs.cols[job];
+  if ((int)blockIdx.x * 64 >= cols) return;
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    int r = rg;
+    for (; r + 48 < nrows; r += 64) {
+      a0 += part[(long)r * cols + c];
+      a1 += part[(long)(r + 16) * cols + c];
+      a2 += part[(long)(r + 32) * cols + c];
+      a3 += part[(long)(r + 48) * cols + c];
+    }
+    for (; r < nrows; r += 16) a0 += part[(long)r * cols + c];
+  }
+  red[rg][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[i][lane];
+    bf16_t* out = jobs.out[job];
+    if (jobs.accumulate[job]) v += bf2f(out[c]);
+    out[c] = f2bf(v);
+  }
+}
+
 // ---------------------------------------------------------------- LayerNorm forward
 template <bool X_F32, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ res_,
@@ -313,6 +351,21 @@ extern "C" int vq3_layernorm_fwd(const void* x, const void* res, int32_t x_f32, 
   }
 #undef VQ3_LN
   VQ3_CHECK_LAUNCH("layernorm_fwd");
+  return 0;
+}
+
+extern "C" int vq3_colsum_multi(const vq3_colsum_job* jobs, int32_t njobs, void* stream) {
+  VQ3_CHECK_ARG(jobs && njobs >= 1 && njobs <= 8, "colsum_multi: 1..8 jobs");
+  ColsumJobs j;
+  int maxcols = 0;
+  for (int i = 0; i < njobs; ++i) {
+    VQ3_CHECK_ARG(jobs[i].part && jobs[i].out_bf16 && jobs[i].nrows > 0 && jobs[i].cols > 0, "colsum_multi: bad job %d", i);
+    j.part[i] = jobs[i].part; j.out[i] = (bf16_t*)jobs[i].out_bf16;
+    j.nrows[i] = jobs[i].nrows; j.cols[i] = jobs[i].cols; j.accumulate[i] = jobs[i].accumulate;
+    maxcols = jobs[i].cols > maxcols ? jobs[i].cols : maxcols;
+  }
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3((maxcols + 63) / 64, njobs), dim3(1024), 0, (hipStream_t)stream, j);
+  VQ3_CHECK_LAUNCH("colsum_multi");
   return 0;
 }
 

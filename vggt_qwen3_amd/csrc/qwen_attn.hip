@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
                                                          const float* __restrict__ q_rstd,
                                                          const float* __restrict__ k_rstd, bf16_t* __restrict__ dqkv,
                                                          float* __restrict__ dq_w, float* __restrict__ dk_w, int L,
-                                                         int Hq, int Hkv) {
+                                                         int Hq, int Hkv, int kv_parts, long part_stride) {
   __shared__ float dw_s[2][D];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
@@ -102,8 +102,19 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
     if (h >= Hq + Hkv) {
       const int hv = h - Hq - Hkv;
       const bf16_t* g = dV + (((long)b * Hkv + hv) * L + l) * D;
-      *reinterpret_cast<uint32_t*>(drow + h * D + e) = *reinterpret_cast<const uint32_t*>(g + e);
-      *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = *reinterpret_cast<const uint32_t*>(g + e + 64);
+      if (kv_parts == 1) {
+        *reinterpret_cast<uint32_t*>(drow + h * D + e) = *reinterpret_cast<const uint32_t*>(g + e);
+        *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = *reinterpret_cast<const uint32_t*>(g + e + 64);
+      } else {                                   // partial slabs of the split dK/dV pass: summed in f32, rounded once
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+        for (int sp = 0; sp < kv_parts; ++sp) {
+          float t0, t1, u0, u1;
+          ld2(g + sp * part_stride + e, t0, t1); ld2(g + sp * part_stride + e + 64, u0, u1);
+          a0 += t0; a1 += t1; b0 += u0; b1 += u1;
+        }
+        *reinterpret_cast<uint32_t*>(drow + h * D + e) = pack2bf(a0, a1);
+        *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = pack2bf(b0, b1);
+      }
       continue;
     }
     const bool isq = h < Hq;
@@ -112,6 +123,13 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
     const float rs = isq ? q_rstd[t * Hq + h] : k_rstd[t * Hkv + (h - Hq)];
     float dy1[2], dy2[2], x1[2], x2[2], w1[2], w2[2];
     ld2(g + e, dy1[0], dy1[1]); ld2(g + e + 64, dy2[0], dy2[1]);
+    if (!isq) {
+      for (int sp = 1; sp < kv_parts; ++sp) {    // the other partial slabs of dK
+        float t0, t1, u0, u1;
+        ld2(g + sp * part_stride + e, t0, t1); ld2(g + sp * part_stride + e + 64, u0, u1);
+        dy1[0] += t0; dy1[1] += t1; dy2[0] += u0; dy2[1] += u1;
+      }
+    }
     ld2(row + h * D + e, x1[0], x1[1]); ld2(row + h * D + e + 64, x2[0], x2[1]);
     ld2(w + e, w1[0], w1[1]); ld2(w + e + 64, w2[0], w2[1]);
     float dn1[2], dn2[2], xh1[2], xh2[2], g1[2], g2[2], part = 0.f;
@@ -165,16 +183,16 @@ extern "C" int vq3_qwen_qkprep_fwd(const void* qkv, const void* q_w, const void*
 
 extern "C" int vq3_qwen_qkprep_bwd(const void* dQ, const void* dK, const void* dV, const void* qkv, const void* q_w,
                                    const void* k_w, const void* cos, const void* sin, const float* q_rstd,
-                                   const float* k_rstd, void* dqkv, float* dq_w_f32, float* dk_w_f32, int32_t B,
-                                   int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, void* stream) {
+                                   const float* k_rstd, void* dqkv, float* dq_w_f32, float* dk_w_f32, int32_t kv_parts,
+                                   int32_t B, int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, void* stream) {
   VQ3_CHECK_ARG(dQ && dK && dV && qkv && q_w && k_w && cos && sin && q_rstd && k_rstd && dqkv && dq_w_f32 && dk_w_f32,
                 "qkprep_bwd: null pointer");
   VQ3_CHECK_ARG(Dh == D, "qkprep_bwd: head_dim must be %d, got %d", D, Dh);
-  VQ3_CHECK_ARG(B > 0 && L > 0 && Hq > 0 && Hkv > 0, "qkprep_bwd: bad shape");
+  VQ3_CHECK_ARG(B > 0 && L > 0 && Hq > 0 && Hkv > 0 && kv_parts >= 1 && kv_parts <= 4, "qkprep_bwd: bad shape");
   hipLaunchKernelGGL(qkprep_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dQ,
                      (const bf16_t*)dK, (const bf16_t*)dV, (const bf16_t*)qkv, (const bf16_t*)q_w, (const bf16_t*)k_w,
                      (const bf16_t*)cos, (const bf16_t*)sin, q_rstd, k_rstd, (bf16_t*)dqkv, dq_w_f32, dk_w_f32, L, Hq,
-                     Hkv);
+                     Hkv, (int)kv_parts, (long)B * Hkv * L * D);
   VQ3_CHECK_LAUNCH("qkprep_bwd");
   return 0;
 }

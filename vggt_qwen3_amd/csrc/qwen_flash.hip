@@ -306,14 +306,21 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* _
                                                                 const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
                                                                 const float* __restrict__ Delta, bf16_t* __restrict__ dK,
                                                                 bf16_t* __restrict__ dV, int L, int Hq, int Hkv, long lddo,
-                                                                float scale) {
+                                                                float scale, int S, long part_stride) {
   __shared__ float red[4][16][64];     // one f32x16 accumulator block per wave
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int nkb = (L + 31) / 32;
-  const int nbh = gridDim.x / nkb;
-  const int kb = blockIdx.x / nbh;                              // kb = 0 walks the most q-blocks: heaviest first
-  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
+  // S workgroups share a key tile: workgroup sp takes the q-blocks kb + sp, kb + sp + S, ... and writes its own partial dK / dV
+  // slab (summed by the q/k-prep backward, which reads them anyway) - the q-block walk of key tile 0 is the longest serial
+  // chain of the layer's backward (7 steps at L = 200), this cuts it to ceil(7 / S)
+  const int sp = blockIdx.x % S;
+  const int bid = blockIdx.x / S;
+  const int nbh = (gridDim.x / S) / nkb;
+  const int kb = bid / nbh;                                     // kb = 0 walks the most q-blocks: heaviest first
+  dK += sp * part_stride;
+  dV += sp * part_stride;
+  const int hk = (bid % nbh) % Hkv, b = (bid % nbh) / Hkv;
   const int G = Hq / Hkv, hq = hk * G + g;
   const bool active = g < G;
   const int key = kb * 32 + r, kc = key < L ? key : L - 1;
@@ -348,10 +355,10 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* _
     const bf16_t* dOh = dO + (long)b * L * lddo + (long)hq * D;
     const float* lse_h = LSE + ((long)b * Hq + hq) * L;
     const float* del_h = Delta + ((long)b * Hq + hq) * L;
-    for (int qb = kb; qb < nkb; ++qb) {
+    for (int qb = kb + sp; qb < nkb; qb += S) {
       // every load of the tile is issued before its first use: one memory round trip per tile instead of four; the next
       // q-block's Q and dO tiles are touched into L2 meanwhile
-      const int nq = qb + 1 < nkb ? qb + 1 : qb;
+      const int nq = qb + S < nkb ? qb + S : qb;
       const unsigned tq = touch_tile(Qh, D, nq * 32, L - 1), tdo = touch_tile(dOh, lddo, nq * 32, L - 1);
       bf16x8 qrow[8], dorow[8];
       u32x2 gdo[2][8], gq[2][8];
@@ -452,20 +459,21 @@ extern "C" int vq3_qwen_flash_fwd(const void* Q, const void* K, const void* V, c
 }
 
 extern "C" int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* keymask, const void* O,
-                                  const void* dO, const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t B,
-                                  int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, int64_t lddo, float scale,
-                                  void* stream) {
+                                  const void* dO, const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t kv_parts,
+                                  int32_t B, int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, int64_t lddo,
+                                  float scale, void* stream) {
   VQ3_CHECK_ARG(Q && K && V && keymask && O && dO && LSE && Delta && dQ && dK && dV, "qwen_flash_bwd: null pointer");
   if (flash_check("qwen_flash_bwd", B, L, Hq, Hkv, Dh)) return 1;
   VQ3_CHECK_ARG(ldo >= (long)Hq * D && lddo >= (long)Hq * D && ldo % 8 == 0 && lddo % 8 == 0, "qwen_flash_bwd: bad row strides");
+  VQ3_CHECK_ARG(kv_parts >= 1 && kv_parts <= 4, "qwen_flash_bwd: kv_parts must be 1..4");
   const int nqb = (L + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(qwen_flash_bwd_dq_kernel, dim3(B * Hkv * nqb), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
                      (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)O, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dQ, L,
                      Hq, Hkv, (long)ldo, (long)lddo, scale);
-  hipLaunchKernelGGL(qwen_flash_bwd_dkv_kernel, dim3(B * Hkv * nqb), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
+  hipLaunchKernelGGL(qwen_flash_bwd_dkv_kernel, dim3(B * Hkv * nqb * kv_parts), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
                      (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dK, (bf16_t*)dV, L, Hq,
-                     Hkv, (long)lddo, scale);
+                     Hkv, (long)lddo, scale, (int)kv_parts, (long)B * Hkv * L * D);
   VQ3_CHECK_LAUNCH("qwen_flash_bwd");
   return 0;
 }

@@ -110,8 +110,22 @@ def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, want_rstd: bool = 
     return (y, rstd) if want_rstd else y
 
 
-def rmsnorm_bwd(dy, x, w, rstd, dres, dw_out: torch.Tensor, accumulate: bool, eps: float = 0.0):
-    """Returns dx (bf16) = [dres +] d/dx; dw_out (bf16 [cols]) (+)= the weight gradient (partial slab + column sum)."""
+def colsum_flush(jobs: list) -> None:
+    """Run the deferred column sums (part f32 [nrows, cols] -> out bf16 [cols] (+)=) collected in `jobs`, 8 per launch."""
+    lib = _lib.load()
+    for i in range(0, len(jobs), 8):
+        chunk = jobs[i:i + 8]
+        arr = (_lib.ColsumJob * len(chunk))()
+        for k, (part, nrows, cols, out, acc) in enumerate(chunk):
+            arr[k].part, arr[k].out_bf16 = part.data_ptr(), out.data_ptr()
+            arr[k].nrows, arr[k].cols, arr[k].accumulate = nrows, cols, 1 if acc else 0
+        check(lib.vq3_colsum_multi(arr, len(chunk), _stream()), "vq3_colsum_multi")
+    jobs.clear()
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres, dw_out: torch.Tensor, accumulate: bool, eps: float = 0.0, defer: Optional[list] = None):
+    """Returns dx (bf16) = [dres +] d/dx; dw_out (bf16 [cols]) (+)= the weight gradient (partial slab + column sum).
+    defer: a list - the column sum is appended to it instead of launched (colsum_flush runs a layer's sums in one launch)."""
     _req(dy, BF16, "rmsnorm_bwd dy"); _req(x, BF16, "rmsnorm_bwd x"); _req(dw_out, BF16, "rmsnorm_bwd dw")
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
     rows, cols = x.shape
@@ -121,6 +135,9 @@ def rmsnorm_bwd(dy, x, w, rstd, dres, dw_out: torch.Tensor, accumulate: bool, ep
     lib = _lib.load()
     check(lib.vq3_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres), dx.data_ptr(),
                               part.data_ptr(), rows, cols, eps, _stream()), "vq3_rmsnorm_bwd")
+    if defer is not None:
+        defer.append((part, nblk, cols, dw_out, accumulate))
+        return dx
     check(lib.vq3_colsum_f32_to_bf16(part.data_ptr(), nblk, cols, dw_out.data_ptr(), 1 if accumulate else 0,
                                      _stream()), "vq3_colsum_f32_to_bf16")
     return dx
@@ -234,17 +251,24 @@ def qwen_qkprep_fwd(qkv, q_w, k_w, cos, sin, B, L, Hq, Hkv, D, eps, want_rstd=Tr
     return Q, K, V, qr, kr
 
 
-def qwen_qkprep_bwd(dQ, dK, dV, qkv, q_w, k_w, cos, sin, qr, kr, dq_w_out, dk_w_out, accumulate, B, L, Hq, Hkv, D):
+def qwen_qkprep_bwd(dQ, dK, dV, qkv, q_w, k_w, cos, sin, qr, kr, dq_w_out, dk_w_out, accumulate, B, L, Hq, Hkv, D,
+                    defer: Optional[list] = None):
     """dq_w_out / dk_w_out: bf16 [D] gradient vectors, (+)= per `accumulate`."""
     for t in (dQ, dK, dV, qkv):
         _req(t, BF16, "qkprep_bwd"); assert t.is_contiguous()
+    kv_parts = dK.shape[0] if dK.dim() == 5 else 1            # [parts, B, Hkv, L, D] partial slabs of the split dK/dV pass
+    assert dV.shape == dK.shape
     dqkv = torch.empty_like(qkv)
     part = torch.empty((2, B * L, D), device=qkv.device, dtype=F32)
     lib = _lib.load()
     check(lib.vq3_qwen_qkprep_bwd(dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), qkv.data_ptr(), q_w.data_ptr(),
                                   k_w.data_ptr(), cos.data_ptr(), sin.data_ptr(), qr.data_ptr(), kr.data_ptr(),
-                                  dqkv.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), B, L, Hq, Hkv, D,
+                                  dqkv.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), kv_parts, B, L, Hq, Hkv, D,
                                   _stream()), "vq3_qwen_qkprep_bwd")
+    if defer is not None:
+        defer.append((part[0], B * L, D, dq_w_out, accumulate))
+        defer.append((part[1], B * L, D, dk_w_out, accumulate))
+        return dqkv
     acc = 1 if accumulate else 0
     check(lib.vq3_colsum_f32_to_bf16(part[0].data_ptr(), B * L, D, dq_w_out.data_ptr(), acc, _stream()), "colsum dq_w")
     check(lib.vq3_colsum_f32_to_bf16(part[1].data_ptr(), B * L, D, dk_w_out.data_ptr(), acc, _stream()), "colsum dk_w")
@@ -528,18 +552,22 @@ def qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, scale):
     return O, lse
 
 
-def qwen_flash_bwd(Q, K, V, keymask, O, dO, lse, B, L, Hq, Hkv, D, scale):
-    """O, dO: bf16 [B*L, Hq*D] token-major. -> dQ [B,Hq,L,D], dK, dV [B,Hkv,L,D] bf16."""
+def qwen_flash_bwd(Q, K, V, keymask, O, dO, lse, B, L, Hq, Hkv, D, scale, kv_parts: Optional[int] = None):
+    """O, dO: bf16 [B*L, Hq*D] token-major. -> dQ [B,Hq,L,D]; dK, dV bf16 [kv_parts, B,Hkv,L,D] partial slabs (kv_parts = 1 gives
+    plain [B,Hkv,L,D], the default); qwen_qkprep_bwd adds the slabs. Worth it when most key tiles are padding (Qwen3ForCausalLM.forward_hidden decides)."""
     _req(O, BF16, "flash_bwd O"); _req(dO, BF16, "flash_bwd dO"); _req(lse, F32, "flash_bwd lse")
     assert O.shape == (B * L, Hq * D) and dO.shape == O.shape and O.stride(1) == 1 and dO.stride(1) == 1
     dev = Q.device
+    if kv_parts is None:
+        kv_parts = 1
     dQ = torch.empty((B, Hq, L, D), device=dev, dtype=BF16)
-    dK = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
-    dV = torch.empty((B, Hkv, L, D), device=dev, dtype=BF16)
+    kv_shape = (B, Hkv, L, D) if kv_parts == 1 else (kv_parts, B, Hkv, L, D)
+    dK = torch.empty(kv_shape, device=dev, dtype=BF16)
+    dV = torch.empty(kv_shape, device=dev, dtype=BF16)
     delta = torch.empty(B * Hq * L + 4, device=dev, dtype=F32)
     check(_lib.load().vq3_qwen_flash_bwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
                                          dO.data_ptr(), lse.data_ptr(), delta.data_ptr(), dQ.data_ptr(), dK.data_ptr(),
-                                         dV.data_ptr(), B, L, Hq, Hkv, D, O.stride(0), dO.stride(0), scale, _stream()),
+                                         dV.data_ptr(), kv_parts, B, L, Hq, Hkv, D, O.stride(0), dO.stride(0), scale, _stream()),
           "vq3_qwen_flash_bwd")
     return dQ, dK, dV
 

@@ -390,6 +390,17 @@ class Qwen3ForCausalLM(nn.Module):
             inputs_embeds = torch.cat([inputs_embeds, inputs_embeds.new_zeros((B, L - L0, H))], dim=1)
             attention_mask = torch.cat([attention_mask, attention_mask.new_zeros((B, L - L0))], dim=1)
         keymask = (attention_mask != 0).to(torch.uint8).contiguous()
+        kv_parts = 1
+        if save and self._flash and L >= 128:
+            # The dK/dV pass walks, per 32-key tile, every query block behind it - its longest serial chain. Key tiles without an
+            # attended key leave at once, so when most of a padded batch's tiles are empty there are CUs to spare and two
+            # workgroups share each live tile's walk (partial slabs, summed by the q/k-prep backward); with dense masks every
+            # workgroup is live and splitting would only add rounds. One tiny host read per forward decides.
+            nkb = (L + 31) // 32
+            pad = nkb * 32 - L
+            km = torch.nn.functional.pad(keymask, (0, pad)) if pad else keymask
+            live = int(km.view(B, nkb, 32).any(-1).sum().item())
+            kv_parts = 2 if live * 2 <= B * nkb else 1
         h = inputs_embeds.reshape(B * L, H)
         saved: List[dict] = []
         for i in range(c.num_hidden_layers):
@@ -405,7 +416,7 @@ class Qwen3ForCausalLM(nn.Module):
                 ctx.update(h_in=h, r1=r1, xn1=xn1, h_mid=h_mid, r2=r2, xn2=xn2, gu=gu, act=act)
                 saved.append(ctx)
             h = h_out
-        return h, {"layers": saved, "B": B, "L": L, "L0": L0, "keymask": keymask}
+        return h, {"layers": saved, "B": B, "L": L, "L0": L0, "keymask": keymask, "kv_parts": kv_parts}
 
     @staticmethod
     def label_rows(labels: torch.Tensor):
@@ -526,6 +537,7 @@ class Qwen3ForCausalLM(nn.Module):
         H, D = c.hidden_size, self.D
         dev = dh.device
         cos, sin = self.rope(L)
+        norm_jobs: list = []       # the layer's four norm-weight column sums, run in one launch at its end
         for i in reversed(range(c.num_hidden_layers)):
             ctx = saved["layers"][i]
             # down_proj
@@ -535,7 +547,7 @@ class Qwen3ForCausalLM(nn.Module):
             d_xn2 = self._dgrad(dgu, f"l{i}.gu")
             self._wgrad(f"l{i}.gu", dgu, ctx["xn2"], accumulate)
             dh_mid = ops.rmsnorm_bwd(d_xn2, ctx["h_mid"], self._w[f"l{i}.ln2"], ctx["r2"], dh, self._g[f"l{i}.ln2"],
-                                     accumulate)
+                                     accumulate, defer=norm_jobs)
             # o_proj
             # d(attention out) head-major [B, Hq, L, D]: one batch per (b, head) over the column block of W_o
             Wo = self._w[f"l{i}.o"]
@@ -543,7 +555,7 @@ class Qwen3ForCausalLM(nn.Module):
                 d_ao = self._dgrad(dh_mid, f"l{i}.o")                   # token-major [B*L, Hq*D]: one plain GEMM
                 self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
                 dQ, dK, dV = ops.qwen_flash_bwd(ctx["Q"], ctx["K"], ctx["V"], saved["keymask"], ctx["ao"], d_ao, ctx["lse"],
-                                                B, L, self.Hq, self.Hkv, D, D ** -0.5)
+                                                B, L, self.Hq, self.Hkv, D, D ** -0.5, kv_parts=saved.get("kv_parts", 1))
             else:
                 d_ao = torch.empty((B, self.Hq, L, D), device=dev, dtype=BF16)
                 ops.gemm_raw(dh_mid, Wo, d_ao, L, D, H, H, self.Hq * D, D, nb1=B, nb2=self.Hq, sA=(L * H, 0), sB=(0, D),
@@ -552,11 +564,12 @@ class Qwen3ForCausalLM(nn.Module):
                 dQ, dK, dV = self._attention_bwd(i, ctx, d_ao, B, L)
             dqkv = ops.qwen_qkprep_bwd(dQ, dK, dV, ctx["qkv"], self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin,
                                        ctx["qr"], ctx["kr"], self._g[f"l{i}.qn"], self._g[f"l{i}.kn"], accumulate, B, L,
-                                       self.Hq, self.Hkv, D)
+                                       self.Hq, self.Hkv, D, defer=norm_jobs)
             d_xn1 = self._dgrad(dqkv, f"l{i}.qkv")
             self._wgrad(f"l{i}.qkv", dqkv, ctx["xn1"], accumulate)
             dh = ops.rmsnorm_bwd(d_xn1, ctx["h_in"], self._w[f"l{i}.ln1"], ctx["r1"], dh_mid, self._g[f"l{i}.ln1"],
-                                 accumulate)
+                                 accumulate, defer=norm_jobs)
+            ops.colsum_flush(norm_jobs)
             if layer_done is not None:
                 self.join_wgrad_stream()
                 layer_done(i)
