@@ -80,6 +80,12 @@ typedef struct vq3_vit_qkv_epilogue {
 } vq3_vit_qkv_epilogue;
 int vq3_gemm_vit_qkv(const vq3_gemm_desc* desc, const vq3_vit_qkv_epilogue* epi, void* stream);
 
+/* The down_proj input-gradient GEMM with the SwiGLU backward in its epilogue (autograd of modeling_qwen3.py:81-83): desc computes
+ * d(act) [M, N] = dY . W (any operand layout, no other epilogue, C ignored); instead of being written it is combined with the saved
+ * pre-activations gu bf16 [M, 2N] = gate | up into dgu bf16 [M, 2N] = d(gate) | d(up), d(gate) = d(act) * up * silu'(gate),
+ * d(up) = d(act) * silu(gate) - same arithmetic and rounding as vq3_silu_mul_bwd on the materialised d(act). */
+int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* desc, const void* gu, void* dgu, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Normalisation
  * ---------------------------------------------------------------------------------------------------------- */

@@ -122,6 +122,29 @@ def test_gemm_forced_configs_with_epilogues(ops, cfg):
         ops.gemm_force_config(-3)
 
 
+@pytest.mark.parametrize("transB", [True, False])
+def test_gemm_swiglu_bwd_epilogue_equals_two_launches(ops, transB):
+    """vq3_gemm_swiglu_bwd (down_proj dgrad with the SwiGLU backward in its epilogue) against the two launches it replaces -
+    vq3_gemm_bf16_nt then vq3_silu_mul_bwd - for the k-major weight layout the backward uses and for the W^T (NT) form."""
+    M, H, I = 300, 256, 520                                   # edges inside tiles in both M and N
+    dY = _rand((M, H), 1.0, seed=30)
+    W = _rand((H, I), 0.1, seed=31)                           # down_proj.weight [out = H, in = I]
+    gu = _rand((M, 2 * I), 1.5, seed=32)
+    Wop = W if transB else W.t().contiguous()
+    d_act = torch.empty((M, I), device="cuda", dtype=BF16)
+    if transB:
+        ops.gemm_raw(dY, W, d_act, M, I, H, H, I, I, transB=True)
+    else:
+        ops.linear(dY, Wop, out=d_act)
+    ref = ops.silu_mul_bwd(d_act, gu)
+    got = ops.gemm_swiglu_bwd(dY, Wop, gu, transB=transB)
+    assert torch.equal(got, ref)                              # same staged bf16 d(act), same arithmetic
+    # and both agree with autograd of silu(g) * u
+    g32 = gu[:, :I].float().requires_grad_(True); u32 = gu[:, I:].float().requires_grad_(True)
+    (torch.nn.functional.silu(g32) * u32).backward(dY.float() @ W.float())
+    assert _relerr(got[:, :I], g32.grad) < 1e-2 and _relerr(got[:, I:], u32.grad) < 1e-2
+
+
 def test_gemm_batched_strided(ops):
     """Attention-shaped use: batch (b, h) with K/V shared by groups of heads and a strided output."""
     Bz, Hq, Hkv, L, D = 2, 8, 2, 200, 128

@@ -51,6 +51,7 @@ SIGNATURES = {
     "vq3_target_arch": [],
     "vq3_gemm_bf16_nt": [C.POINTER(GemmDesc), c_p],
     "vq3_gemm_vit_qkv": [C.POINTER(GemmDesc), C.POINTER(VitQkvEpilogue), c_p],
+    "vq3_gemm_swiglu_bwd": [C.POINTER(GemmDesc), c_p, c_p, c_p],
     "vq3_rmsnorm_fwd": [c_p, c_p, c_p, c_p, i64, i32, i64, i64, f32, c_p],
     "vq3_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "vq3_colsum_f32_to_bf16": [c_p, i32, i32, c_p, i32, c_p],

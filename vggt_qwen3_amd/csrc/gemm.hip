@@ -292,9 +292,10 @@ int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStr
 
 }  // namespace
 
-static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve, void* stream) {
+static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve, void* stream, const void* sw_gu = nullptr,
+                         void* sw_dgu = nullptr) {
   VQ3_CHECK_ARG(d != nullptr, "gemm: null descriptor");
-  VQ3_CHECK_ARG(d->A && d->B && (d->C || ve), "gemm: null operand pointer");
+  VQ3_CHECK_ARG(d->A && d->B && (d->C || ve || sw_dgu), "gemm: null operand pointer");
   VQ3_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
   VQ3_CHECK_ARG(d->K % 8 == 0 && d->K >= 8, "gemm: K=%d must be a positive multiple of 8", d->K);
   VQ3_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm: lda=%d / ldb=%d must be multiples of 8", d->lda, d->ldb);
@@ -305,7 +306,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   VQ3_CHECK_ARG(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0), "gemm: A/B must be 16-byte aligned");
   VQ3_CHECK_ARG(d->sA1 % 8 == 0 && d->sA2 % 8 == 0 && d->sB1 % 8 == 0 && d->sB2 % 8 == 0,
                 "gemm: batch strides of A/B must be multiples of 8 elements");
-  VQ3_CHECK_ARG(ve || d->ldc >= d->N, "gemm: ldc=%d < N=%d", d->ldc, d->N);
+  VQ3_CHECK_ARG(ve || sw_dgu || d->ldc >= d->N, "gemm: ldc=%d < N=%d", d->ldc, d->N);
   VQ3_CHECK_ARG(d->nb1 >= 1 && d->nb2 >= 1 && d->b2divB >= 1, "gemm: bad batch dims");
   VQ3_CHECK_ARG((long)d->nb1 * d->nb2 <= 65535, "gemm: too many batches");
   VQ3_CHECK_ARG(d->act >= 0 && d->act <= 2, "gemm: bad activation %d", d->act);
@@ -340,6 +341,18 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     p.vit.N = ve->N; p.vit.NH = ve->NH; p.vit.P = ve->tokens_per_frame; p.vit.patch_start = ve->patch_start; p.vit.Wp = ve->Wp;
     p.vit.use_norm = ve->use_norm; p.vit.use_rope = ve->use_rope; p.vit.eps = ve->eps;
     p.C = ve->Q; p.ldc = d->N;          // placeholders: the staged epilogue checks their alignment, nothing is stored through them
+    p.sC1 = p.sC2 = 0;
+  }
+  p.sw_gu = nullptr; p.sw_dgu = nullptr;
+  if (sw_dgu) {
+    VQ3_CHECK_ARG(sw_gu != nullptr, "gemm_swiglu_bwd: null gate|up pointer");
+    VQ3_CHECK_ARG(!d->out_f32 && !d->accumulate && !d->R && !d->colscale && !d->bias && d->act == 0 && d->ksplit <= 1 && d->nb1 == 1 &&
+                      d->nb2 == 1 && d->N % 8 == 0 && d->alpha == 1.f,
+                  "gemm_swiglu_bwd: plain bf16 GEMM (no epilogue, no batch), N %% 8 == 0");
+    VQ3_CHECK_ARG(((uintptr_t)sw_gu | (uintptr_t)sw_dgu) % 16 == 0, "gemm_swiglu_bwd: gu / dgu must be 16-byte aligned");
+    p.epi = 2;
+    p.sw_gu = (const bf16_t*)sw_gu; p.sw_dgu = (bf16_t*)sw_dgu;
+    p.C = sw_dgu; p.ldc = d->N;         // placeholders (alignment checks only)
     p.sC1 = p.sC2 = 0;
   }
   const int esz = d->out_f32 ? 4 : 2;
@@ -420,6 +433,11 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) { return g
 extern "C" int vq3_gemm_vit_qkv(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* epi, void* stream) {
   VQ3_CHECK_ARG(epi != nullptr, "gemm_vit_qkv: null epilogue descriptor");
   return gemm_dispatch(d, epi, stream);
+}
+
+extern "C" int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* d, const void* gu, void* dgu, void* stream) {
+  VQ3_CHECK_ARG(dgu != nullptr, "gemm_swiglu_bwd: null output pointer");
+  return gemm_dispatch(d, nullptr, stream, gu, dgu);
 }
 
 extern "C" int vq3_gemm_force_config(int32_t cfg) {

@@ -35,8 +35,10 @@ struct GemmParams {
   int accumulate;  // C += result
   int vec_ok;      // C (and R) rows are 16B (f32) / 8B (bf16) aligned for 4-wide stores
   float alpha;
-  int epi;         // 0 = C / R epilogue; 1 = VitQkvEpi (staged path only)
+  int epi;         // 0 = C / R epilogue; 1 = VitQkvEpi; 2 = SwiGLU backward (staged path only)
   VitQkvEpi vit;
+  const bf16_t* sw_gu;   // epi == 2: saved gate|up pre-activations [M, 2N]
+  bf16_t* sw_dgu;        //           d(gate|up) [M, 2N]; the GEMM result d(act) [M, N] is never written
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -280,6 +282,41 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
   constexpr int CPR = BN / 8;                  // 16-byte chunks per row
   if (p.epi == 1) {
     vit_qkv_store<BM, BN>(p, smem, m0, n0, tid, nthreads);
+    return;
+  }
+  if (p.epi == 2) {
+    // SwiGLU backward on the way out (modeling_qwen3.py:81-83 under autograd): the tile is d(act) = d(silu(g) * u); with the saved
+    // g | u rows read the same coalesced way it leaves as dg = d * u * silu'(g) and du = d * silu(g) - arithmetic of silu_mul_bwd_kernel
+    constexpr int CPR2 = BN / 8;
+    const int rpp = nthreads / CPR2, c = tid % CPR2, n = n0 + c * 8;
+    if (n >= p.N) return;                               // N % 8 == 0 (checked on the host)
+    for (int row = tid / CPR2; row < BM; row += rpp) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      const u32x4 dv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
+      const bf16_t* gp = p.sw_gu + (long)m * 2 * p.N + n;
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(gp);
+      const u32x4 uv = *reinterpret_cast<const u32x4*>(gp + p.N);
+      u32x4 og, ou;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float r_g[2], r_u[2];
+#pragma unroll
+        for (int hgh = 0; hgh < 2; ++hgh) {
+          const float df = bf2f((bf16_t)((dv[k] >> (16 * hgh)) & 0xffff));
+          const float gf = bf2f((bf16_t)((gv[k] >> (16 * hgh)) & 0xffff));
+          const float uf = bf2f((bf16_t)((uv[k] >> (16 * hgh)) & 0xffff));
+          const float sg = 1.f / (1.f + __expf(-gf));
+          r_g[hgh] = df * uf * (sg * (1.f + gf * (1.f - sg)));
+          r_u[hgh] = df * (gf * sg);
+        }
+        og[k] = pack2bf(r_g[0], r_g[1]);
+        ou[k] = pack2bf(r_u[0], r_u[1]);
+      }
+      bf16_t* op = p.sw_dgu + (long)m * 2 * p.N + n;
+      *reinterpret_cast<u32x4*>(op) = og;
+      *reinterpret_cast<u32x4*>(op + p.N) = ou;
+    }
     return;
   }
   bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff;

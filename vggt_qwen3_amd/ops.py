@@ -395,6 +395,32 @@ def vit_qkprep(qkv, N, NH, *, qn=None, kn=None, cos=None, sin=None, tokens_per_f
     return Q, K, V
 
 
+def gemm_swiglu_bwd(dY: torch.Tensor, W: torch.Tensor, gu: torch.Tensor, transB: bool) -> torch.Tensor:
+    """silu_mul_bwd(dY @ W (or dY @ W^T), gu) in one launch: dY bf16 [M, K]; W bf16 [K, N] (transB: k-major, as a weight [out=K, in=N]
+    is stored) or [N, K]; gu bf16 [M, 2N] -> dgu bf16 [M, 2N]. d(act) is never materialised (vq3_gemm_swiglu_bwd)."""
+    _req(dY, BF16, "swiglu_bwd dY"); _req(W, BF16, "swiglu_bwd W"); _req(gu, BF16, "swiglu_bwd gu")
+    assert dY.dim() == 2 and W.dim() == 2 and dY.stride(1) == 1 and W.stride(1) == 1 and gu.is_contiguous()
+    M, K = dY.shape
+    N = W.shape[1] if transB else W.shape[0]
+    assert (W.shape[0] if transB else W.shape[1]) == K and gu.shape == (M, 2 * N)
+    dgu = torch.empty_like(gu)
+    d = GemmDesc()
+    d.A = dY.data_ptr(); d.B = W.data_ptr(); d.C = None
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = M, N, K, dY.stride(0), W.stride(0), N, 0
+    d.nb1 = d.nb2 = d.b2divB = 1
+    d.alpha = 1.0
+    d.transA, d.transB = 0, 1 if transB else 0
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().vq3_gemm_swiglu_bwd(d, gu.data_ptr(), dgu.data_ptr(), _stream()), "vq3_gemm_swiglu_bwd")
+        e1.record()
+        GEMM_PROFILE.append((2.0 * M * N * K, 2.0 * M * K + 2.0 * N * K + 2.0 * M * N * 4, e0, e1, (M, N, K, 1)))
+    else:
+        check(_lib.load().vq3_gemm_swiglu_bwd(d, gu.data_ptr(), dgu.data_ptr(), _stream()), "vq3_gemm_swiglu_bwd")
+    return dgu
+
+
 def linear_vit_qkv(x: torch.Tensor, w: torch.Tensor, bias, N: int, NH: int, *, qn=None, kn=None, cos=None, sin=None,
                    tokens_per_frame=0, patch_start=0, Wp=0, eps=1e-5):
     """vit_qkprep(linear(x, w, bias)) in ONE launch: x bf16 [T, C] @ w[3*NH*64, C]^T (+ bias) -> Q, K, V bf16 [T/N, NH, N, 64]

@@ -541,9 +541,13 @@ class Qwen3ForCausalLM(nn.Module):
         for i in reversed(range(c.num_hidden_layers)):
             ctx = saved["layers"][i]
             # down_proj
-            d_act = self._dgrad(dh, f"l{i}.down")
+            # d(act) = dh . W_down with the SwiGLU backward in the GEMM epilogue: d(gate | up) leaves directly
+            wt = getattr(self, "_wt", None)
+            if wt is not None and f"l{i}.down" in wt and dh.is_contiguous():
+                dgu = ops.gemm_swiglu_bwd(dh, wt[f"l{i}.down"], ctx["gu"], transB=False)
+            else:
+                dgu = ops.gemm_swiglu_bwd(dh, self._w[f"l{i}.down"], ctx["gu"], transB=True)
             self._wgrad(f"l{i}.down", dh, ctx["act"], accumulate)
-            dgu = ops.silu_mul_bwd(d_act, ctx["gu"])
             d_xn2 = self._dgrad(dgu, f"l{i}.gu")
             self._wgrad(f"l{i}.gu", dgu, ctx["xn2"], accumulate)
             dh_mid = ops.rmsnorm_bwd(d_xn2, ctx["h_mid"], self._w[f"l{i}.ln2"], ctx["r2"], dh, self._g[f"l{i}.ln2"],
