@@ -338,7 +338,8 @@ int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* 
 
 /* Benchmarking / test hook for vq3_gemm_bf16_nt's kernel choice on NT, K % 64 == 0 shapes: cfg = -3 restores the automatic
  * choice (the default), -1 the register-staged reference kernel, 0..14 a gemm2.hip tile configuration, 20 / 21 / 22 the
- * 8-phase kernels of gemm6.hip (256x256 / 256x128 / 128x256 tiles). Process-wide; not meant for concurrent use with launches on other threads. */
+ * 8-phase kernels of gemm6.hip (256x256 / 256x128 / 128x256 tiles); 102 / 103 / 105 pin the schedule of the any-layout kernel
+ * (gemm3.hip: 128x128 2-stage, 128x128 loader ring, 256x128 loader ring; -3 releases it too). Process-wide; not meant for concurrent use with launches on other threads. */
 int vq3_gemm_force_config(int32_t cfg);
 
 #ifdef __cplusplus

@@ -122,6 +122,35 @@ def test_gemm_forced_configs_with_epilogues(ops, cfg):
         ops.gemm_force_config(-3)
 
 
+@pytest.mark.parametrize("sched", [102, 103, 105])
+def test_gemm_kmajor_layouts_all_schedules(ops, sched):
+    """The any-layout kernel (gemm3.hip) in each of its schedules - 128x128 two-stage, 128x128 loader ring, 256x128 loader ring -
+    for every operand layout (NT, k-major B = dgrad, k-major A and B = wgrad), K not a multiple of 64 (tail zero-fill), M / N edges
+    inside tiles, accumulate into bf16 (the wgrad form) and a residual."""
+    try:
+        ops.gemm_force_config(sched)
+        for (M, N, K) in ((1200, 520, 200), (304, 1032, 1208), (2560, 1024, 1200)):
+            A = _rand((M, K), 0.5, seed=40); Bm = _rand((N, K), 0.5, seed=41)
+            At, Bt = A.t().contiguous(), Bm.t().contiguous()              # k-major copies [K, M], [K, N]
+            ref = A.float() @ Bm.float().t()
+            for tA, tB in ((False, True), (True, True), (True, False)):
+                C = torch.empty((M, N), device="cuda", dtype=BF16)
+                ops.gemm_raw(At if tA else A, Bt if tB else Bm, C, M, N, K, M if tA else K, N if tB else K, N, transA=tA, transB=tB)
+                assert _relerr(C, ref) < 4e-3, (sched, M, N, K, tA, tB, _relerr(C, ref))
+            C = _rand((M, N), 1.0, seed=42); C0 = C.clone()
+            ops.gemm_raw(At, Bt, C, M, N, K, M, N, N, transA=True, transB=True, accumulate=True)
+            assert _relerr(C, ref + C0.float()) < 4e-3
+            R = _rand((M, N), 1.0, seed=43)
+            C = torch.empty((M, N), device="cuda", dtype=BF16)
+            ops.gemm_raw(A, Bt, C, M, N, K, K, N, N, transB=True, R=R, ldr=N)
+            assert _relerr(C, ref.to(BF16).float() + R.float()) < 4e-3
+            C32 = torch.empty((M, N), device="cuda", dtype=F32)
+            ops.gemm_raw(At, Bt, C32, M, N, K, M, N, N, transA=True, transB=True)
+            assert _relerr(C32, ref) < 1e-5
+    finally:
+        ops.gemm_force_config(-3)
+
+
 @pytest.mark.parametrize("transB", [True, False])
 def test_gemm_swiglu_bwd_epilogue_equals_two_launches(ops, transB):
     """vq3_gemm_swiglu_bwd (down_proj dgrad with the SwiGLU backward in its epilogue) against the two launches it replaces -

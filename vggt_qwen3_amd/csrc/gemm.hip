@@ -180,13 +180,16 @@ int choose_config(int M, int N, int K, int nbatch) {
 }
 
 // v3 (k-major operands / K tails) has 128x128 tiles only: 3-stage ring + loader waves vs 2 stages x 2 workgroups.
+int g_forced_v3 = 0;     // vq3_gemm_force_config(102 / 103 / 105): pin the k-major kernel's schedule
+
 int choose_v3_stages(int M, int N, int K, int nbatch) {
+  if (g_forced_v3) return g_forced_v3;
   static int forced = -1;
   if (forced < 0) {
-    const char* e = getenv("VQ3_GEMM_V3_STAGES");   // benchmarking override: 2 or 3
+    const char* e = getenv("VQ3_GEMM_V3_STAGES");   // benchmarking override: 2, 3 or 5 (256x128 tile)
     forced = e ? atoi(e) : 0;
   }
-  if (forced == 2 || forced == 3) return forced;
+  if (forced == 2 || forced == 3 || forced == 5) return forced;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
   const bool shortk = K <= 1536;
   const double s2 = (shortk ? 1.00 : 0.93) * fill(t128, 512);
@@ -376,8 +379,8 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   }
   if (d->transA || d->transB || d->K % BK != 0) {
     int nstage = choose_v3_stages(d->M, d->N, d->K, nbatch);
-    if (getenv("VQ3_GEMM_V3_STAGES") == nullptr && (long)d->M * d->N * d->K >= (1L << 24))
-      nstage = tuned_choice(p, d->transA, d->transB, nbatch, s, {102, 103}, 100 + nstage) - 100;
+    if (!g_forced_v3 && getenv("VQ3_GEMM_V3_STAGES") == nullptr && (long)d->M * d->N * d->K >= (1L << 24))
+      nstage = tuned_choice(p, d->transA, d->transB, nbatch, s, {102, 103, 105}, 100 + nstage) - 100;
     const int rc = launch_gemm_v3(p, d->transA, d->transB, nstage, nbatch, s);
     if (rc) return rc;
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3)");
@@ -441,7 +444,12 @@ extern "C" int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* d, const void* gu, void*
 }
 
 extern "C" int vq3_gemm_force_config(int32_t cfg) {
+  if (cfg == 102 || cfg == 103 || cfg == 105) {       // schedule of the any-layout kernel (gemm3.hip)
+    g_forced_v3 = cfg - 100;
+    return 0;
+  }
   VQ3_CHECK_ARG(cfg >= -3 && cfg <= 64 && cfg != -2, "gemm_force_config: cfg %d out of range", cfg);
   g_forced_cfg = cfg;
+  if (cfg == -3) g_forced_v3 = 0;
   return 0;
 }

@@ -19,8 +19,8 @@
 namespace vq3gemm {
 namespace {
 
-constexpr int BK = 64, BM = 128, BN = 128;
-constexpr int OPB = BM * BK * 2;  // bytes per operand tile (16 KiB)
+constexpr int BK = 64, BN = 128;
+constexpr int OPB = 128 * BK * 2;  // bytes per 128-row (or 128-column) operand sub-tile (16 KiB)
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // ds_read_b64_tr_b16 through inline asm, NOT through __builtin_amdgcn_ds_read_tr16_b64: with the builtin hipcc
@@ -45,14 +45,19 @@ __device__ __forceinline__ bf16x8 join(const u32x2& lo, const u32x2& hi) {
   return __builtin_bit_cast(bf16x8, t);
 }
 
-template <int WM, int WN, int NSTAGE, int NLOAD, bool AKM, bool BKM, bool OUT_F32>
+// BM = 128 or 256: the A tile is BM / 128 sub-tiles of 128 rows, each with the 64 x 128 image described above (a 256-row tile
+// at 64 x 64 per wave moves 0.5 KB of LDS per MFMA instead of 1.0: the k-major counterpart of gemm2's 256 x 128 loader kernel).
+template <int BM, int WM, int WN, int NSTAGE, int NLOAD, bool AKM, bool BKM, bool OUT_F32>
 __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((WM * WN + NLOAD + 3) / 4)) void gemm_v3_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
+  constexpr int SA = BM / 128;                        // A sub-tiles
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr int STAGE = 2 * OPB;
+  constexpr int STAGE = (SA + 1) * OPB;
   // NLOAD > 0: dedicated DMA waves (wid >= NW) issue every piece (see gemm2.hip)
   constexpr int NISS = NLOAD > 0 ? NLOAD : NW;
-  constexpr int PPW = 32 / NISS;  // 16 A pieces + 16 B pieces per stage
+  constexpr int NPIECE = 16 * (SA + 1);               // 16 pieces per sub-tile: A sub-tiles first, then B
+  constexpr int PPW = NPIECE / NISS;
+  static_assert(16 % NISS == 0, "the 16 pieces of a sub-tile must divide evenly over the issuing waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,10 +81,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
 
   // ---- DMA sources. piece index within an operand: po = (wid + NW*j) & 15; j < PPW/2 -> A, else B.
   // tile_ptr(op, piece, tile): per-lane source address of that piece.
-  auto src_ptr = [&](bool isA, int po, int tile) -> const bf16_t* {
+  auto src_ptr = [&](int sub, int po, int tile) -> const bf16_t* {
+    const bool isA = sub < SA;
     const bf16_t* base = isA ? A : B;
     const long ld = isA ? p.lda : p.ldb;
-    const int ext = isA ? p.M : p.N, x0 = isA ? m0 : n0;
+    const int ext = isA ? p.M : p.N, x0 = isA ? m0 + 128 * sub : n0;
     const bool km = isA ? AKM : BKM;
     if (!km) {
       const int prow = lane >> 3;
@@ -100,13 +106,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
   auto issue = [&](int tile, int stage) {
     char* sb = smem + stage * STAGE;
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      const bool isA = j < PPW / 2;
-      const int po = (iw + NISS * j) & 15;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_ptr(isA, po, tile),
-                                       (__attribute__((address_space(3))) void*)(sb + (isA ? 0 : OPB) + po * 1024), 16,
-                                       0, 0);
-    }
+    for (int sub = 0; sub <= SA; ++sub)               // compile-time sub-tile: operand, layout and leading dimension fold
+#pragma unroll
+      for (int jj = 0; jj < 16 / NISS; ++jj) {
+        const int po = iw + NISS * jj;                // this wave's pieces of the sub-tile
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_ptr(sub, po, tile),
+                                         (__attribute__((address_space(3))) void*)(sb + sub * OPB + po * 1024), 16, 0, 0);
+      }
   };
 
   f32x4 acc[TM][TN];
@@ -126,15 +132,16 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     const int krow_base = 8 * fq + (li >> 2);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int row = wm * (BM / WM) + i * 16;
-      if (AKM) a_off[i] = krow_base * 256 + ((((row >> 4)) ^ fl) << 5) + lane_part;
-      else { const int rr = row + fr; a_off[i] = rr * 128 + ((fq ^ (rr & 7)) << 4); }
+      const int trow = wm * (BM / WM) + i * 16;
+      const int sub = trow >> 7, row = trow & 127;     // 128-row sub-tile and the row inside it
+      if (AKM) a_off[i] = sub * OPB + krow_base * 256 + ((((row >> 4)) ^ fl) << 5) + lane_part;
+      else { const int rr = row + fr; a_off[i] = sub * OPB + rr * 128 + ((fq ^ (rr & 7)) << 4); }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = wn * (BN / WN) + j * 16;
-      if (BKM) b_off[j] = OPB + krow_base * 256 + ((((row >> 4)) ^ fl) << 5) + lane_part;
-      else { const int rr = row + fr; b_off[j] = OPB + rr * 128 + ((fq ^ (rr & 7)) << 4); }
+      if (BKM) b_off[j] = SA * OPB + krow_base * 256 + ((((row >> 4)) ^ fl) << 5) + lane_part;
+      else { const int rr = row + fr; b_off[j] = SA * OPB + rr * 128 + ((fq ^ (rr & 7)) << 4); }
     }
   }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -196,12 +203,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     const u32x4 z = {0u, 0u, 0u, 0u};
     if (AKM) {
       const int n16 = (BK - krem) * 16;
-      for (int idx = tid; idx < n16; idx += 64 * NW) *reinterpret_cast<u32x4*>(sa + krem * 256 + idx * 16) = z;
+      for (int sub = 0; sub < SA; ++sub)
+        for (int idx = tid; idx < n16; idx += 64 * NW) *reinterpret_cast<u32x4*>(sa + sub * OPB + krem * 256 + idx * 16) = z;
     } else {
       const int c0 = krem >> 3, nch = 8 - c0;
       for (int idx = tid; idx < BM * nch; idx += 64 * NW) {
-        const int row = idx & (BM - 1), kc = c0 + idx / BM;
-        *reinterpret_cast<u32x4*>(sa + row * 128 + ((kc ^ (row & 7)) << 4)) = z;
+        const int trow = idx & (BM - 1), kc = c0 + idx / BM;
+        const int sub = trow >> 7, row = trow & 127;
+        *reinterpret_cast<u32x4*>(sa + sub * OPB + row * 128 + ((kc ^ (row & 7)) << 4)) = z;
       }
     }
     __syncthreads();
@@ -340,14 +349,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
   }
 }
 
-template <int NSTAGE, int NLOAD, bool AKM, bool BKM>
+template <int BM, int NSTAGE, int NLOAD, bool AKM, bool BKM>
 int launch_v3(GemmParams& p, int nbatch, hipStream_t stream) {
-  constexpr int SMEM = NSTAGE * 2 * OPB;
+  constexpr int SMEM = NSTAGE * (BM / 128 + 1) * OPB;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, true>,
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v3_kernel<BM, 4, 2, NSTAGE, NLOAD, AKM, BKM, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, false>,
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v3_kernel<BM, 4, 2, NSTAGE, NLOAD, AKM, BKM, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       vq3_set_error("gemm v3: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -360,25 +369,39 @@ int launch_v3(GemmParams& p, int nbatch, hipStream_t stream) {
   p.xm = choose_xm(p.mtiles, p.ntiles);
   dim3 grid(p.mtiles * p.ntiles, p.nsplit, nbatch);
   if (p.out_f32)
-    hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, true>), grid, dim3(64 * (8 + NLOAD)), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_v3_kernel<BM, 4, 2, NSTAGE, NLOAD, AKM, BKM, true>), grid, dim3(64 * (8 + NLOAD)), SMEM, stream, p);
   else
-    hipLaunchKernelGGL((gemm_v3_kernel<4, 2, NSTAGE, NLOAD, AKM, BKM, false>), grid, dim3(64 * (8 + NLOAD)), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_v3_kernel<BM, 4, 2, NSTAGE, NLOAD, AKM, BKM, false>), grid, dim3(64 * (8 + NLOAD)), SMEM, stream, p);
   return 0;
 }
 
 }  // namespace
 
+// nstage: 2 = 128x128 tile, 2 stages x 2 workgroups per CU; 3 = 128x128, 4-stage ring + 2 loader waves;
+//         5 = 256x128 tile, 3-stage ring + 2 loader waves (one workgroup per CU)
 int launch_gemm_v3(GemmParams& p, int transA, int transB, int nstage, int nbatch, hipStream_t stream) {
-  const int sel = (nstage == 3 ? 4 : 0) | (transA ? 2 : 0) | (transB ? 1 : 0);
-  switch (sel) {
-    case 0: return launch_v3<2, 0, false, false>(p, nbatch, stream);
-    case 1: return launch_v3<2, 0, false, true>(p, nbatch, stream);
-    case 2: return launch_v3<2, 0, true, false>(p, nbatch, stream);
-    case 3: return launch_v3<2, 0, true, true>(p, nbatch, stream);
-    case 4: return launch_v3<4, 2, false, false>(p, nbatch, stream);
-    case 5: return launch_v3<4, 2, false, true>(p, nbatch, stream);
-    case 6: return launch_v3<4, 2, true, false>(p, nbatch, stream);
-    default: return launch_v3<4, 2, true, true>(p, nbatch, stream);
+  const int lay = (transA ? 2 : 0) | (transB ? 1 : 0);
+  if (nstage == 5) {
+    switch (lay) {
+      case 0: return launch_v3<256, 3, 2, false, false>(p, nbatch, stream);
+      case 1: return launch_v3<256, 3, 2, false, true>(p, nbatch, stream);
+      case 2: return launch_v3<256, 3, 2, true, false>(p, nbatch, stream);
+      default: return launch_v3<256, 3, 2, true, true>(p, nbatch, stream);
+    }
+  }
+  if (nstage == 3) {
+    switch (lay) {
+      case 0: return launch_v3<128, 4, 2, false, false>(p, nbatch, stream);
+      case 1: return launch_v3<128, 4, 2, false, true>(p, nbatch, stream);
+      case 2: return launch_v3<128, 4, 2, true, false>(p, nbatch, stream);
+      default: return launch_v3<128, 4, 2, true, true>(p, nbatch, stream);
+    }
+  }
+  switch (lay) {
+    case 0: return launch_v3<128, 2, 0, false, false>(p, nbatch, stream);
+    case 1: return launch_v3<128, 2, 0, false, true>(p, nbatch, stream);
+    case 2: return launch_v3<128, 2, 0, true, false>(p, nbatch, stream);
+    default: return launch_v3<128, 2, 0, true, true>(p, nbatch, stream);
   }
 }
 
