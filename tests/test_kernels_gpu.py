@@ -79,7 +79,7 @@ def test_gemm_epilogues(ops):
     assert _relerr(C, base + C0) < 1e-5
 
 
-@pytest.mark.parametrize("cfg", [20, 21, 22, 11, 13, 7, 9])
+@pytest.mark.parametrize("cfg", [20, 21, 22, 11, 13, 7, 9, 15, 16])
 def test_gemm_forced_configs_with_epilogues(ops, cfg):
     """Every tile configuration behind vq3_gemm_bf16_nt (20 = the 256x256 8-phase kernel; 11 / 13 / 7 / 9 = loader-wave and
     2-stage kernels) through the whole epilogue surface - bias, GELU, LayerScale, residual, accumulate, f32 output - with M and N
