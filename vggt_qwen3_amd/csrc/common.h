@@ -68,17 +68,29 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
-// erf to 1.5e-7 absolute (Abramowitz-Stegun 7.1.26): one v_exp, one v_rcp, 5 FMAs - libm's erff costs ~10x more and
-// the result is rounded to bf16 (eps 4e-3) right after, so nothing observable changes.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.f - poly * __expf(-ax * ax);
-  return copysignf(r, x);
+// Exact-form (erf) GELU, torch.nn.GELU()'s default, two values per VALU instruction: GELU(x) = x * Phi(x) with
+//   Phi(-a) = 2^q(a),  a = min(|x|, 5.5),  q = degree-7 fit of log2 Phi(-a) on [0, 5.5]      (Phi(x) = 1 - Phi(-x) for x > 0)
+// log2 Phi(-a) is smooth (it does not saturate as erf does), so 7 packed FMAs + one v_exp_f32 give |error| <= 7e-7 absolute and
+// 1.2e-5 relative for |x| < 3 (Phi of the negative tail is the quantity computed directly, so it keeps its relative accuracy);
+// the result is rounded to bf16 (2^-9 relative) right after. No v_rcp, no log2(e) multiply, none of libm erff's range checks:
+// on the VGGT fc1 GEMM (25 M outputs per launch, one workgroup per CU: nothing overlaps the epilogue) the activation is what the
+// tile's tail costs - 18.6 us of an 88.6 us launch with the Abramowitz-Stegun 7.1.26 form (v_rcp + v_exp + 12 scalar-lane ops).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+  const f32x2_t a = {fminf(fabsf(x[0]), 5.5f), fminf(fabsf(x[1]), 5.5f)};
+  f32x2_t q = {-1.921234625e-06f, -1.921234625e-06f};
+  q = __builtin_elementwise_fma(q, a, f32x2_t{6.328849712e-05f, 6.328849712e-05f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{-9.434208502e-04f, -9.434208502e-04f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{8.556272268e-03f, 8.556272268e-03f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{-5.405228293e-02f, -5.405228293e-02f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{-4.583817849e-01f, -4.583817849e-01f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{-1.151278331e+00f, -1.151278331e+00f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{-9.999938561e-01f, -9.999938561e-01f});
+  const f32x2_t h = {0.5f - __builtin_amdgcn_exp2f(q[0]), 0.5f - __builtin_amdgcn_exp2f(q[1])};
+  const f32x2_t phi = {0.5f + copysignf(h[0], x[0]), 0.5f + copysignf(h[1], x[1])};
+  return x * phi;
 }
-// exact-form (erf) GELU as torch.nn.GELU() default
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2_t{x, x})[0]; }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 
 // ---- host side error plumbing (C ABI returns int, message kept per thread) ----

@@ -201,7 +201,10 @@ __device__ __forceinline__ void store_quad_pre(const GemmParams& p, long coff, i
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-  if (p.act) {
+  if (p.act == 1) {
+    const f32x2_t g0 = gelu_erf2(f32x2_t{v[0], v[1]}), g1 = gelu_erf2(f32x2_t{v[2], v[3]});
+    v[0] = rbf(g0[0]); v[1] = rbf(g0[1]); v[2] = rbf(g1[0]); v[3] = rbf(g1[1]);
+  } else if (p.act) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = rbf(apply_act(v[r], p.act));
   }
@@ -236,6 +239,7 @@ __device__ __forceinline__ void store_quad_pre(const GemmParams& p, long coff, i
 // LDS image of the C tile - rows of BN bf16, 16-byte chunks XOR (row & 15): conflict-free for the 8-byte quad writes
 // (16 lanes = 16 rows, one column group) and for the 16-byte row reads - and leave as whole rows: 16 B per lane,
 // BN * 2 contiguous bytes per row, with the residual / accumulate operand read the same coalesced way.
+constexpr int EPI_U = 4;     // rows per thread whose global operands are in flight together in the staged epilogues
 template <int BN>
 __device__ __forceinline__ int cstage_off(int row, int chunk) {
   constexpr int MASK = BN / 8 >= 16 ? 15 : BN / 8 - 1;     // rows of fewer than 16 chunks (BN = 64): 2-way on the quad writes
@@ -256,7 +260,10 @@ __device__ __forceinline__ void stage_quad(const GemmParams& p, char* smem, int 
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-  if (p.act) {
+  if (p.act == 1) {
+    const f32x2_t g0 = gelu_erf2(f32x2_t{v[0], v[1]}), g1 = gelu_erf2(f32x2_t{v[2], v[3]});
+    v[0] = rbf(g0[0]); v[1] = rbf(g0[1]); v[2] = rbf(g1[0]); v[3] = rbf(g1[1]);
+  } else if (p.act) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = rbf(apply_act(v[r], p.act));
   }
@@ -290,32 +297,43 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
     constexpr int CPR2 = BN / 8;
     const int rpp = nthreads / CPR2, c = tid % CPR2, n = n0 + c * 8;
     if (n >= p.N) return;                               // N % 8 == 0 (checked on the host)
-    for (int row = tid / CPR2; row < BM; row += rpp) {
-      const int m = m0 + row;
-      if (m >= p.M) break;
-      const u32x4 dv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
-      const bf16_t* gp = p.sw_gu + (long)m * 2 * p.N + n;
-      const u32x4 gv = *reinterpret_cast<const u32x4*>(gp);
-      const u32x4 uv = *reinterpret_cast<const u32x4*>(gp + p.N);
-      u32x4 og, ou;
+    for (int row0 = tid / CPR2; row0 < BM; row0 += rpp * EPI_U) {
+      // the saved operands of EPI_U rows are requested first: one L2 / HBM round trip per batch instead of one per row
+      u32x4 gv[EPI_U], uv[EPI_U];
+      bool ok[EPI_U];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float r_g[2], r_u[2];
-#pragma unroll
-        for (int hgh = 0; hgh < 2; ++hgh) {
-          const float df = bf2f((bf16_t)((dv[k] >> (16 * hgh)) & 0xffff));
-          const float gf = bf2f((bf16_t)((gv[k] >> (16 * hgh)) & 0xffff));
-          const float uf = bf2f((bf16_t)((uv[k] >> (16 * hgh)) & 0xffff));
-          const float sg = 1.f / (1.f + __expf(-gf));
-          r_g[hgh] = df * uf * (sg * (1.f + gf * (1.f - sg)));
-          r_u[hgh] = df * (gf * sg);
-        }
-        og[k] = pack2bf(r_g[0], r_g[1]);
-        ou[k] = pack2bf(r_u[0], r_u[1]);
+      for (int u = 0; u < EPI_U; ++u) {
+        const int row = row0 + u * rpp, m = m0 + row;
+        ok[u] = row < BM && m < p.M;
+        const bf16_t* gp = p.sw_gu + (long)(ok[u] ? m : p.M - 1) * 2 * p.N + n;
+        gv[u] = *reinterpret_cast<const u32x4*>(gp);
+        uv[u] = *reinterpret_cast<const u32x4*>(gp + p.N);
       }
-      bf16_t* op = p.sw_dgu + (long)m * 2 * p.N + n;
-      *reinterpret_cast<u32x4*>(op) = og;
-      *reinterpret_cast<u32x4*>(op + p.N) = ou;
+#pragma unroll
+      for (int u = 0; u < EPI_U; ++u) {
+        if (!ok[u]) continue;
+        const int row = row0 + u * rpp, m = m0 + row;
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
+        u32x4 og, ou;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float r_g[2], r_u[2];
+#pragma unroll
+          for (int hgh = 0; hgh < 2; ++hgh) {
+            const float df = bf2f((bf16_t)((dv[k] >> (16 * hgh)) & 0xffff));
+            const float gf = bf2f((bf16_t)((gv[u][k] >> (16 * hgh)) & 0xffff));
+            const float uf = bf2f((bf16_t)((uv[u][k] >> (16 * hgh)) & 0xffff));
+            const float sg = 1.f / (1.f + __expf(-gf));
+            r_g[hgh] = df * uf * (sg * (1.f + gf * (1.f - sg)));
+            r_u[hgh] = df * (gf * sg);
+          }
+          og[k] = pack2bf(r_g[0], r_g[1]);
+          ou[k] = pack2bf(r_u[0], r_u[1]);
+        }
+        bf16_t* op = p.sw_dgu + (long)m * 2 * p.N + n;
+        *reinterpret_cast<u32x4*>(op) = og;
+        *reinterpret_cast<u32x4*>(op + p.N) = ou;
+      }
     }
     return;
   }
@@ -326,39 +344,57 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
   const int n = n0 + c * 8;
   if (n >= p.N) return;
   const bool fulln = n + 7 < p.N;
-  for (int row = tid / CPR; row < BM; row += rpp) {
+  if (fulln) {
+    for (int row0 = tid / CPR; row0 < BM; row0 += rpp * EPI_U) {
+      // residual / old-C rows of EPI_U passes are requested before any of them is used (and before this batch's stores, which
+      // the compiler must assume alias them): one L2 / HBM round trip per batch instead of one per row
+      u32x4 rv[EPI_U], cv[EPI_U];
+      bool ok[EPI_U];
+#pragma unroll
+      for (int u = 0; u < EPI_U; ++u) {
+        const int row = row0 + u * rpp, m = m0 + row;
+        ok[u] = row < BM && m < p.M;
+        const long mc = ok[u] ? m : p.M - 1;
+        if (R) rv[u] = *reinterpret_cast<const u32x4*>(R + mc * p.ldr + n);
+        if (p.accumulate) cv[u] = *reinterpret_cast<const u32x4*>(C + mc * p.ldc + n);
+      }
+#pragma unroll
+      for (int u = 0; u < EPI_U; ++u) {
+        if (!ok[u]) continue;
+        const int row = row0 + u * rpp, m = m0 + row;
+        const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(sv[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(sv[k] >> 16)); }
+        if (R) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[2 * k] = rbf(v[2 * k] + bf2f((bf16_t)(rv[u][k] & 0xffff)));
+            v[2 * k + 1] = rbf(v[2 * k + 1] + bf2f((bf16_t)(rv[u][k] >> 16)));
+          }
+        }
+        if (p.accumulate) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v[2 * k] += bf2f((bf16_t)(cv[u][k] & 0xffff)); v[2 * k + 1] += bf2f((bf16_t)(cv[u][k] >> 16)); }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2bf(v[2 * k], v[2 * k + 1]);
+        *reinterpret_cast<u32x4*>(C + (long)m * p.ldc + n) = o;
+      }
+    }
+    return;
+  }
+  for (int row = tid / CPR; row < BM; row += rpp) {      // ragged last chunk of a row (N % 8 != 0): element-wise
     const int m = m0 + row;
     if (m >= p.M) break;
     const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
     bf16_t* cp = C + (long)m * p.ldc + n;
-    if (fulln) {
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(sv[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(sv[k] >> 16)); }
-      if (R) {
-        const u32x4 rv = *reinterpret_cast<const u32x4*>(R + (long)m * p.ldr + n);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[2 * k] = rbf(v[2 * k] + bf2f((bf16_t)(rv[k] & 0xffff)));
-          v[2 * k + 1] = rbf(v[2 * k + 1] + bf2f((bf16_t)(rv[k] >> 16)));
-        }
-      }
-      if (p.accumulate) {
-        const u32x4 cv = *reinterpret_cast<const u32x4*>(cp);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[2 * k] += bf2f((bf16_t)(cv[k] & 0xffff)); v[2 * k + 1] += bf2f((bf16_t)(cv[k] >> 16)); }
-      }
-      u32x4 o;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = pack2bf(v[2 * k], v[2 * k + 1]);
-      *reinterpret_cast<u32x4*>(cp) = o;
-    } else {
-      for (int k = 0; k < 8 && n + k < p.N; ++k) {
-        float x = bf2f((bf16_t)((sv[k >> 1] >> ((k & 1) * 16)) & 0xffff));
-        if (R) x = rbf(x + bf2f(R[(long)m * p.ldr + n + k]));
-        if (p.accumulate) x += bf2f(cp[k]);
-        cp[k] = f2bf(x);
-      }
+    for (int k = 0; k < 8 && n + k < p.N; ++k) {
+      float x = bf2f((bf16_t)((sv[k >> 1] >> ((k & 1) * 16)) & 0xffff));
+      if (R) x = rbf(x + bf2f(R[(long)m * p.ldr + n + k]));
+      if (p.accumulate) x += bf2f(cp[k]);
+      cp[k] = f2bf(x);
     }
   }
 }
@@ -367,6 +403,24 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
 // head; the head's 64 features are the 8 consecutive lanes around it (CPR is a multiple of 8 and tiles start at multiples of
 // 64 columns), so the LayerNorm sums are three xor-shuffles and the rotate-half partner (feature e ^ 16) is lane ^ 2.
 // Arithmetic and rounding points are those of vit_qkprep4_kernel (vggt.hip).
+// lane exchange inside groups of 8 lanes on the DPP path of the VALU (no LDS-permute traffic next to the staged tile's reads)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum8(float v) {          // all-reduce over the 8 lanes l & ~7 .. l | 7
+  v += dpp_mov<0xB1>(v);                                  // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_mov<0x4E>(v);                                  // quad_perm [2,3,0,1]: lane ^ 2
+  return v + dpp_mov<0x141>(v);                           // row_half_mirror: lane i <-> 7 - i, i.e. the other quad's sum
+}
+// x = q * d + r for 0 <= x < 2^22 and a small divisor, through the float reciprocal with one correction step either way
+__device__ __forceinline__ void divmod_f(int x, int d, float inv, int& q, int& r) {
+  q = (int)((float)x * inv);
+  r = x - q * d;
+  if (r < 0) { r += d; --q; }
+  else if (r >= d) { r -= d; ++q; }
+}
+
 template <int BM, int BN>
 __device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* smem, int m0, int n0, int tid, int nthreads) {
   constexpr int CPR = BN / 8;
@@ -387,51 +441,63 @@ __device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* s
   }
   bf16_t* base = which == 0 ? e.Q : (which == 1 ? e.K : e.V);
   const bool neg = (d0 & 16) == 0;                       // (e & 16) == 0 -> rotate-half takes -x[e + 16]
-  for (int row = tid / CPR; row < BM; row += rpp) {
-    const int m = m0 + row;
-    if (m >= p.M) break;
-    const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
-    float x[8];
+  const float invN = 1.f / (float)e.N, invP = 1.f / (float)(e.P > 0 ? e.P : 1), invW = 1.f / (float)(e.Wp > 0 ? e.Wp : 1);
+  for (int row0 = tid / CPR; row0 < BM; row0 += rpp * EPI_U) {
+    // token coordinates and the cos / sin rows of EPI_U passes first (they depend on the row only), then the arithmetic: the table
+    // reads' round trip is paid once per batch. Rows past M are computed on row M - 1 and not stored, so all lanes stay in step.
+    int gi[EPI_U], ti[EPI_U];
+    bool ok[EPI_U];
+    u32x4 cr[EPI_U], sr[EPI_U];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { x[2 * k] = bf2f((bf16_t)(sv[k] & 0xffff)); x[2 * k + 1] = bf2f((bf16_t)(sv[k] >> 16)); }
-    const int g = m / e.N, tok = m - g * e.N;
-    if (norm) {
-      float sum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-#pragma unroll
-      for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-      const float mean = sum * (1.f / 64.f);
-      float sq = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { x[j] -= mean; sq = fmaf(x[j], x[j], sq); }
-#pragma unroll
-      for (int o = 4; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-      const float rs = rsqrtf(sq * (1.f / 64.f) + e.eps);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = rbf(x[j] * rs * w8[j] + b8[j]);
-    }
-    if (rope) {
-      const int tp = tok % e.P;
-      int py = 0, px = 0;
-      if (tp >= e.patch_start) {
-        py = (tp - e.patch_start) / e.Wp + 1;
-        px = (tp - e.patch_start) % e.Wp + 1;
-      }
-      const int pos = d0 < 32 ? py : px;
-      const u32x4 cr = *reinterpret_cast<const u32x4*>(e.cos + pos * 32 + (d0 & 31));
-      const u32x4 sr = *reinterpret_cast<const u32x4*>(e.sin + pos * 32 + (d0 & 31));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float cj = bf2f((bf16_t)((cr[j >> 1] >> ((j & 1) * 16)) & 0xffff));
-        const float sj = bf2f((bf16_t)((sr[j >> 1] >> ((j & 1) * 16)) & 0xffff));
-        const float pj = __shfl_xor(x[j], 2, 64);
-        const float rj = neg ? -pj : pj;
-        x[j] = rbf(rbf(x[j] * cj) + rbf(rj * sj));
+    for (int u = 0; u < EPI_U; ++u) {
+      const int row = row0 + u * rpp, m = m0 + row;
+      ok[u] = row < BM && m < p.M;
+      divmod_f(ok[u] ? m : p.M - 1, e.N, invN, gi[u], ti[u]);
+      if (rope) {
+        int fr, tp = ti[u];
+        if (e.P != e.N) divmod_f(ti[u], e.P, invP, fr, tp);
+        int py = 0, px = 0;
+        if (tp >= e.patch_start) {
+          divmod_f(tp - e.patch_start, e.Wp, invW, py, px);
+          ++py; ++px;
+        }
+        const int pos = d0 < 32 ? py : px;
+        cr[u] = *reinterpret_cast<const u32x4*>(e.cos + pos * 32 + (d0 & 31));
+        sr[u] = *reinterpret_cast<const u32x4*>(e.sin + pos * 32 + (d0 & 31));
       }
     }
-    u32x4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = pack2bf(x[2 * k], x[2 * k + 1]);
-    *reinterpret_cast<u32x4*>(base + (((long)g * e.NH + head) * e.N + tok) * 64 + d0) = o;
+    for (int u = 0; u < EPI_U; ++u) {
+      const int row = row0 + u * rpp;
+      const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row < BM ? row : BM - 1, c));
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { x[2 * k] = bf2f((bf16_t)(sv[k] & 0xffff)); x[2 * k + 1] = bf2f((bf16_t)(sv[k] >> 16)); }
+      if (norm) {
+        const float mean = sum8(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * (1.f / 64.f);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j] -= mean; sq = fmaf(x[j], x[j], sq); }
+        const float rs = rsqrtf(sum8(sq) * (1.f / 64.f) + e.eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = rbf(x[j] * rs * w8[j] + b8[j]);
+      }
+      if (rope) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float cj = bf2f((bf16_t)((cr[u][j >> 1] >> ((j & 1) * 16)) & 0xffff));
+          const float sj = bf2f((bf16_t)((sr[u][j >> 1] >> ((j & 1) * 16)) & 0xffff));
+          const float pj = dpp_mov<0x4E>(x[j]);                                                  // feature e ^ 16: lane ^ 2
+          const float rj = neg ? -pj : pj;
+          x[j] = rbf(rbf(x[j] * cj) + rbf(rj * sj));
+        }
+      }
+      if (!ok[u]) continue;
+      u32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = pack2bf(x[2 * k], x[2 * k + 1]);
+      *reinterpret_cast<u32x4*>(base + (((long)gi[u] * e.NH + head) * e.N + ti[u]) * 64 + d0) = o;
+    }
   }
 }
 
