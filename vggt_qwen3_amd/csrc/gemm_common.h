@@ -239,7 +239,7 @@ __device__ __forceinline__ void store_quad_pre(const GemmParams& p, long coff, i
 // LDS image of the C tile - rows of BN bf16, 16-byte chunks XOR (row & 15): conflict-free for the 8-byte quad writes
 // (16 lanes = 16 rows, one column group) and for the 16-byte row reads - and leave as whole rows: 16 B per lane,
 // BN * 2 contiguous bytes per row, with the residual / accumulate operand read the same coalesced way.
-constexpr int EPI_U = 4;     // rows per thread whose global operands are in flight together in the staged epilogues
+constexpr int EPI_U = 8;     // rows per thread whose global operands are in flight together in the staged epilogues
 template <int BN>
 __device__ __forceinline__ int cstage_off(int row, int chunk) {
   constexpr int MASK = BN / 8 >= 16 ? 15 : BN / 8 - 1;     // rows of fewer than 16 chunks (BN = 64): 2-way on the quad writes

@@ -297,11 +297,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
   store_tile(0);
   __syncthreads();
 
+  // a wave whose 32 * QB query rows all lie past N (the ragged last block: N = 1029 leaves 5 rows for wave 0 and none for waves
+  // 1-3) only helps to stage K / V: its SIMD's MFMA and VALU slots go to the other workgroup on the CU
+  const bool active = q0 < N;
   for (int t = 0; t < nt; ++t) {
     const bool more = t + 1 < nt;
     const char* sb = smem + (t & 1) * (2 * FA_KV * 128);
     const unsigned sbase = lds_base + (unsigned)((t & 1) * (2 * FA_KV * 128));
     if (more) load_tile(t + 1);
+    if (active) {
     // ---- S^T = K . Q'^T - m
     f32x16 s0[QB], s1[QB];
     if (!NEGM) {
@@ -452,6 +456,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
         }
       }
     }
+    }   // active
     if (more) store_tile((t + 1) & 1);
     __syncthreads();
   }
