@@ -218,13 +218,14 @@ def main():
     loss = None
     # warm-up runs whole accumulation cycles too (so the timed region starts on a cycle boundary); the first cycle
     # also pays the one-time costs (LDS attribute setup, allocator growth, RCCL channel setup)
-    nwarm = max(args.warmup, 1)
-    trainer.grad_accum = nwarm
+    # (and, with the weight-gradient GEMMs of `wgrad_defer` micro-batches fused into one, the autotuner's first sight of every
+    # contraction length the window's flush pattern produces: the warm-up is rounded UP to whole windows of the timed schedule)
+    nwarm = (max(args.warmup, 1) + accum - 1) // accum * accum
+    trainer.grad_accum = accum
     nxt = batch if args.vision_prefetch else None   # next micro-batch's (frozen) vision forward overlaps this one
     for _ in range(nwarm):
         loss = trainer.micro_step(batch, nxt)
-    trainer.grad_accum = accum
-    assert trainer.micro % nwarm == 0
+    assert trainer.micro % accum == 0
     trainer.micro = 0
     sync()
     t0 = time.perf_counter()
@@ -247,8 +248,9 @@ def main():
     trimmed = None
     if not args.trim_pad and not args.no_trim_variant:
         model.trim_padding = True
-        trainer.grad_accum, trainer.micro = 1, 0
-        loss_t = trainer.micro_step(batch, nxt)      # warm the trimmed shapes (allocator, LDS attributes)
+        trainer.grad_accum, trainer.micro = cycles[0], 0
+        for _ in range(cycles[0]):
+            loss_t = trainer.micro_step(batch, nxt)  # warm the trimmed shapes over one whole window (allocator, LDS attributes, autotuner)
         sync()
         t0 = time.perf_counter()
         for clen in cycles:
@@ -309,10 +311,10 @@ def main():
             model.geom_tokens, trainer.geom_on = 8, True
             for key, fp8 in (("c4_variant", False), ("c5_variant", True)):
                 model.text_model.enable_fp8_forward(fp8)
-                trainer.grad_accum, trainer.micro = 1, 0
-                trainer.micro_step(b8)                                   # warm the 8-view shapes
                 n8 = max(1, args.variant_steps)
                 trainer.grad_accum, trainer.micro = n8, 0                # one accumulation cycle: n8 micro-batches + one AdamW
+                for _ in range(n8):
+                    trainer.micro_step(b8)                               # warm the 8-view shapes over the same cycle
                 dt8, l8 = timed(lambda: trainer.micro_step(b8), n8)
                 variants[key] = {"value": round(B / dt8, 3), "unit": "samples/s", "ms_per_step": round(dt8 * 1e3, 2), "steps": n8,
                                  "views": 8, "geom_tokens": 8, "fp8_text_forward": fp8, "batch_per_gpu": B, "loss": round(float(l8.item()), 4),
@@ -328,24 +330,31 @@ def main():
     # ---- live roofline of the dominant kernel (gemm_nt_kernel): one extra instrumented step, HIP events per launch
     roof = None
     if rank == 0:
-        ops.GEMM_PROFILE = []
         model.text_model._wgrad_stream = None   # serial launches: per-launch event times are not inflated by overlap
-        trainer.grad_accum = 1
-        trainer.micro = 0
-        trainer.micro_step(batch)
+        # one group of the deferred weight-gradient schedule (every projection's weight-gradient GEMM runs over nroof micro-batches'
+        # rows): per-step figures below are the group's totals / nroof
+        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)), accum))
+        trainer.grad_accum, trainer.micro = nroof, 0
+        for _ in range(nroof):
+            trainer.micro_step(batch)               # (the serial schedule's shapes are tuned before the events go in)
         torch.cuda.synchronize()
-        fl = sum(g[0] for g in ops.GEMM_PROFILE)
-        by = sum(g[1] for g in ops.GEMM_PROFILE)
-        ms = sum(g[2].elapsed_time(g[3]) for g in ops.GEMM_PROFILE)
-        nlaunch = len(ops.GEMM_PROFILE)
+        ops.GEMM_PROFILE = []
+        trainer.micro = 0
+        for _ in range(nroof):
+            trainer.micro_step(batch)
+        torch.cuda.synchronize()
+        fl = sum(g[0] for g in ops.GEMM_PROFILE) / nroof
+        by = sum(g[1] for g in ops.GEMM_PROFILE) / nroof
+        ms = sum(g[2].elapsed_time(g[3]) for g in ops.GEMM_PROFILE) / nroof
+        nlaunch = len(ops.GEMM_PROFILE) / nroof
         if os.environ.get("VQ3_GEMM_TABLE"):
             import collections
             tab = collections.defaultdict(lambda: [0, 0.0, 0.0])
             for g in ops.GEMM_PROFILE:
-                t = tab[g[4]]; t[0] += 1; t[1] += g[2].elapsed_time(g[3]); t[2] += g[0]
+                t = tab[g[4]]; t[0] += 1.0 / nroof; t[1] += g[2].elapsed_time(g[3]) / nroof; t[2] += g[0] / nroof
             print("GEMM shapes (M,N,K,batch): calls, ms/step, TF/s", file=sys.stderr)
             for k, (c, m_, f_) in sorted(tab.items(), key=lambda kv: -kv[1][1])[:40]:
-                print(f"  {k}: {c:4d} {m_:8.3f} ms {f_ / m_ / 1e9:8.1f} TF/s", file=sys.stderr)
+                print(f"  {k}: {c:6.1f} {m_:8.3f} ms {f_ / m_ / 1e9:8.1f} TF/s", file=sys.stderr)
         ops.GEMM_PROFILE = None
         ach = fl / (ms * 1e-3) / 1e12
         # PMC counters cannot be read from inside the run: `traffic` is the rocprofv3 --pmc result of THIS command at the
@@ -360,12 +369,13 @@ def main():
                 "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_unit": "bytes/launch (L2<->fabric, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)",
-                "algorithmic_bytes_per_launch": round(by / nlaunch), "launches_per_step": nlaunch, "avg_launch_us": round(ms * 1e3 / nlaunch, 2),
+                "algorithmic_bytes_per_launch": round(by / nlaunch), "launches_per_step": round(nlaunch, 1), "avg_launch_us": round(ms * 1e3 / nlaunch, 2),
                 "gemm_ms_per_step": round(ms, 2), "gemm_tflop_per_step": round(fl / 1e12, 3)}
     elif world > 1:
-        trainer.grad_accum = 1
-        trainer.micro = 0
-        trainer.micro_step(batch)  # keep collectives matched across ranks
+        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)), accum))
+        trainer.grad_accum, trainer.micro = nroof, 0
+        for _ in range(2 * nroof):
+            trainer.micro_step(batch)  # keep collectives matched across ranks
     if use_dist:
         dist.barrier()
 
@@ -373,7 +383,7 @@ def main():
         tf_train = (flops_vggt(V, args.image_size) + flops_perceiver() + 3 * flops_qwen(L)) / 1e12
         out = {
             "metric": "Stage-1 train samples/sec (VGGT+Qwen3-4B bf16)", "value": round(value, 3), "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_executed": nwarm, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8-e4m3 fwd / bf16 bwd" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": ("Stage-1 ScanQA bf16: VGGT-1B aggregator @%dpx x %d view(s) + 128-latent/6-layer "
                                     "Perceiver + Qwen3-4B fwd+bwd + RCCL all-reduce + AdamW(fp32 master); random-init "

@@ -200,6 +200,7 @@ def test_resume_refreshes_weight_derived_copies(tmp_path):
     la = ta.micro_step(batch)
     lc = tc.micro_step(batch)
     assert abs(la.item() - lc.item()) < 1e-5 * abs(la.item())
+    a.text_model.flush_deferred(); c.text_model.flush_deferred()   # mid-window: the projections' weight-gradient GEMMs are still pending
     assert relerr(c.text_model.flat_g, a.text_model.flat_g) < 2e-2
     # model checkpoint loaded AFTER a trainer exists: derived copies and the fp32 master follow
     d = build()
@@ -247,3 +248,67 @@ def test_perceiver_train_mode_dropout():
     assert 1e-3 < d < 0.6, d                                               # perturbed, not destroyed
     proj.cfg.dropout = 0.0
     assert torch.equal(proj(tok), e1)                                      # p = 0 in train mode == eval path
+
+
+def test_deferred_weight_gradients_match_per_microbatch_gemms():
+    """Stage1Trainer(wgrad_defer=n): the projections' weight-gradient GEMMs run once per n micro-batches over the concatenated
+    token rows (qwen3.py "deferred weight gradients"). Over one window of 4 DIFFERENT micro-batches - labels moved around, one
+    micro-batch without any label, window boundary in the middle of a group - flat_g must equal what per-micro-batch GEMMs
+    accumulate (up to their bf16 read-modify-write rounding), and must be no further from an f32 accumulation of the per-micro-batch
+    gradients than the per-micro-batch path is. The pairing guard must refuse two forwards in a row."""
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z, m, build, batch = _vlm()
+
+    def variants():
+        out = []
+        for k in range(4):
+            b = dict(batch)
+            ids = batch["input_ids"].clone()
+            lab = batch["labels"].clone()
+            keep = lab != -100
+            if k == 2:
+                lab[:] = -100                                   # a micro-batch whose answer was truncated away
+            elif k:
+                g = torch.Generator().manual_seed(100 + k)
+                noise = torch.randint(5, 200, ids.shape, generator=g).to(ids.device)
+                ids = torch.where(keep, noise, ids)
+                lab = torch.where(keep, noise, lab)
+            b["input_ids"], b["labels"] = ids, lab
+            out.append(b)
+        return out
+
+    mbs = variants()
+    grads = {}
+    for depth in (1, 2, 3, 4):
+        model = build()
+        tr = Stage1Trainer(model, lr=0.0, proj_lr=0.0, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=4,
+                           wgrad_defer=depth, max_grad_norm=None)
+        assert model.text_model._wd_depth == depth
+        for b in mbs:
+            tr.micro_step(b)
+        assert not any(model.text_model._wd_rows)               # nothing left pending after the boundary
+        grads[depth] = model.text_model.flat_g.float().clone()
+        del tr, model
+    # f32 reference: per-micro-batch gradients (grad_accum=1 windows, scale 1/4 applied afterwards) summed in f32
+    model = build()
+    tr = Stage1Trainer(model, lr=0.0, proj_lr=0.0, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=1, max_grad_norm=None)
+    ref = torch.zeros_like(grads[1])
+    for k, b in enumerate(mbs):
+        tr.micro_step(b)
+        if k != 2:
+            ref += model.text_model.flat_g.float() * 0.25
+    e1 = relerr(grads[1], ref)
+    for depth in (2, 3, 4):
+        assert relerr(grads[depth], grads[1]) < 1e-2, (depth, relerr(grads[depth], grads[1]))
+        assert relerr(grads[depth], ref) <= e1 * 1.5 + 1e-4, (depth, relerr(grads[depth], ref), e1)
+    # pairing guard
+    model = build()
+    tm = model.text_model
+    tm.enable_wgrad_deferral(2)
+    st1 = model.forward_state(batch["pixel_values"], batch["geom_token"], batch["input_ids"], batch["attention_mask"], batch["labels"],
+                              need_grad=True)
+    st2 = model.forward_state(batch["pixel_values"], batch["geom_token"], batch["input_ids"], batch["attention_mask"], batch["labels"],
+                              need_grad=True)
+    with pytest.raises(RuntimeError, match="alternate"):
+        model._backward_text(st1, 1.0, False)
+    model._backward_text(st2, 1.0, False)                       # the latest forward's operands are intact

@@ -13,8 +13,15 @@ def load_window(path):
     starts = sorted({rows[i]["Start_Timestamp"] for i in big}, key=int)       # one entry per optimiser step
     if len(starts) < 2:
         raise SystemExit("need at least 2 optimiser steps in the trace")
-    t_lo = max(int(rows[i]["End_Timestamp"]) for i in big if rows[i]["Start_Timestamp"] == starts[-2])
-    t_hi = max(int(rows[i]["End_Timestamp"]) for i in big if rows[i]["Start_Timestamp"] == starts[-1])
+    # the accumulation window with the most micro-batches (bench.py ends with one-micro-batch instrumented windows; the timed
+    # region's windows are the long ones); ties go to the latest
+    ends = [max(int(rows[i]["End_Timestamp"]) for i in big if rows[i]["Start_Timestamp"] == st) for st in starts]
+    splice = sorted(int(r["Start_Timestamp"]) for r in rows if "embed_splice_fwd_kernel" in r["Kernel_Name"])
+    best, t_lo, t_hi = -1, ends[-2], ends[-1]
+    for a, b in zip(ends[:-1], ends[1:]):
+        n = sum(1 for t in splice if a <= t <= b)
+        if n >= best:
+            best, t_lo, t_hi = n, a, b
     win = [r for r in rows if t_lo <= int(r["Start_Timestamp"]) and int(r["End_Timestamp"]) <= t_hi]
     nmicro = max(1, sum(1 for r in win if "embed_splice_fwd_kernel" in r["Kernel_Name"]) // ncnt)
     wall_ms = (t_hi - t_lo) / 1e6

@@ -34,6 +34,16 @@ def _req(t: torch.Tensor, dtype, name: str) -> None:
         raise _lib.Vq3Error(f"{name}: expected dtype {dtype}, got {t.dtype}")
 
 
+def _out2d(out: Optional[torch.Tensor], rows: int, cols: int, like: torch.Tensor, name: str) -> torch.Tensor:
+    """The op's bf16 [rows, cols] result: a fresh tensor, or the caller's (a row block of a longer-lived slab, e.g. the deferred
+    weight-gradient operands of Qwen3ForCausalLM) when it has exactly that shape and dense rows."""
+    if out is None:
+        return torch.empty((rows, cols), device=like.device, dtype=BF16)
+    if out.dtype != BF16 or tuple(out.shape) != (rows, cols) or not out.is_contiguous() or out.device != like.device:
+        raise _lib.Vq3Error(f"{name}: out must be a contiguous bf16 [{rows}, {cols}] tensor on {like.device}")
+    return out
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -99,11 +109,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, *, bias=None, colscale=None, residu
 
 
 # ----------------------------------------------------------------------------------------------- norms
-def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, want_rstd: bool = False):
+def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, want_rstd: bool = False, out: Optional[torch.Tensor] = None):
     _req(x, BF16, "rmsnorm x"); _req(w, BF16, "rmsnorm w")
     assert x.dim() == 2 and x.stride(1) == 1
     rows, cols = x.shape
-    y = torch.empty((rows, cols), device=x.device, dtype=BF16)
+    y = _out2d(out, rows, cols, x, "rmsnorm_fwd")
     rstd = torch.empty((rows,), device=x.device, dtype=F32) if want_rstd else None
     check(_lib.load().vq3_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), _p(rstd), rows, cols, x.stride(0),
                                       y.stride(0), eps, _stream()), "vq3_rmsnorm_fwd")
@@ -123,13 +133,14 @@ def colsum_flush(jobs: list) -> None:
     jobs.clear()
 
 
-def rmsnorm_bwd(dy, x, w, rstd, dres, dw_out: torch.Tensor, accumulate: bool, eps: float = 0.0, defer: Optional[list] = None):
+def rmsnorm_bwd(dy, x, w, rstd, dres, dw_out: torch.Tensor, accumulate: bool, eps: float = 0.0, defer: Optional[list] = None,
+                out: Optional[torch.Tensor] = None):
     """Returns dx (bf16) = [dres +] d/dx; dw_out (bf16 [cols]) (+)= the weight gradient (partial slab + column sum).
     defer: a list - the column sum is appended to it instead of launched (colsum_flush runs a layer's sums in one launch)."""
     _req(dy, BF16, "rmsnorm_bwd dy"); _req(x, BF16, "rmsnorm_bwd x"); _req(dw_out, BF16, "rmsnorm_bwd dw")
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
     rows, cols = x.shape
-    dx = torch.empty_like(x)
+    dx = _out2d(out, rows, cols, x, "rmsnorm_bwd")
     nblk = (rows + 3) // 4
     part = torch.empty((nblk, cols), device=x.device, dtype=F32)
     lib = _lib.load()
@@ -160,11 +171,11 @@ def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float,
 
 
 # ----------------------------------------------------------------------------------------------- element-wise
-def silu_mul_fwd(gu: torch.Tensor) -> torch.Tensor:
+def silu_mul_fwd(gu: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(gu, BF16, "silu_mul gu")
     assert gu.is_contiguous() and gu.dim() == 2 and gu.shape[1] % 2 == 0
     rows, two_i = gu.shape
-    act = torch.empty((rows, two_i // 2), device=gu.device, dtype=BF16)
+    act = _out2d(out, rows, two_i // 2, gu, "silu_mul_fwd")
     check(_lib.load().vq3_silu_mul_fwd(gu.data_ptr(), act.data_ptr(), rows, two_i // 2, _stream()), "vq3_silu_mul_fwd")
     return act
 
@@ -252,13 +263,13 @@ def qwen_qkprep_fwd(qkv, q_w, k_w, cos, sin, B, L, Hq, Hkv, D, eps, want_rstd=Tr
 
 
 def qwen_qkprep_bwd(dQ, dK, dV, qkv, q_w, k_w, cos, sin, qr, kr, dq_w_out, dk_w_out, accumulate, B, L, Hq, Hkv, D,
-                    defer: Optional[list] = None):
+                    defer: Optional[list] = None, out: Optional[torch.Tensor] = None):
     """dq_w_out / dk_w_out: bf16 [D] gradient vectors, (+)= per `accumulate`."""
     for t in (dQ, dK, dV, qkv):
         _req(t, BF16, "qkprep_bwd"); assert t.is_contiguous()
     kv_parts = dK.shape[0] if dK.dim() == 5 else 1            # [parts, B, Hkv, L, D] partial slabs of the split dK/dV pass
     assert dV.shape == dK.shape
-    dqkv = torch.empty_like(qkv)
+    dqkv = _out2d(out, qkv.shape[0], qkv.shape[1], qkv, "qwen_qkprep_bwd")
     part = torch.empty((2, B * L, D), device=qkv.device, dtype=F32)
     lib = _lib.load()
     check(lib.vq3_qwen_qkprep_bwd(dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), qkv.data_ptr(), q_w.data_ptr(),
@@ -395,7 +406,7 @@ def vit_qkprep(qkv, N, NH, *, qn=None, kn=None, cos=None, sin=None, tokens_per_f
     return Q, K, V
 
 
-def gemm_swiglu_bwd(dY: torch.Tensor, W: torch.Tensor, gu: torch.Tensor, transB: bool) -> torch.Tensor:
+def gemm_swiglu_bwd(dY: torch.Tensor, W: torch.Tensor, gu: torch.Tensor, transB: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """silu_mul_bwd(dY @ W (or dY @ W^T), gu) in one launch: dY bf16 [M, K]; W bf16 [K, N] (transB: k-major, as a weight [out=K, in=N]
     is stored) or [N, K]; gu bf16 [M, 2N] -> dgu bf16 [M, 2N]. d(act) is never materialised (vq3_gemm_swiglu_bwd)."""
     _req(dY, BF16, "swiglu_bwd dY"); _req(W, BF16, "swiglu_bwd W"); _req(gu, BF16, "swiglu_bwd gu")
@@ -403,7 +414,7 @@ def gemm_swiglu_bwd(dY: torch.Tensor, W: torch.Tensor, gu: torch.Tensor, transB:
     M, K = dY.shape
     N = W.shape[1] if transB else W.shape[0]
     assert (W.shape[0] if transB else W.shape[1]) == K and gu.shape == (M, 2 * N)
-    dgu = torch.empty_like(gu)
+    dgu = _out2d(out, M, 2 * N, gu, "gemm_swiglu_bwd")
     d = GemmDesc()
     d.A = dY.data_ptr(); d.B = W.data_ptr(); d.C = None
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = M, N, K, dY.stride(0), W.stride(0), N, 0
@@ -565,13 +576,13 @@ def linear_fp8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, residual:
 
 
 # ---------------------------------------------------------------------------------------------- fused Qwen3 attention
-def qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, scale):
+def qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, scale, out: Optional[torch.Tensor] = None):
     """-> (O bf16 [B*L, Hq*D] token-major, LSE f32 [B, Hq, L])."""
     for t in (Q, K, V):
         _req(t, BF16, "qwen_flash"); assert t.is_contiguous()
     _req(keymask, torch.uint8, "qwen_flash keymask")
     assert Q.shape == (B, Hq, L, D) and K.shape == (B, Hkv, L, D) and V.shape == K.shape and keymask.shape == (B, L)
-    O = torch.empty((B * L, Hq * D), device=Q.device, dtype=BF16)
+    O = _out2d(out, B * L, Hq * D, Q, "qwen_flash_fwd")
     lse = torch.empty(B * Hq * L + 4, device=Q.device, dtype=F32)[: B * Hq * L].view(B, Hq, L)   # 16 B of slack
     check(_lib.load().vq3_qwen_flash_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
                                          lse.data_ptr(), B, L, Hq, Hkv, D, Hq * D, scale, _stream()), "vq3_qwen_flash_fwd")

@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .hostplan import PLAN
 from .ops import BF16, F32, round_up
 
 
@@ -113,6 +114,14 @@ class Qwen3ForCausalLM(nn.Module):
             self._wgrad_stream = torch.cuda.Stream(device=self.device_)
         self._fp8 = None
         self._wt = None
+        # deferred weight-gradient GEMMs (enable_wgrad_deferral): operand slabs, rows pending, forward/backward pairing ticket
+        self._wd_depth = 1
+        self._wd_slabs = None
+        self._wd_cap = 0
+        self._wd_rows = [0] * config.num_hidden_layers          # per layer: token rows waiting in its slabs
+        self._wd_first_acc = [False] * config.num_hidden_layers  # per layer: does its next product add to flat_g or overwrite it
+        self._wd_ticket = 0
+        self._wd_count = 0                                       # backward passes since the last full flush
         # fused causal attention (csrc/qwen_flash.hip) covers up to 4 query heads per kv head (Qwen3-4B: 4);
         # VQ3_QWEN_FLASH=0 keeps the batched GEMM + softmax chain
         self._flash = self.Hq % self.Hkv == 0 and self.Hq // self.Hkv <= 4 and os.environ.get("VQ3_QWEN_FLASH", "1") != "0"
@@ -353,7 +362,7 @@ class Qwen3ForCausalLM(nn.Module):
         return ops.linear(x, self._w[name], residual=residual)
 
     # ------------------------------------------------------------------ forward
-    def _attention_fwd(self, i, xn, B, L, keymask, ctx):
+    def _attention_fwd(self, i, xn, B, L, keymask, ctx, ao_out=None):
         """L is a multiple of 8 here (forward_hidden pads). Scores are materialised per (b, head) - at L = 200 the
         attention is < 1 % of the FLOPs - as batched GEMMs that read Q, K, V exactly as the prep kernel wrote them."""
         c = self.config
@@ -364,7 +373,7 @@ class Qwen3ForCausalLM(nn.Module):
                                               D, c.rms_norm_eps, want_rstd=ctx is not None)
         if self._flash:
             # fused causal GQA attention: scores stay in registers; LSE is all the backward needs
-            ao, lse = ops.qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, D ** -0.5)
+            ao, lse = ops.qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, D ** -0.5, out=ao_out)
             if ctx is not None:
                 ctx.update(qkv=qkv, Q=Q, K=K, V=V, qr=qr, kr=kr, lse=lse, ao=ao)
             return ao
@@ -372,7 +381,7 @@ class Qwen3ForCausalLM(nn.Module):
         ops.gemm_raw(Q, K, S, L, L, D, D, D, L, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * D, L * D),
                      sB=(Hkv * L * D, L * D), sC=(Hq * L * L, L * L), alpha=D ** -0.5)
         P = ops.softmax_fwd(S, keymask, Hq, L, L, True)
-        ao = torch.empty((B * L, Hq * D), device=xn.device, dtype=BF16)
+        ao = ao_out if ao_out is not None else torch.empty((B * L, Hq * D), device=xn.device, dtype=BF16)
         # O[b,h] = P[b,h] . V[b,h/G]  (V [L, D] is the k-major B operand)
         ops.gemm_raw(P, V, ao, L, D, L, L, D, Hq * D, nb1=B, nb2=Hq, b2divB=G, sA=(Hq * L * L, L * L),
                      sB=(Hkv * L * D, L * D), sC=(L * Hq * D, D), transB=True)
@@ -380,7 +389,7 @@ class Qwen3ForCausalLM(nn.Module):
             ctx.update(qkv=qkv, Q=Q, K=K, V=V, qr=qr, kr=kr, P=P, ao=ao)
         return ao
 
-    def forward_hidden(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, save: bool):
+    def forward_hidden(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, save: bool, plan_key=None):
         """36x decoder layer (modeling_qwen3.py:294-323, 367-427). Returns (h_last [B*L,H] pre-final-norm, saved)."""
         B, L0, H = inputs_embeds.shape
         c = self.config
@@ -399,24 +408,30 @@ class Qwen3ForCausalLM(nn.Module):
             nkb = (L + 31) // 32
             pad = nkb * 32 - L
             km = torch.nn.functional.pad(keymask, (0, pad)) if pad else keymask
-            live = int(km.view(B, nkb, 32).any(-1).sum().item())
+            count = lambda: int(km.view(B, nkb, 32).any(-1).sum().item())
+            live = PLAN.get(("live_key_tiles", L), plan_key, count) if plan_key is not None else count()
             kv_parts = 2 if live * 2 <= B * nkb else 1
         h = inputs_embeds.reshape(B * L, H)
         saved: List[dict] = []
+        wd_off = self._wd_begin(B * L) if save else None       # row offset of this micro-batch in the deferred-wgrad slabs (or None)
+        wv = (lambda i, key: self._wd_view(i, key, wd_off, B * L)) if wd_off is not None else (lambda i, key: None)
         for i in range(c.num_hidden_layers):
             ctx = {} if save else None
-            xn1, r1 = ops.rmsnorm_fwd(h, self._w[f"l{i}.ln1"], c.rms_norm_eps, want_rstd=True)
-            ao = self._attention_fwd(i, xn1, B, L, keymask, ctx)
+            xn1, r1 = ops.rmsnorm_fwd(h, self._w[f"l{i}.ln1"], c.rms_norm_eps, want_rstd=True, out=wv(i, "qkv.X"))
+            ao = self._attention_fwd(i, xn1, B, L, keymask, ctx, ao_out=wv(i, "o.X"))
             h_mid = self._proj(ao, f"l{i}.o", residual=h)
-            xn2, r2 = ops.rmsnorm_fwd(h_mid, self._w[f"l{i}.ln2"], c.rms_norm_eps, want_rstd=True)
+            xn2, r2 = ops.rmsnorm_fwd(h_mid, self._w[f"l{i}.ln2"], c.rms_norm_eps, want_rstd=True, out=wv(i, "gu.X"))
             gu = self._proj(xn2, f"l{i}.gu")
-            act = ops.silu_mul_fwd(gu)
+            act = ops.silu_mul_fwd(gu, out=wv(i, "down.X"))
             h_out = self._proj(act, f"l{i}.down", residual=h_mid)
             if save:
                 ctx.update(h_in=h, r1=r1, xn1=xn1, h_mid=h_mid, r2=r2, xn2=xn2, gu=gu, act=act)
                 saved.append(ctx)
             h = h_out
-        return h, {"layers": saved, "B": B, "L": L, "L0": L0, "keymask": keymask, "kv_parts": kv_parts}
+        out = {"layers": saved, "B": B, "L": L, "L0": L0, "keymask": keymask, "kv_parts": kv_parts}
+        if wd_off is not None:
+            out["wd_off"], out["wd_ticket"] = wd_off, self._wd_ticket
+        return h, out
 
     @staticmethod
     def label_rows(labels: torch.Tensor):
@@ -430,7 +445,7 @@ class Qwen3ForCausalLM(nn.Module):
         idx = (flat != -100).nonzero(as_tuple=False).squeeze(1)
         return idx.to(torch.int32), flat[idx].to(torch.int32)
 
-    def loss_head(self, h_last: torch.Tensor, labels: torch.Tensor, save: bool, L: Optional[int] = None):
+    def loss_head(self, h_last: torch.Tensor, labels: torch.Tensor, save: bool, L: Optional[int] = None, plan_key=None):
         """Final RMSNorm + tied lm_head + shifted mean cross-entropy, evaluated only on the rows that carry a label
         (the other rows of the reference's [B,L,V] logits never reach the loss). Also leaves d(loss)/d(logits) in
         place for the backward."""
@@ -438,7 +453,10 @@ class Qwen3ForCausalLM(nn.Module):
         H = c.hidden_size
         if L is not None and labels.shape[1] < L:   # h_last rows follow the padded length of forward_hidden
             labels = torch.cat([labels, labels.new_full((labels.shape[0], L - labels.shape[1]), -100)], dim=1)
-        idx, tgt = self.label_rows(labels)
+        if plan_key is not None:
+            idx, tgt = PLAN.get(("label_rows", tuple(labels.shape)), plan_key, lambda: self.label_rows(labels))
+        else:
+            idx, tgt = self.label_rows(labels)
         n = int(idx.numel())
         if n == 0:
             return torch.full((), float("nan"), device=h_last.device, dtype=F32), None
@@ -463,8 +481,82 @@ class Qwen3ForCausalLM(nn.Module):
                      c.hidden_size, self.vocab_p)
         return out[:, : self.vocab]
 
+    # ------------------------------------------------------------------ deferred weight gradients
+    # dW = sum over the window's micro-batches of dY_j^T . X_j is ONE product over the concatenated token rows: [dY_1; dY_2; ..]^T .
+    # [X_1; X_2; ..]. Run per micro-batch (contraction = 1200 rows) every weight-gradient GEMM re-reads and re-writes its whole bf16
+    # gradient (16 GB of HBM traffic per micro-batch at Qwen3-4B) behind 19 K steps; run once per `depth` micro-batches the same kernels
+    # reach 0.9-1.1 PF/s instead of 0.54-0.70 (tools/bench_wgrad_k.py) and the partial sums of the group stay in the MFMA's f32
+    # accumulators. Cost: the operands must outlive their micro-batch - per layer eight bf16 slabs [depth * rows, cols] (99 KB per
+    # token row: 34 GB at depth 8, rows 1200, 36 layers), which the producing kernels write in place (`out=`), so nothing is copied.
+    # The layers do not all multiply on the same micro-batch: layer i does when (micro-batch index + i) % depth == depth - 1, so every
+    # backward pass carries 1 / depth of the layers' (long) products on the weight-gradient stream, where they fill the CUs that the
+    # 200-tile dgrad GEMMs of the main stream leave idle - all of them on one micro-batch in `depth` would run alone after its backward.
+    WD_KEYS = ("down.dY", "down.X", "gu.dY", "gu.X", "o.dY", "o.X", "qkv.dY", "qkv.X")
+
+    def _wd_cols(self, key: str) -> int:
+        c = self.config
+        I, H = c.intermediate_size, c.hidden_size
+        return {"down.dY": H, "down.X": I, "gu.dY": 2 * I, "gu.X": H, "o.dY": H, "o.X": self.Hq * self.D,
+                "qkv.dY": (self.Hq + 2 * self.Hkv) * self.D, "qkv.X": H}[key]
+
+    def enable_wgrad_deferral(self, depth: int) -> None:
+        """depth micro-batches share one weight-gradient GEMM per projection (1 = off: one per micro-batch, no slabs). The caller's
+        loop must alternate forward_hidden(save=True) / backward_hidden and pass flush=True on the last micro-batch of every
+        accumulation window (Stage1Trainer does)."""
+        if any(self._wd_rows):
+            raise RuntimeError("enable_wgrad_deferral: a group of micro-batches is pending; flush it first")
+        self._wd_depth = max(1, int(depth))
+        if self._wd_depth == 1:
+            self._wd_slabs, self._wd_cap = None, 0
+
+    def _wd_begin(self, rows: int):
+        if self._wd_depth <= 1:
+            return None
+        if self._wd_slabs is None or rows > self._wd_cap:
+            if any(self._wd_rows):
+                self.flush_deferred()
+            per_row = sum(self._wd_cols(k) for k in self.WD_KEYS) * 2 * self.config.num_hidden_layers
+            depth = self._wd_depth
+            free = torch.cuda.mem_get_info(self.device_)[0] if self.device_.type == "cuda" else 1 << 62
+            held = 0 if self._wd_slabs is None else per_row * self._wd_cap
+            while depth > 1 and per_row * rows * depth > 0.6 * (free + held):     # leave room for the step itself
+                depth //= 2
+            if depth <= 1:
+                self._wd_depth, self._wd_slabs, self._wd_cap = 1, None, 0
+                return None
+            self._wd_slabs = None                                  # release before the new allocation
+            cap = rows * depth
+            self._wd_slabs = {(i, k): torch.zeros((cap, self._wd_cols(k)), device=self.device_, dtype=BF16)
+                              for i in range(self.config.num_hidden_layers) for k in self.WD_KEYS}
+            self._wd_cap = cap
+        if max(self._wd_rows) + rows > self._wd_cap:               # (rows vary with trimmed padding) no room left: flush what is pending
+            self.flush_deferred()
+        self._wd_ticket += 1
+        return list(self._wd_rows)                                 # this micro-batch's row offset in every layer's slabs
+
+    def _wd_view(self, i: int, key: str, off, rows: int) -> torch.Tensor:
+        return self._wd_slabs[(i, key)][off[i]:off[i] + rows]
+
+    def _wd_flush_layer(self, i: int, rows: int):
+        for name in ("down", "gu", "o", "qkv"):
+            self._wgrad(f"l{i}.{name}", self._wd_slabs[(i, name + ".dY")][:rows], self._wd_slabs[(i, name + ".X")][:rows],
+                        self._wd_first_acc[i], slab=True)
+        self._wd_rows[i] = 0
+
+    def flush_deferred(self, layer_done=None) -> None:
+        """Weight-gradient GEMMs over the rows still pending (a window that ends on a micro-batch without labels, a slab resize, a
+        look at flat_g in the middle of a window)."""
+        for i in reversed(range(self.config.num_hidden_layers)):
+            if self._wd_rows[i]:
+                self._wd_flush_layer(i, self._wd_rows[i])
+            if layer_done is not None:
+                self.join_wgrad_stream()
+                layer_done(i)
+        self.join_wgrad_stream()
+        self._wd_count = 0
+
     # ------------------------------------------------------------------ backward
-    def _wgrad(self, name: str, dY: torch.Tensor, X: torch.Tensor, accumulate: bool):
+    def _wgrad(self, name: str, dY: torch.Tensor, X: torch.Tensor, accumulate: bool, slab: bool = False):
         """dW[N,K] (+)= dY^T[N,M] . X[M,K]: dY and X are read as stored (k-major A and B operands, contraction = token
         rows). Weight gradients have no consumer inside the backward, so they are enqueued on a second HIP stream:
         their GEMM tails overlap the dgrad chain on the main one."""
@@ -476,8 +568,9 @@ class Qwen3ForCausalLM(nn.Module):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self._wgrad_now(name, dY, X, accumulate)
-        dY.record_stream(side)
-        X.record_stream(side)
+        if not slab:                                     # (slabs live as long as the model)
+            dY.record_stream(side)
+            X.record_stream(side)
 
     def _wgrad_now(self, name: str, dY: torch.Tensor, X: torch.Tensor, accumulate: bool):
         M, N = dY.shape
@@ -528,56 +621,85 @@ class Qwen3ForCausalLM(nn.Module):
                          sB=(Hq * L * D, G * L * D), sC=(Hkv * L * D, L * D), transA=True, transB=True)
         return dQ, dK, dV
 
-    def backward_hidden(self, saved, dh: torch.Tensor, accumulate: bool, gscale_hook=None, layer_done=None):
+    def backward_hidden(self, saved, dh: torch.Tensor, accumulate: bool, gscale_hook=None, layer_done=None, flush: bool = True):
         """Backward through the decoder stack. dh: d(loss)/d(h_last) [B*L, H] bf16. Gradients go to flat_g
         (accumulate=False overwrites). layer_done(i) is called when layer i's gradients are final (DP overlap hook).
-        Returns d(inputs_embeds) [B*L, H]."""
+        flush (only with enable_wgrad_deferral): False keeps this micro-batch's weight-gradient operands in the slabs for a later
+        micro-batch of the same window to multiply; the window's last micro-batch must pass True. Returns d(inputs_embeds) [B*L, H]."""
         c = self.config
         B, L = saved["B"], saved["L"]
         H, D = c.hidden_size, self.D
         dev = dh.device
         cos, sin = self.rope(L)
         norm_jobs: list = []       # the layer's four norm-weight column sums, run in one launch at its end
+        M = B * L
+        wd_off = saved.get("wd_off")
+        if wd_off is not None:
+            if saved.get("wd_ticket") != self._wd_ticket or wd_off != self._wd_rows:
+                raise RuntimeError("deferred weight gradients: forward_hidden(save=True) and backward_hidden must alternate "
+                                   "(another forward has reused this micro-batch's operand rows)")
+            wv = lambda i, key: self._wd_view(i, key, wd_off, M)
+            top = wv(c.num_hidden_layers - 1, "down.dY")
+            top.copy_(dh)
+            dh = top
+            phase = self._wd_count
+            self._wd_count += 1
+        else:
+            wv = lambda i, key: None
         for i in reversed(range(c.num_hidden_layers)):
             ctx = saved["layers"][i]
             # down_proj
             # d(act) = dh . W_down with the SwiGLU backward in the GEMM epilogue: d(gate | up) leaves directly
             wt = getattr(self, "_wt", None)
             if wt is not None and f"l{i}.down" in wt and dh.is_contiguous():
-                dgu = ops.gemm_swiglu_bwd(dh, wt[f"l{i}.down"], ctx["gu"], transB=False)
+                dgu = ops.gemm_swiglu_bwd(dh, wt[f"l{i}.down"], ctx["gu"], transB=False, out=wv(i, "gu.dY"))
             else:
-                dgu = ops.gemm_swiglu_bwd(dh, self._w[f"l{i}.down"], ctx["gu"], transB=True)
-            self._wgrad(f"l{i}.down", dh, ctx["act"], accumulate)
+                dgu = ops.gemm_swiglu_bwd(dh, self._w[f"l{i}.down"], ctx["gu"], transB=True, out=wv(i, "gu.dY"))
+            if wd_off is None:
+                self._wgrad(f"l{i}.down", dh, ctx["act"], accumulate)
             d_xn2 = self._dgrad(dgu, f"l{i}.gu")
-            self._wgrad(f"l{i}.gu", dgu, ctx["xn2"], accumulate)
+            if wd_off is None:
+                self._wgrad(f"l{i}.gu", dgu, ctx["xn2"], accumulate)
             dh_mid = ops.rmsnorm_bwd(d_xn2, ctx["h_mid"], self._w[f"l{i}.ln2"], ctx["r2"], dh, self._g[f"l{i}.ln2"],
-                                     accumulate, defer=norm_jobs)
+                                     accumulate, defer=norm_jobs, out=wv(i, "o.dY"))
             # o_proj
             # d(attention out) head-major [B, Hq, L, D]: one batch per (b, head) over the column block of W_o
             Wo = self._w[f"l{i}.o"]
             if self._flash:
                 d_ao = self._dgrad(dh_mid, f"l{i}.o")                   # token-major [B*L, Hq*D]: one plain GEMM
-                self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
+                if wd_off is None:
+                    self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
                 dQ, dK, dV = ops.qwen_flash_bwd(ctx["Q"], ctx["K"], ctx["V"], saved["keymask"], ctx["ao"], d_ao, ctx["lse"],
                                                 B, L, self.Hq, self.Hkv, D, D ** -0.5, kv_parts=saved.get("kv_parts", 1))
             else:
                 d_ao = torch.empty((B, self.Hq, L, D), device=dev, dtype=BF16)
                 ops.gemm_raw(dh_mid, Wo, d_ao, L, D, H, H, self.Hq * D, D, nb1=B, nb2=self.Hq, sA=(L * H, 0), sB=(0, D),
                              sC=(self.Hq * L * D, L * D), transB=True)
-                self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
+                if wd_off is None:
+                    self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
                 dQ, dK, dV = self._attention_bwd(i, ctx, d_ao, B, L)
             dqkv = ops.qwen_qkprep_bwd(dQ, dK, dV, ctx["qkv"], self._w[f"l{i}.qn"], self._w[f"l{i}.kn"], cos, sin,
                                        ctx["qr"], ctx["kr"], self._g[f"l{i}.qn"], self._g[f"l{i}.kn"], accumulate, B, L,
-                                       self.Hq, self.Hkv, D, defer=norm_jobs)
+                                       self.Hq, self.Hkv, D, defer=norm_jobs, out=wv(i, "qkv.dY"))
             d_xn1 = self._dgrad(dqkv, f"l{i}.qkv")
-            self._wgrad(f"l{i}.qkv", dqkv, ctx["xn1"], accumulate)
+            if wd_off is None:
+                self._wgrad(f"l{i}.qkv", dqkv, ctx["xn1"], accumulate)
+            else:
+                if wd_off[i] == 0:
+                    self._wd_first_acc[i] = accumulate     # the group's products overwrite or add as its first micro-batch would have
+                if flush or (phase + i) % self._wd_depth == self._wd_depth - 1 or wd_off[i] + 2 * M > self._wd_cap:
+                    self._wd_flush_layer(i, wd_off[i] + M)   # the layer's four products over every pending row, this micro-batch's included
+                else:
+                    self._wd_rows[i] = wd_off[i] + M
             dh = ops.rmsnorm_bwd(d_xn1, ctx["h_in"], self._w[f"l{i}.ln1"], ctx["r1"], dh_mid, self._g[f"l{i}.ln1"],
-                                 accumulate, defer=norm_jobs)
+                                 accumulate, defer=norm_jobs, out=wv(i - 1, "down.dY") if (wd_off is not None and i > 0) else None)
             ops.colsum_flush(norm_jobs)
             if layer_done is not None:
                 self.join_wgrad_stream()
                 layer_done(i)
         self.join_wgrad_stream()
+        if wd_off is not None and flush:
+            self._wd_count = 0
         return dh
 
     def backward_loss_head(self, head_ctx, rows: int, gscale: float, accumulate: bool) -> torch.Tensor:

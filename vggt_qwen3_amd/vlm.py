@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .hostplan import PLAN
 from .ops import BF16, F32
 from .perceiver import PerceiverConfig, PerceiverProjector
 from .qwen3 import Qwen3Config, Qwen3ForCausalLM
@@ -267,7 +268,7 @@ class VGGTQwen3VLM(nn.Module):
 
     # ------------------------------------------------------------------ splice (integer work, host side)
     def _srcmap(self, input_ids: torch.Tensor, S: int) -> torch.Tensor:
-        return build_srcmap(input_ids, self.image_id, S)
+        return PLAN.get(("srcmap", self.image_id, S), (input_ids,), lambda: build_srcmap(input_ids, self.image_id, S))
 
     # ------------------------------------------------------------------ forward / backward
     def forward_state(self, images, geom_token, input_ids, attention_mask, labels, need_grad: bool) -> dict:
@@ -277,6 +278,7 @@ class VGGTQwen3VLM(nn.Module):
         input_ids = input_ids.to(self.device_)
         attention_mask = attention_mask.to(self.device_)
         labels = labels.to(self.device_)
+        attention_mask0, labels0 = attention_mask, labels       # the caller's tensors: keys of the remembered host-side facts
         B, L = input_ids.shape
         images = images.to(self.device_)
         vis = self._take_prefetched(images)
@@ -295,8 +297,10 @@ class VGGTQwen3VLM(nn.Module):
         if self.trim_padding:
             # Exact shortcut: columns after the last attended / labelled position of the whole batch are padding for
             # every row - masked as keys, never read as queries, no label - so they cannot change loss or gradients.
-            used = ((attention_mask != 0) | (labels != -100)).any(dim=0).nonzero()
-            L_eff = int(used.max().item()) + 1 if used.numel() else 1
+            def last_used():
+                used = ((attention_mask != 0) | (labels != -100)).any(dim=0).nonzero()
+                return int(used.max().item()) + 1 if used.numel() else 1
+            L_eff = PLAN.get("last_used_column", (attention_mask0, labels0), last_used)
             L_eff = min(L, max(8, (L_eff + 7) // 8 * 8))
             if L_eff < L:
                 input_ids = input_ids[:, :L_eff].contiguous()
@@ -306,12 +310,12 @@ class VGGTQwen3VLM(nn.Module):
                 L = L_eff
         self._last_L = L
         emb = ops.embed_splice_fwd(input_ids.contiguous(), tm._w["embed"], feats16, srcmap, B, L, H, S)
-        h_last, saved = tm.forward_hidden(emb, attention_mask, save=need_grad)
-        loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad, L=saved["L"])
+        h_last, saved = tm.forward_hidden(emb, attention_mask, save=need_grad, plan_key=(attention_mask0,))
+        loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad, L=saved["L"], plan_key=(labels0,))
         return dict(loss=loss, saved=saved, head=head_ctx, srcmap=srcmap, input_ids=input_ids, B=B, L=L, S=S,
                     geom_ctx=geom_ctx, geom_y=gy, emb=emb, h_last=h_last)
 
-    def _backward_text(self, st: dict, gscale: float, accumulate: bool, layer_done=None):
+    def _backward_text(self, st: dict, gscale: float, accumulate: bool, layer_done=None, flush: bool = True):
         """Backward of everything that has gradients in the reference: Qwen3 (all parameters, tied embedding) and,
         when geometry tokens are present, geom_head. Returns d(loss)/d(geom_head output) or None."""
         tm = self.text_model
@@ -324,13 +328,15 @@ class VGGTQwen3VLM(nn.Module):
             # every rank issues the same sequence of bucket all-reduces.
             if not accumulate:
                 tm.zero_grad_flat()
-            if layer_done is not None:
+            if flush and any(tm._wd_rows):
+                tm.flush_deferred(layer_done)        # earlier micro-batches of the window still wait for their weight-gradient GEMMs
+            elif layer_done is not None:
                 for i in reversed(range(tm.config.num_hidden_layers)):
                     layer_done(i)
             return None
         Lp = st["saved"]["L"]                                   # forward_hidden pads L to a multiple of 8
         dh = tm.backward_loss_head(st["head"], B * Lp, gscale, accumulate)
-        d_emb = tm.backward_hidden(st["saved"], dh, accumulate, layer_done=layer_done)
+        d_emb = tm.backward_hidden(st["saved"], dh, accumulate, layer_done=layer_done, flush=flush)
         if Lp != L:
             d_emb = d_emb.view(B, Lp, H)[:, :L].contiguous()
         ids = st["input_ids"].reshape(-1)
