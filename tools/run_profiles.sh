@@ -1,15 +1,23 @@
 #!/bin/bash
-# Round-2 profiling passes (run on the GPU box through gpurun): kernel trace of the default bench, the serial accum-4 trace for the
-# per-micro-batch breakdown, and four separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA busy / LDS conflicts).
+# Round-2 profiling passes (run on the GPU box through gpurun; usage: bash tools/run_profiles.sh <commit>): kernel stats of the default
+# bench, the serial accum-8 trace for the per-micro-batch / per-shape breakdowns, and four separate --pmc passes (FETCH_SIZE / WRITE_SIZE /
+# MFMA busy / LDS conflicts). The summaries land in gpurun_out/r2_prof/out (copy them to profiles/); the raw traces are deleted.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+COMMIT=${1:-unknown}
 O=gpurun_out/r2_prof
-mkdir -p $O
-SHORT="bench.py --steps 8 --grad-accum 4 --warmup 4 --no-variants --no-trim-variant --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -o d -- python3 bench.py --no-variants --no-trim-variant --no-cpu-baseline > $O/default.log 2>&1 && echo default ok
-VQ3_WGRAD_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d $O/serial -o s -- python3 $SHORT > $O/serial.log 2>&1 && echo serial ok
+rm -rf $O; mkdir -p $O/out
+SHORT="bench.py --steps 16 --grad-accum 8 --warmup 8 --no-variants --no-trim-variant --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -o d -- python3 bench.py --no-variants --no-trim-variant --no-cpu-baseline > $O/default.log 2>&1 && cp $O/default/d_kernel_stats.csv $O/out/r2_default_bench_kernel_stats.csv && echo default ok
+rm -rf $O/default
+VQ3_WGRAD_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d $O/serial -o s -- python3 $SHORT > $O/serial.log 2>&1 && python tools/step_breakdown.py $O/serial/s_kernel_trace.csv $O/out/r2_step_breakdown_accum8_serial.csv > /dev/null && python tools/trace_by_shape.py $O/serial/s_kernel_trace.csv $O/out/r2_step_by_shape_accum8_serial.csv > /dev/null && echo serial ok
+rm -rf $O/serial
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $SHORT > $O/fetch.log 2>&1 && echo fetch ok
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $SHORT > $O/write.log 2>&1 && echo write ok
+python tools/summarize_pmc.py $O/fetch/f_counter_collection.csv $O/write/w_counter_collection.csv $O/out/r2_pmc "$COMMIT" "rocprofv3 --pmc <counter> -- python3 $SHORT (window: the longest accumulation window of the run)" > /dev/null && echo traffic ok
+rm -rf $O/fetch $O/write
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o m -- python3 $SHORT > $O/mfma.log 2>&1 && echo mfma ok
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/lds -o l -- python3 $SHORT > $O/lds.log 2>&1 && echo lds ok
-ls -la $O/*/ | head -40
+python tools/summarize_pmc_mfma.py $O/mfma/m_counter_collection.csv $O/lds/l_counter_collection.csv $O/out/r2_pmc_mfma_lds.csv > /dev/null && echo mfma_lds ok
+rm -rf $O/mfma $O/lds
+ls -la $O/out
