@@ -122,6 +122,38 @@ def test_gemm_forced_configs_with_epilogues(ops, cfg):
         ops.gemm_force_config(-3)
 
 
+def test_gemm_whole_rounds_plus_row_tail(ops):
+    """cfg 30 (gemm.hip: launch_split_rows): the 256 x 256 kernel on the row tiles that fill whole rounds of the chip + a second launch
+    for the remaining rows - here 65 x 4 = 260 tiles = one round of 256 CUs + 4: rows 0..16383 and a 116-row tail. Same contract as
+    every other configuration, epilogue operands offset with the rows."""
+    try:
+        ops.gemm_force_config(30)
+        M, N, K = 16500, 1024, 256
+        A = _rand((M, K), 0.5, seed=3); W = _rand((N, K), 0.5, seed=4)
+        bias = _rand((N,), 1.0, F32, seed=5); cs = _rand((N,), 1.0, F32, seed=6)
+        R16 = _rand((M, N), 1.0, seed=7)
+        base = A.float() @ W.float().t()
+        out = ops.linear(A, W)
+        assert _relerr(out, base) < 4e-3
+        assert _relerr(out[-116:], base[-116:]) < 4e-3 and _relerr(out[16300:16400], base[16300:16400]) < 4e-3
+        out = ops.linear(A, W, bias=bias, colscale=cs, residual=R16, act=ops.ACT_GELU, alpha=0.5)
+        t = (base * 0.5 + bias).to(BF16)
+        t = torch.nn.functional.gelu(t.float()).to(BF16)
+        t = (t.float() * cs).to(BF16)
+        ref = (t.float() + R16.float()).to(BF16)
+        assert _relerr(out, ref) < 4e-3 and _relerr(out[-116:], ref[-116:]) < 4e-3
+        C = _rand((M, N), 1.0, seed=8); C0 = C.clone()
+        ops.linear(A, W, out=C, accumulate=True)
+        assert _relerr(C, base + C0.float()) < 4e-3 and _relerr(C[-116:], (base + C0.float())[-116:]) < 4e-3
+        out32 = ops.linear(A, W, bias=bias, out_dtype=F32)
+        assert _relerr(out32, base + bias) < 1e-5
+        # a shape the split does not apply to falls back to the plain 256 x 256 launch
+        A2 = _rand((300, 192), 0.5, seed=9); W2 = _rand((520, 192), 0.5, seed=10)
+        assert _relerr(ops.linear(A2, W2), A2.float() @ W2.float().t()) < 4e-3
+    finally:
+        ops.gemm_force_config(-3)
+
+
 @pytest.mark.parametrize("sched", [102, 103, 105])
 def test_gemm_kmajor_layouts_all_schedules(ops, sched):
     """The any-layout kernel (gemm3.hip) in each of its schedules - 128x128 two-stage, 128x128 loader ring, 256x128 loader ring -

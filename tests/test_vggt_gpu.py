@@ -176,3 +176,38 @@ def test_fused_qkv_epilogue_equals_linear_plus_vit_qkprep(use_norm, use_rope, cf
         assert (a.float() - b.float()).abs().max() <= 2 ** -6 * b.float().abs().max(), name
         assert ((a.float() - b.float()).norm() / b.float().norm()).item() < 2e-3, name
     assert torch.equal(got[2], ref[2])                   # V is a pure copy
+
+
+def test_fused_qkv_epilogue_with_row_tail_launch():
+    """cfg 30 (whole rounds of 256 x 256 tiles + a small-tile launch for the remaining rows) under the fused q|k|v epilogue: the tail
+    launch starts at token 16 384 of 16 632 (its rows' group / token indices must carry that offset). 7 groups of 2376 tokens
+    (= 8 frames of 5 + 292 patch tokens; 65 x 12 = 780 tiles = 3 rounds of 256 + 12)."""
+    from vggt_qwen3_amd import ops
+    torch.manual_seed(2)
+    NH, C, Wp, ps = 16, 128, 4, 5
+    P = ps + 73 * Wp                                     # 297 tokens per frame
+    G, N = 7, 8 * P
+    T = G * N
+    assert T == 16632
+    x = torch.randn(T, C, device="cuda").to(BF16)
+    w = (torch.randn(3 * NH * 64, C, device="cuda") * 0.06).to(BF16)
+    bias = torch.randn(3 * NH * 64, device="cuda") * 0.1
+    qn = (torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1)
+    kn = (torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1)
+    ang = torch.rand(75, 16, device="cuda") * 3.0
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(BF16).contiguous(), emb.sin().to(BF16).contiguous()
+    kw = dict(qn=qn, kn=kn, cos=cos, sin=sin, tokens_per_frame=P, patch_start=ps, Wp=Wp, eps=1e-5)
+    try:
+        ops.gemm_force_config(20)
+        ref = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
+        ops.gemm_force_config(30)
+        got = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
+    finally:
+        ops.gemm_force_config(-3)
+    for name, a, b in zip("QKV", got, ref):
+        af, bf = a.float().reshape(-1, NH, N, 64), b.float().reshape(-1, NH, N, 64)
+        assert (af - bf).abs().max() <= 2 ** -6 * bf.abs().max(), name
+        assert ((af - bf).norm() / bf.norm()).item() < 2e-3, name
+        # the tail rows are the last 248 tokens of the last group
+        assert ((af[-1, :, -248:] - bf[-1, :, -248:]).norm() / bf[-1, :, -248:].norm()).item() < 2e-3, name

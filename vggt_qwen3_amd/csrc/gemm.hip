@@ -225,9 +225,52 @@ bool autotune_on(hipStream_t s) {
   return true;
 }
 
+// cfg 30: the 256 x 256 kernel on the row tiles that make WHOLE rounds of the chip, the remaining rows as a second small-tile launch.
+// M = 49 392 (8 views x 6 x 1029 tokens), N = 1024 is 193 x 4 = 772 tiles = 3 rounds of 256 CUs + 4 tiles: the 4 cost a fourth round
+// (fc2: 500 us where 3 rounds take 375). Rows 0 .. 192 * 256 - 1 are exactly 3 rounds; the last 240 rows are 16 tiles of 128 x 128.
+int g_num_cu = 0;
+int num_cus() {
+  if (!g_num_cu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    (void)hipGetLastError();
+    g_num_cu = n;
+  }
+  return g_num_cu;
+}
+// rows the 256 x 256 launch takes (0 = the split does not apply to this shape)
+int split_rows_main(const GemmParams& p, int nbatch) {
+  if (nbatch != 1 || p.epi == 2 || p.M < 512) return 0;
+  const long nt = (p.N + 255) / 256, mt = (p.M + 255) / 256, cu = num_cus();
+  const long rounds = mt * nt / cu, rem = mt * nt % cu;
+  if (rounds < 1 || rem == 0 || rem * 2 > cu) return 0;         // a last round at least half full is left alone
+  const long mt_main = rounds * cu / nt;
+  const long tail = p.M - mt_main * 256;
+  if (mt_main < 1 || tail <= 0 || tail > 2048) return 0;
+  return (int)(mt_main * 256);
+}
+int choose_config(int M, int N, int K, int nbatch);
+int launch_split_rows(GemmParams p, int nbatch, hipStream_t s) {
+  const int m_main = split_rows_main(p, nbatch);
+  if (!m_main) return launch_gemm_v6(p, 0, nbatch, s);
+  GemmParams a = p, b = p;
+  a.M = m_main;
+  b.M = p.M - m_main;
+  const size_t esz = p.out_f32 ? 4 : 2;
+  b.A = p.A + (long)m_main * p.lda;
+  b.C = (char*)p.C + (size_t)m_main * p.ldc * esz;
+  if (p.R) b.R = (const char*)p.R + (size_t)m_main * p.ldr * esz;
+  if (p.epi == 1) { b.C = p.C; b.vit.m_off = m_main; }      // Q / K / V are addressed by token index, C is a placeholder
+  int rc = launch_gemm_v6(a, 0, nbatch, s);
+  if (rc) return rc;
+  const long t128 = (long)((b.M + 127) / 128) * ((b.N + 127) / 128);
+  return launch_gemm_v2(b, (p.K <= 1536 && t128 > num_cus()) ? 7 : 13, nbatch, s);
+}
+
 // launches one candidate; cand < 100: NT config (v2 cfg id or 20 = v6); cand >= 100: v3 with (cand - 100) stages
 int launch_candidate(GemmParams p, int cand, int transA, int transB, int nbatch, hipStream_t s) {
   if (cand >= 100) return launch_gemm_v3(p, transA, transB, cand - 100, nbatch, s);
+  if (cand == 30) return launch_split_rows(p, nbatch, s);
   if (cand >= 20 && cand <= 22) return launch_gemm_v6(p, cand - 20, nbatch, s);
   return launch_gemm_v2(p, cand, nbatch, s);
 }
@@ -343,6 +386,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     p.vit.cos = (const bf16_t*)ve->cos; p.vit.sin = (const bf16_t*)ve->sin;
     p.vit.N = ve->N; p.vit.NH = ve->NH; p.vit.P = ve->tokens_per_frame; p.vit.patch_start = ve->patch_start; p.vit.Wp = ve->Wp;
     p.vit.use_norm = ve->use_norm; p.vit.use_rope = ve->use_rope; p.vit.eps = ve->eps;
+    p.vit.m_off = 0;
     p.C = ve->Q; p.ldc = d->N;          // placeholders: the staged epilogue checks their alignment, nothing is stored through them
     p.sC1 = p.sC2 = 0;
   }
@@ -394,7 +438,14 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     if ((long)((d->M + 255) / 256) * ((d->N + 255) / 256) * nbatch >= 64) cands.push_back(20);
     if ((long)((d->M + 255) / 256) * ((d->N + 127) / 128) * nbatch >= 64) cands.push_back(21);
     if ((long)((d->M + 127) / 128) * ((d->N + 255) / 256) * nbatch >= 64) cands.push_back(22);
+    if (split_rows_main(p, nbatch)) cands.push_back(30);
     cfg = tuned_choice(p, 0, 0, nbatch, s, cands, cfg);
+  }
+  if (cfg == 30) {
+    const int rc = launch_split_rows(p, nbatch, s);
+    if (rc) return rc;
+    VQ3_CHECK_LAUNCH("gemm_bf16_nt(v6 + row tail)");
+    return 0;
   }
   if (cfg >= 20 && cfg <= 22) {
     const int rc = launch_gemm_v6(p, cfg - 20, nbatch, s);

@@ -13,6 +13,7 @@ struct VitQkvEpi {
   const float *qn_w, *qn_b, *kn_w, *kn_b;  // [64] each (use_norm)
   const bf16_t *cos, *sin;                 // [maxpos + 1, 32] (use_rope)
   int N, NH, P, patch_start, Wp, use_norm, use_rope;
+  int m_off;       // token index of this launch's row 0 (the row-tail launch of gemm.hip: launch_split_rows starts past 0)
   float eps;
 };
 
@@ -452,7 +453,7 @@ __device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* s
     for (int u = 0; u < EPI_U; ++u) {
       const int row = row0 + u * rpp, m = m0 + row;
       ok[u] = row < BM && m < p.M;
-      divmod_f(ok[u] ? m : p.M - 1, e.N, invN, gi[u], ti[u]);
+      divmod_f((ok[u] ? m : p.M - 1) + e.m_off, e.N, invN, gi[u], ti[u]);
       if (rope) {
         int fr, tp = ti[u];
         if (e.P != e.N) divmod_f(ti[u], e.P, invP, fr, tp);
