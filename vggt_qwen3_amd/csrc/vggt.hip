@@ -400,20 +400,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
       }
     }
     FA_VISSUE(0, 0);
-    // ---- P^T = exp2(S^T), row sums
+    // ---- P^T = exp2(S^T) in four chunks of 16 keys, O^T += V^T . P^T chunk by chunk: the exponentials of chunk u + 1 sit between
+    // the MFMAs of chunk u (an MFMA holds the SIMD's issue port for 8 of its 32 cycles: the VALU work rides in the other 24), and
+    // the V^T fragments of step u + 1 are in flight while step u multiplies
+    float ps[QB];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      float ps = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s0[qb][i] = __builtin_amdgcn_exp2f(s0[qb][i]);
-        s1[qb][i] = __builtin_amdgcn_exp2f(s1[qb][i]);
-        ps += s0[qb][i] + s1[qb][i];
-      }
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps), __float_as_uint(ps), false, false);
-      l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    // ---- O^T += V^T . P^T, the V^T fragments of step u + 1 in flight while step u multiplies
+    for (int qb = 0; qb < QB; ++qb) ps[qb] = 0.f;
+#define FA_EXP(U)                                                                                                       \
+  do {                                                                                                                  \
+    _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                                 \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                   \
+        if ((U) < 2) { s0[qb][8 * ((U) & 1) + j] = __builtin_amdgcn_exp2f(s0[qb][8 * ((U) & 1) + j]); ps[qb] += s0[qb][8 * ((U) & 1) + j]; } \
+        else { s1[qb][8 * ((U) & 1) + j] = __builtin_amdgcn_exp2f(s1[qb][8 * ((U) & 1) + j]); ps[qb] += s1[qb][8 * ((U) & 1) + j]; }         \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  } while (0)
 #define FA_PV(U, BUFI)                                                                                                  \
   do {                                                                                                                  \
     const u32x4 ta = {va[BUFI][0][0], va[BUFI][0][1], va[BUFI][1][0], va[BUFI][1][1]};                                  \
@@ -426,17 +427,37 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
       o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1[qb], 0, 0, 0);            \
     }                                                                                                                   \
   } while (0)
+    // one MFMA, then a few of the next chunk's VALU instructions, ... (scheduler hint for the region up to the next wait)
+#define FA_MIX()                                                                                                        \
+  do {                                                                                                                  \
+    _Pragma("unroll") for (int g = 0; g < 2 * QB; ++g) {                                                                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                \
+      __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);                                                                \
+    }                                                                                                                   \
+  } while (0)
+    FA_EXP(0);
     FA_VISSUE(1, 1);
     FA_VWAIT(0, 4);
     FA_PV(0, 0);
+    FA_EXP(1);
+    FA_MIX();
     FA_VISSUE(2, 0);
     FA_VWAIT(1, 4);
     FA_PV(1, 1);
+    FA_EXP(2);
+    FA_MIX();
     FA_VISSUE(3, 1);
     FA_VWAIT(0, 4);
     FA_PV(2, 0);
+    FA_EXP(3);
+    FA_MIX();
     FA_VWAIT(1, 0);
     FA_PV(3, 1);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps[qb]), __float_as_uint(ps[qb]), false, false);
+      l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
     // ---- deferred rescale: only when some lane's scores outgrew the stale max by more than THR
     bool grow = false;
 #pragma unroll
