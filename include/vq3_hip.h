@@ -80,6 +80,26 @@ typedef struct vq3_vit_qkv_epilogue {
 } vq3_vit_qkv_epilogue;
 int vq3_gemm_vit_qkv(const vq3_gemm_desc* desc, const vq3_vit_qkv_epilogue* epi, void* stream);
 
+/* LayerNorm folded into the GEMMs either side of it (the pre-norm blocks of the published VGGT / DINOv2 towers, reached from
+ * vggt_qwen3_vlm.py:144: x -> LayerNorm -> Linear). With B = gamma o W, bias = b + W . beta and colsum[n] = sum_k B[n,k]
+ *   Linear(LayerNorm(x))[m,n] = rstd_m * ((x . B^T)[m,n] - mu_m * colsum[n]) + bias[n],
+ * so the consuming GEMM reads the RAW rows x (desc.A) and applies the row statistics in its epilogue: the normalised activation is
+ * never written or read. stats_in: f32 [M, parts_in, 2] = (sum, sum of squares) of x's row over parts_in column groups (K = the
+ * normalised width). stats_out: the producing GEMM (the residual add that forms x) leaves the same pairs for ITS output rows,
+ * f32 [M, N / 128, 2] over groups of 128 stored bf16 columns - every slot written by exactly one thread (no atomics, no zeroing,
+ * bit-identical from run to run). vq3_rowstats128 computes them for rows no GEMM produced. Needs the bf16 whole-row epilogue:
+ * bf16 C, one batch, 16-byte aligned rows. */
+typedef struct vq3_gemm_ln_fold {
+  const float* stats_in; /* or NULL */
+  int32_t parts_in;
+  float eps;
+  const float* colsum;   /* f32 [N], 16-byte aligned (with stats_in) */
+  float* stats_out;      /* or NULL; needs N % 128 == 0 */
+} vq3_gemm_ln_fold;
+int vq3_gemm_bf16_nt_ln(const vq3_gemm_desc* desc, const vq3_gemm_ln_fold* ln, void* stream);
+int vq3_gemm_vit_qkv_ln(const vq3_gemm_desc* desc, const vq3_vit_qkv_epilogue* epi, const vq3_gemm_ln_fold* ln, void* stream);
+int vq3_rowstats128(const void* x_bf16, float* stats, int64_t rows, int32_t cols, void* stream);
+
 /* The down_proj input-gradient GEMM with the SwiGLU backward in its epilogue (autograd of modeling_qwen3.py:81-83): desc computes
  * d(act) [M, N] = dY . W (any operand layout, no other epilogue, C ignored); instead of being written it is combined with the saved
  * pre-activations gu bf16 [M, 2N] = gate | up into dgu bf16 [M, 2N] = d(gate) | d(up), d(gate) = d(act) * up * silu'(gate),

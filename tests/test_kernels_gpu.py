@@ -154,6 +154,47 @@ def test_gemm_whole_rounds_plus_row_tail(ops):
         ops.gemm_force_config(-3)
 
 
+@pytest.mark.parametrize("cfg", [-3, 20, 21, 22, 11, 13, 7, 30])
+def test_gemm_layernorm_fold(ops, cfg):
+    """LayerNorm folded into the GEMMs either side of it (vq3_gemm_bf16_nt_ln): the producer (residual GEMM) leaves per-row
+    (sum, sum of squares) over 128-column groups of what it stored, the consumer reads the RAW rows and applies
+    rstd (x.B^T - mu colsum) + bias in its epilogue. Against: torch LayerNorm (f32 statistics of the bf16 rows) -> bf16 -> GEMM. Every tile
+    configuration; M with a ragged last tile; GELU on the consumer; statistics also from vq3_rowstats128 and bit-identical twice."""
+    try:
+        ops.gemm_force_config(cfg)
+        M, C, N2 = (16500 if cfg == 30 else 1029), 1024, 512
+        eps = 1e-5
+        h = _rand((M, 256), 0.5, seed=1); Wp = _rand((C, 256), 0.3, seed=2)
+        R = _rand((M, C), 1.0, seed=3) + 0.7                      # non-zero row means
+        gamma = (torch.rand(C, device="cuda") + 0.5); beta = torch.randn(C, device="cuda") * 0.2
+        W = _rand((N2, C), 0.05, seed=4).float(); b = torch.randn(N2, device="cuda") * 0.1
+        # producer: x = R + h.Wp^T, statistics on the way out
+        st = torch.full((M, C // 128, 2), float("nan"), device="cuda", dtype=F32)
+        x = ops.linear(h, Wp, residual=R, ln_fold=ops.ln_fold(stats_out=st))
+        xf = x.float()
+        assert torch.equal(x, ops.linear(h, Wp, residual=R))      # the statistics do not change the product
+        assert torch.allclose(st[:, :, 0], xf.view(M, C // 128, 128).sum(-1), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(st[:, :, 1], (xf * xf).view(M, C // 128, 128).sum(-1), rtol=1e-5, atol=1e-3)
+        st2 = ops.rowstats128(x)
+        assert torch.allclose(st2, st, rtol=1e-5, atol=1e-3)
+        st_again = torch.empty_like(st)
+        ops.linear(h, Wp, residual=R, ln_fold=ops.ln_fold(stats_out=st_again))
+        assert torch.equal(st, st_again)
+        # consumer
+        Bw = (W * gamma[None, :]).to(BF16)
+        colsum = Bw.float().sum(1).contiguous()
+        dvec = (b + W @ beta).contiguous()
+        y = ops.linear(x, Bw, bias=dvec, act=ops.ACT_GELU, ln_fold=ops.ln_fold(stats_in=st, eps=eps, colsum=colsum))
+        xn = torch.nn.functional.layer_norm(xf, (C,), gamma, beta, eps)
+        ref = torch.nn.functional.gelu((xn @ W.t() + b).to(BF16).float())
+        assert _relerr(y, ref) < 6e-3, (cfg, _relerr(y, ref))
+        # the unfused form on the same kernels (LayerNorm output rounded to bf16, as the reference does) agrees as closely
+        y0 = ops.linear(xn.to(BF16), W.to(BF16), bias=b, act=ops.ACT_GELU)
+        assert _relerr(y, y0) < 8e-3
+    finally:
+        ops.gemm_force_config(-3)
+
+
 @pytest.mark.parametrize("sched", [102, 103, 105])
 def test_gemm_kmajor_layouts_all_schedules(ops, sched):
     """The any-layout kernel (gemm3.hip) in each of its schedules - 128x128 two-stage, 128x128 loader ring, 256x128 loader ring -

@@ -58,9 +58,26 @@ def main():
         ("qkv fused norm+rope", 2.0 * M * 3 * C * C, lambda i: ops.linear_vit_qkv(x, wq[i % nw], b3, N, NH, qn=qn, kn=qn, cos=cos, sin=sin,
                                                                                    tokens_per_frame=N, patch_start=5, Wp=32)),
     ]
+    st = ops.rowstats128(x)
+    st_o = torch.empty((M, C // 128, 2), device="cuda", dtype=torch.float32)
+    c4 = torch.randn(4 * C, device="cuda"); c3 = torch.randn(3 * C, device="cuda")
+    lnf = ops.layernorm_fwd
+    g1, be1 = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    rows += [
+        ("layernorm alone", 0.0, lambda i: lnf(x, g1, be1, 1e-5)),
+        ("fc1 +bias+gelu +ln_in", 2.0 * M * 4 * C * C, lambda i: ops.linear(x, w1[i % nw], bias=b4, act=1, out=o4,
+                                                                          ln_fold=ops.ln_fold(stats_in=st, eps=1e-5, colsum=c4))),
+        ("fc2 +bias+ls+res +st_out", 2.0 * M * 4 * C * C, lambda i: ops.linear(h, w2[i % nw], bias=b1, colscale=ls, residual=res, out=o1,
+                                                                             ln_fold=ops.ln_fold(stats_out=st_o))),
+        ("proj +bias+ls+res +st_out", 2.0 * M * C * C, lambda i: ops.linear(x, wp[i % nw], bias=b1, colscale=ls, residual=res, out=o1,
+                                                                          ln_fold=ops.ln_fold(stats_out=st_o))),
+        ("qkv fused norm+rope +ln_in", 2.0 * M * 3 * C * C, lambda i: ops.linear_vit_qkv(x, wq[i % nw], b3, N, NH, qn=qn, kn=qn, cos=cos, sin=sin,
+                                                                                          tokens_per_frame=N, patch_start=5, Wp=32,
+                                                                                          ln_fold=ops.ln_fold(stats_in=st, eps=1e-5, colsum=c3))),
+    ]
     for name, fl, fn in rows:
         t = timeit(fn)
-        print(f"{name:24s} {t:7.1f} us  {fl / t / 1e6:7.1f} TF/s", flush=True)
+        print(f"{name:28s} {t:7.1f} us  {fl / t / 1e6:7.1f} TF/s", flush=True)
     ops.gemm_force_config(-3)
 
 

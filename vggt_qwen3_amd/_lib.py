@@ -35,6 +35,10 @@ class VitQkvEpilogue(C.Structure):
                 ("Wp", i32), ("use_norm", i32), ("use_rope", i32), ("eps", f32)]
 
 
+class GemmLnFold(C.Structure):
+    _fields_ = [("stats_in", c_p), ("parts_in", i32), ("eps", f32), ("colsum", c_p), ("stats_out", c_p)]
+
+
 class ColsumJob(C.Structure):
     _fields_ = [("part", c_p), ("out_bf16", c_p), ("nrows", i32), ("cols", i32), ("accumulate", i32)]
 
@@ -52,6 +56,9 @@ SIGNATURES = {
     "vq3_gemm_bf16_nt": [C.POINTER(GemmDesc), c_p],
     "vq3_gemm_vit_qkv": [C.POINTER(GemmDesc), C.POINTER(VitQkvEpilogue), c_p],
     "vq3_gemm_swiglu_bwd": [C.POINTER(GemmDesc), c_p, c_p, c_p],
+    "vq3_gemm_bf16_nt_ln": [C.POINTER(GemmDesc), C.POINTER(GemmLnFold), c_p],
+    "vq3_gemm_vit_qkv_ln": [C.POINTER(GemmDesc), C.POINTER(VitQkvEpilogue), C.POINTER(GemmLnFold), c_p],
+    "vq3_rowstats128": [c_p, c_p, i64, i32, c_p],
     "vq3_rmsnorm_fwd": [c_p, c_p, c_p, c_p, i64, i32, i64, i64, f32, c_p],
     "vq3_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "vq3_colsum_f32_to_bf16": [c_p, i32, i32, c_p, i32, c_p],

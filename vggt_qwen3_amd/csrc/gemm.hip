@@ -261,6 +261,8 @@ int launch_split_rows(GemmParams p, int nbatch, hipStream_t s) {
   b.C = (char*)p.C + (size_t)m_main * p.ldc * esz;
   if (p.R) b.R = (const char*)p.R + (size_t)m_main * p.ldr * esz;
   if (p.epi == 1) { b.C = p.C; b.vit.m_off = m_main; }      // Q / K / V are addressed by token index, C is a placeholder
+  if (p.ln_in) b.ln_in = p.ln_in + (long)m_main * p.ln_parts * 2;
+  if (p.st_out) b.st_out = p.st_out + (long)m_main * (p.N >> 7) * 2;
   int rc = launch_gemm_v6(a, 0, nbatch, s);
   if (rc) return rc;
   const long t128 = (long)((b.M + 127) / 128) * ((b.N + 127) / 128);
@@ -324,7 +326,7 @@ int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int tr
 
 int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStream_t s, const std::vector<int>& cands, int fallback) {
   const int flags = (transA ? 1 : 0) | (transB ? 2 : 0) | (p.out_f32 ? 4 : 0) | (p.accumulate ? 8 : 0) | (p.R ? 16 : 0) |
-                    (p.bias ? 32 : 0) | (p.act << 6) | (p.colscale ? 256 : 0) | (p.epi << 9);
+                    (p.bias ? 32 : 0) | (p.act << 6) | (p.colscale ? 256 : 0) | (p.epi << 9) | (p.ln_in ? 4096 : 0) | (p.st_out ? 8192 : 0);
   const TuneKey key(p.M, p.N, p.K, nbatch, flags);
   std::lock_guard<std::mutex> lock(g_tune_mutex);
   auto it = g_tuned.find(key);
@@ -339,7 +341,7 @@ int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStr
 }  // namespace
 
 static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve, void* stream, const void* sw_gu = nullptr,
-                         void* sw_dgu = nullptr) {
+                         void* sw_dgu = nullptr, const vq3_gemm_ln_fold* ln = nullptr) {
   VQ3_CHECK_ARG(d != nullptr, "gemm: null descriptor");
   VQ3_CHECK_ARG(d->A && d->B && (d->C || ve || sw_dgu), "gemm: null operand pointer");
   VQ3_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -409,6 +411,23 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
 
   hipStream_t s = (hipStream_t)stream;
   const int nbatch = d->nb1 * d->nb2;
+  p.ln_in = nullptr; p.ln_c = nullptr; p.ln_parts = 0; p.ln_eps = 0.f; p.st_out = nullptr;
+  if (ln && (ln->stats_in || ln->stats_out)) {
+    // both halves live in the LDS-staged epilogue: the conditions of gemm_common.h: staged_ok must hold, or the kernels would
+    // silently take the register epilogue
+    VQ3_CHECK_ARG(!sw_dgu && !d->out_f32 && d->ksplit <= 1 && nbatch == 1 && p.vec_ok && p.ldc % 8 == 0 && ((uintptr_t)p.C % 16 == 0) &&
+                      (!d->R || (d->ldr % 8 == 0 && (uintptr_t)d->R % 16 == 0)) && g_forced_cfg != -1 && g_forced_cfg != 4 && g_forced_cfg != 5,
+                  "gemm ln fold: needs the staged bf16 epilogue (bf16 C, one batch, 16-byte aligned rows, tile width >= 128)");
+    if (ln->stats_in) {
+      VQ3_CHECK_ARG(ln->colsum && ln->parts_in > 0 && ln->parts_in <= 64 && ((uintptr_t)ln->stats_in % 8 == 0) && ((uintptr_t)ln->colsum % 16 == 0),
+                    "gemm ln fold: stats_in needs colsum [N] (16-byte aligned) and 1..64 (sum, sumsq) pairs per row");
+      p.ln_in = ln->stats_in; p.ln_c = ln->colsum; p.ln_parts = ln->parts_in; p.ln_eps = ln->eps;
+    }
+    if (ln->stats_out) {
+      VQ3_CHECK_ARG(!ve && d->N % 128 == 0 && ((uintptr_t)ln->stats_out % 8 == 0), "gemm ln fold: stats_out needs N %% 128 == 0 and a plain C epilogue");
+      p.st_out = ln->stats_out;
+    }
+  }
   if (d->ksplit > 1) {
     VQ3_CHECK_ARG(d->out_f32 && !d->bias && !d->colscale && !d->R && d->act == 0 && !d->accumulate,
                   "gemm: split-K needs a zero-initialised f32 C and no epilogue");
@@ -487,6 +506,15 @@ extern "C" int vq3_gemm_bf16_nt(const vq3_gemm_desc* d, void* stream) { return g
 extern "C" int vq3_gemm_vit_qkv(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* epi, void* stream) {
   VQ3_CHECK_ARG(epi != nullptr, "gemm_vit_qkv: null epilogue descriptor");
   return gemm_dispatch(d, epi, stream);
+}
+
+extern "C" int vq3_gemm_bf16_nt_ln(const vq3_gemm_desc* d, const vq3_gemm_ln_fold* ln, void* stream) {
+  return gemm_dispatch(d, nullptr, stream, nullptr, nullptr, ln);
+}
+
+extern "C" int vq3_gemm_vit_qkv_ln(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* epi, const vq3_gemm_ln_fold* ln, void* stream) {
+  VQ3_CHECK_ARG(epi != nullptr, "gemm_vit_qkv_ln: null epilogue descriptor");
+  return gemm_dispatch(d, epi, stream, nullptr, nullptr, ln);
 }
 
 extern "C" int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* d, const void* gu, void* dgu, void* stream) {

@@ -326,6 +326,18 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
       if (p.colscale) cs_v[j] = *reinterpret_cast<const f32x4*>(p.colscale + n);
     }
     __syncthreads();
+    if (p.ln_in) {      // folded LayerNorm: rstd (acc - mu c) per lane-owned row, before the usual epilogue
+      f32x4 cc[TN];
+      float mu[TM], rs[TM];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) cc[j] = ln_colsum(p, n0 + wn * (BN / WN) + j * 16 + 4 * fq);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ln_row(p, m0 + wm * (BM / WM) + i * 16 + fr, mu[i], rs[i]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = ln_apply(acc[i][j], mu[i], rs[i], cc[j]);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -278,6 +278,22 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
         if (p.bias) bias_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.colscale) cs_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.colscale + n);
       }
+    if (p.ln_in) {      // folded LayerNorm: rstd (acc - mu c) per lane-owned row, before the usual epilogue
+      f32x4 cc[BH * 2];
+      float mu[AH * 4], rs[AH * 4];
+#pragma unroll
+      for (int j = 0; j < BH; ++j)
+#pragma unroll
+        for (int nt2 = 0; nt2 < 2; ++nt2) cc[j * 2 + nt2] = ln_colsum(p, n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq);
+#pragma unroll
+      for (int i = 0; i < AH; ++i)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) ln_row(p, m0 + i * 128 + wr * 64 + mt * 16 + fr, mu[i * 4 + mt], rs[i * 4 + mt]);
+#pragma unroll
+      for (int r = 0; r < AH * 4; ++r)
+#pragma unroll
+        for (int q = 0; q < BH * 2; ++q) acc[r][q] = ln_apply(acc[r][q], mu[r], rs[r], cc[q]);
+    }
 #pragma unroll
     for (int i = 0; i < AH; ++i)
 #pragma unroll

@@ -40,7 +40,48 @@ struct GemmParams {
   VitQkvEpi vit;
   const bf16_t* sw_gu;   // epi == 2: saved gate|up pre-activations [M, 2N]
   bf16_t* sw_dgu;        //           d(gate|up) [M, 2N]; the GEMM result d(act) [M, N] is never written
+  // LayerNorm folded into the GEMM that consumes it (staged epilogue only): A holds the raw rows x, B = gamma o W, bias = b + W.beta,
+  // ln_c[n] = sum_k B[n,k]; the row statistics arrive as ln_parts (sum, sum of squares) pairs per row. y = rstd (acc - mu c) + bias.
+  const float* ln_in;    // [M, ln_parts, 2] or null
+  const float* ln_c;     // [N]
+  int ln_parts;
+  float ln_eps;
+  // ... and produced for the NEXT LayerNorm by the GEMM that writes its input: per row and 128 output columns the (sum, sum of squares)
+  // of the stored bf16 values, st_out [M, N / 128, 2] (N % 128 == 0, every slot written by exactly one thread: no atomics, no zeroing)
+  float* st_out;
 };
+
+// row statistics of the folded LayerNorm (contraction length K is the normalised width)
+__device__ __forceinline__ void ln_row(const GemmParams& p, int m, float& mu, float& rs) {
+  m = m < p.M ? m : p.M - 1;
+  const float* st = p.ln_in + (long)m * p.ln_parts * 2;
+  float sm = 0.f, sq = 0.f;
+  if (p.ln_parts == 8) {                        // width 1024: four 16-byte loads in flight together, summed in slot order
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(st + 4 * i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sm += v[i][0]; sq += v[i][1]; sm += v[i][2]; sq += v[i][3]; }
+  } else {
+    for (int i = 0; i < p.ln_parts; ++i) {      // fixed order: bit-identical from run to run
+      const float2 v = *reinterpret_cast<const float2*>(st + 2 * i);
+      sm += v.x; sq += v.y;
+    }
+  }
+  const float inv = 1.f / (float)p.K;
+  mu = sm * inv;
+  rs = rsqrtf(fmaxf(sq * inv - mu * mu, 0.f) + p.ln_eps);
+}
+__device__ __forceinline__ f32x4 ln_colsum(const GemmParams& p, int n) {
+  n = n + 3 < p.N ? n : (p.N >= 4 ? p.N - 4 : 0);     // columns past N are never stored
+  return *reinterpret_cast<const f32x4*>(p.ln_c + n);
+}
+__device__ __forceinline__ f32x4 ln_apply(const f32x4& a, float mu, float rs, const f32x4& c) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = rs * (a[r] - mu * c[r]);
+  return o;
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return gelu_erf(v);
@@ -240,6 +281,21 @@ __device__ __forceinline__ void store_quad_pre(const GemmParams& p, long coff, i
 // LDS image of the C tile - rows of BN bf16, 16-byte chunks XOR (row & 15): conflict-free for the 8-byte quad writes
 // (16 lanes = 16 rows, one column group) and for the 16-byte row reads - and leave as whole rows: 16 B per lane,
 // BN * 2 contiguous bytes per row, with the residual / accumulate operand read the same coalesced way.
+// lane exchange inside groups of 8 lanes on the DPP path of the VALU (no LDS-permute traffic next to the staged tile's reads)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum8(float v) {          // all-reduce over the 8 lanes l & ~7 .. l | 7
+  v += dpp_mov<0xB1>(v);                                  // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_mov<0x4E>(v);                                  // quad_perm [2,3,0,1]: lane ^ 2
+  return v + dpp_mov<0x141>(v);                           // row_half_mirror: lane i <-> 7 - i, i.e. the other quad's sum
+}
+__device__ __forceinline__ float sum16(float v) {         // all-reduce over the 16 lanes of a DPP row
+  v = sum8(v);
+  return v + dpp_mov<0x140>(v);                           // row_mirror: lane i <-> 15 - i, i.e. the other half-row's sum
+}
+
 constexpr int EPI_U = 8;     // rows per thread whose global operands are in flight together in the staged epilogues
 template <int BN>
 __device__ __forceinline__ int cstage_off(int row, int chunk) {
@@ -382,6 +438,19 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = pack2bf(v[2 * k], v[2 * k + 1]);
         *reinterpret_cast<u32x4*>(C + (long)m * p.ldc + n) = o;
+        if (p.st_out) {
+          // (sum, sum of squares) of the 128 stored values around this thread's 8: the 16 lanes of a 16-lane row hold them
+          float sm = 0.f, sq = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float lo = bf2f((bf16_t)(o[k] & 0xffff)), hi = bf2f((bf16_t)(o[k] >> 16));
+            sm += lo + hi;
+            sq = fmaf(lo, lo, fmaf(hi, hi, sq));
+          }
+          sm = sum16(sm); sq = sum16(sq);
+          if ((c & 15) == 0)
+            *reinterpret_cast<float2*>(p.st_out + ((long)m * (p.N >> 7) + (n >> 7)) * 2) = float2{sm, sq};
+        }
       }
     }
     return;
@@ -404,16 +473,6 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
 // head; the head's 64 features are the 8 consecutive lanes around it (CPR is a multiple of 8 and tiles start at multiples of
 // 64 columns), so the LayerNorm sums are three xor-shuffles and the rotate-half partner (feature e ^ 16) is lane ^ 2.
 // Arithmetic and rounding points are those of vit_qkprep4_kernel (vggt.hip).
-// lane exchange inside groups of 8 lanes on the DPP path of the VALU (no LDS-permute traffic next to the staged tile's reads)
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float sum8(float v) {          // all-reduce over the 8 lanes l & ~7 .. l | 7
-  v += dpp_mov<0xB1>(v);                                  // quad_perm [1,0,3,2]: lane ^ 1
-  v += dpp_mov<0x4E>(v);                                  // quad_perm [2,3,0,1]: lane ^ 2
-  return v + dpp_mov<0x141>(v);                           // row_half_mirror: lane i <-> 7 - i, i.e. the other quad's sum
-}
 // x = q * d + r for 0 <= x < 2^22 and a small divisor, through the float reciprocal with one correction step either way
 __device__ __forceinline__ void divmod_f(int x, int d, float inv, int& q, int& r) {
   q = (int)((float)x * inv);

@@ -335,6 +335,40 @@ extern "C" int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   return 0;
 }
 
+namespace {
+// (sum, sum of squares) per row and 128-column group of a bf16 matrix: the input of a LayerNorm folded into the GEMM that consumes it
+// (gemm_common.h: ln_row), for rows that no GEMM epilogue has produced statistics for. One thread per 8 columns, 16 lanes per group.
+__global__ __launch_bounds__(256) void rowstats128_kernel(const bf16_t* __restrict__ x, float* __restrict__ st, long rows, int cols) {
+  const int tpr = cols >> 3;                                   // threads per row (multiple of 16)
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = gid / tpr;
+  const int c = (int)(gid - row * tpr);
+  float sm = 0.f, sq = 0.f;
+  if (row < rows) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + row * cols + c * 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float lo = bf2f((bf16_t)(v[k] & 0xffff)), hi = bf2f((bf16_t)(v[k] >> 16));
+      sm += lo + hi;
+      sq = fmaf(lo, lo, fmaf(hi, hi, sq));
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }
+  if (row < rows && (c & 15) == 0) *reinterpret_cast<float2*>(st + (row * (cols >> 7) + (c >> 4)) * 2) = float2{sm, sq};
+}
+}  // namespace
+
+extern "C" int vq3_rowstats128(const void* x, float* stats, int64_t rows, int32_t cols, void* stream) {
+  VQ3_CHECK_ARG(x && stats && rows > 0 && cols > 0 && cols % 128 == 0, "rowstats128: bad arguments (cols must be a multiple of 128)");
+  VQ3_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)stats % 8 == 0, "rowstats128: x must be 16-byte aligned");
+  const long threads = rows * (cols / 8);
+  hipLaunchKernelGGL(rowstats128_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, stats,
+                     (long)rows, cols);
+  VQ3_CHECK_LAUNCH("rowstats128");
+  return 0;
+}
+
 extern "C" int vq3_layernorm_fwd(const void* x, const void* res, int32_t x_f32, const float* w, const float* b,
                                  void* y_bf16, float* y_f32, int64_t rows, int32_t cols, float eps, void* stream) {
   VQ3_CHECK_ARG(x && w && b && (y_bf16 || y_f32), "layernorm_fwd: null pointer");

@@ -53,9 +53,9 @@ def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, 
              *, bias=None, colscale=None, R=None, ldr: int = 0, nb1: int = 1, nb2: int = 1, b2divB: int = 1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), act: int = 0, accumulate: bool = False, alpha: float = 1.0,
              a_off: int = 0, b_off: int = 0, c_off: int = 0, r_off: int = 0, transA: bool = False,
-             transB: bool = False, ksplit: int = 1) -> None:
+             transB: bool = False, ksplit: int = 1, ln_fold=None) -> None:
     """Raw descriptor launch. A/B bf16; C bf16 or f32 (decides out_f32). Offsets are in elements.
-    transA / transB: the operand is stored k-major ([K, ld]) instead of [M or N, ld]."""
+    transA / transB: the operand is stored k-major ([K, ld]) instead of [M or N, ld]. ln_fold: a GemmLnFold (see ln_fold())."""
     _req(A, BF16, "gemm A"); _req(B, BF16, "gemm B")
     if C.dtype not in (BF16, F32):
         raise _lib.Vq3Error(f"gemm C: dtype must be bf16 or f32, got {C.dtype}")
@@ -75,21 +75,52 @@ def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, 
     d.act = act; d.out_f32 = 1 if C.dtype == F32 else 0; d.accumulate = 1 if accumulate else 0
     d.alpha = alpha
     d.transA = 1 if transA else 0; d.transB = 1 if transB else 0; d.ksplit = ksplit
+    lib = _lib.load()
+    launch = (lambda: check(lib.vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")) if ln_fold is None else \
+             (lambda: check(lib.vq3_gemm_bf16_nt_ln(d, ln_fold, _stream()), "vq3_gemm_bf16_nt_ln"))
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_lib.load().vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")
+        launch()
         e1.record()
         GEMM_PROFILE.append((2.0 * M * N * K * nb1 * nb2,
                              float(nb1 * nb2) * (2.0 * M * K + 2.0 * N * K / b2divB + C.element_size() * M * N *
                                                  (1 + (R is not None) + bool(accumulate))), e0, e1, (M, N, K, nb1 * nb2)))
         return
-    check(_lib.load().vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")
+    launch()
+
+
+def ln_fold(stats_in: Optional[torch.Tensor] = None, eps: float = 0.0, colsum: Optional[torch.Tensor] = None,
+            stats_out: Optional[torch.Tensor] = None):
+    """Descriptor of a LayerNorm folded into the GEMMs either side of it (include/vq3_hip.h: vq3_gemm_ln_fold). stats_in f32
+    [M, parts, 2] = (sum, sum of squares) of the rows of the RAW activation the GEMM reads as A, colsum f32 [N] = row sums of the
+    gamma-scaled weight; stats_out f32 [M, N / 128, 2]: the GEMM leaves the same pairs for its own output rows. The tensors must
+    outlive the launch (the caller keeps them)."""
+    f = _lib.GemmLnFold()
+    if stats_in is not None:
+        _req(stats_in, F32, "ln_fold stats_in"); _req(colsum, F32, "ln_fold colsum")
+        assert stats_in.is_contiguous() and stats_in.dim() == 3 and stats_in.shape[2] == 2 and colsum.is_contiguous()
+        f.stats_in, f.parts_in, f.eps, f.colsum = stats_in.data_ptr(), stats_in.shape[1], eps, colsum.data_ptr()
+    if stats_out is not None:
+        _req(stats_out, F32, "ln_fold stats_out"); assert stats_out.is_contiguous()
+        f.stats_out = stats_out.data_ptr()
+    return f
+
+
+def rowstats128(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(sum, sum of squares) per row and 128-column group of a bf16 matrix -> f32 [rows, cols / 128, 2] (vq3_rowstats128)."""
+    _req(x, BF16, "rowstats128 x"); assert x.dim() == 2 and x.is_contiguous() and x.shape[1] % 128 == 0
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols // 128, 2), device=x.device, dtype=F32)
+    assert out.shape == (rows, cols // 128, 2) and out.dtype == F32 and out.is_contiguous()
+    check(_lib.load().vq3_rowstats128(x.data_ptr(), out.data_ptr(), rows, cols, _stream()), "vq3_rowstats128")
+    return out
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, *, bias=None, colscale=None, residual=None, act: int = 0,
            out: Optional[torch.Tensor] = None, out_dtype=BF16, accumulate: bool = False,
-           alpha: float = 1.0) -> torch.Tensor:
+           alpha: float = 1.0, ln_fold=None) -> torch.Tensor:
     """out[M,N] = epilogue(x[M,K] @ w[N,K]^T). x, w: 2-D bf16 with unit inner stride."""
     assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
     M, K = x.shape
@@ -104,7 +135,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, *, bias=None, colscale=None, residu
         assert residual.shape == (M, N) and residual.stride(1) == 1
         ldr = residual.stride(0)
     gemm_raw(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, colscale=colscale, R=residual,
-             ldr=ldr, act=act, accumulate=accumulate, alpha=alpha)
+             ldr=ldr, act=act, accumulate=accumulate, alpha=alpha, ln_fold=ln_fold)
     return out
 
 
@@ -433,7 +464,7 @@ def gemm_swiglu_bwd(dY: torch.Tensor, W: torch.Tensor, gu: torch.Tensor, transB:
 
 
 def linear_vit_qkv(x: torch.Tensor, w: torch.Tensor, bias, N: int, NH: int, *, qn=None, kn=None, cos=None, sin=None,
-                   tokens_per_frame=0, patch_start=0, Wp=0, eps=1e-5):
+                   tokens_per_frame=0, patch_start=0, Wp=0, eps=1e-5, ln_fold=None):
     """vit_qkprep(linear(x, w, bias)) in ONE launch: x bf16 [T, C] @ w[3*NH*64, C]^T (+ bias) -> Q, K, V bf16 [T/N, NH, N, 64]
     with the per-head LayerNorm / 2-D RoPE applied in the GEMM epilogue (vq3_gemm_vit_qkv); qkv is never materialised."""
     _req(x, BF16, "vit_qkv x"); _req(w, BF16, "vit_qkv w")
@@ -458,14 +489,17 @@ def linear_vit_qkv(x: torch.Tensor, w: torch.Tensor, bias, N: int, NH: int, *, q
         e.cos, e.sin = cos.data_ptr(), sin.data_ptr()
     e.N, e.NH, e.tokens_per_frame, e.patch_start, e.Wp = N, NH, tokens_per_frame, patch_start, Wp
     e.use_norm, e.use_rope, e.eps = int(use_norm), int(use_rope), eps
+    lib = _lib.load()
+    launch = (lambda: check(lib.vq3_gemm_vit_qkv(d, e, _stream()), "vq3_gemm_vit_qkv")) if ln_fold is None else \
+             (lambda: check(lib.vq3_gemm_vit_qkv_ln(d, e, ln_fold, _stream()), "vq3_gemm_vit_qkv_ln"))
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_lib.load().vq3_gemm_vit_qkv(d, e, _stream()), "vq3_gemm_vit_qkv")
+        launch()
         e1.record()
         GEMM_PROFILE.append((2.0 * T * d.N * K, 2.0 * T * K + 2.0 * d.N * K + 2.0 * T * d.N, e0, e1, (T, d.N, K, 1)))
     else:
-        check(_lib.load().vq3_gemm_vit_qkv(d, e, _stream()), "vq3_gemm_vit_qkv")
+        launch()
     return Q, Kt, V
 
 

@@ -19,6 +19,7 @@ path is checked against this repo's own CPU restatement (oracle/vggt.py) only. F
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -49,6 +50,8 @@ class Aggregator(nn.Module):
         if embed_dim % 64 or embed_dim // num_heads != 64:
             raise ops._lib.Vq3Error("VGGT HIP path requires head_dim == 64")
         self.img_size, self.patch_size, self.embed_dim = img_size, patch_size, embed_dim
+        # the blocks' two pre-LayerNorms folded into the q|k|v and fc1 GEMMs (needs 128-column statistic groups; VQ3_VGGT_LN_FOLD=0: off)
+        self._ln_fold = embed_dim % 128 == 0 and os.environ.get("VQ3_VGGT_LN_FOLD", "1") != "0"
         self.depth, self.num_heads = depth, num_heads
         self.dino_depth = depth if dino_depth is None else dino_depth
         self.mlp_dim = int(embed_dim * mlp_ratio)
@@ -157,6 +160,16 @@ class Aggregator(nn.Module):
             if qk:
                 d["qn"] = (f(prefix + "attn.q_norm.weight"), f(prefix + "attn.q_norm.bias"))
                 d["kn"] = (f(prefix + "attn.k_norm.weight"), f(prefix + "attn.k_norm.bias"))
+            if self._ln_fold:
+                # Linear(LayerNorm(x)) = rstd (x . (gamma o W)^T - mu colsum) + (b + W . beta): the frozen tower's two pre-norms are
+                # folded into the weights once (ops.ln_fold); colsum is taken from the bf16-rounded product the GEMM will read
+                for lin, nrm in (("qkv", "n1"), ("fc1", "n2")):
+                    name = prefix + ("attn.qkv." if lin == "qkv" else "mlp.fc1.")
+                    W = self.p(name + "weight").detach().float()
+                    wf = (W * d[nrm][0][None, :]).to(BF16).contiguous()
+                    d[lin + "_wf"] = wf
+                    d[lin + "_c"] = wf.float().sum(1).contiguous()
+                    d[lin + "_d"] = (f(name + "bias") + W @ d[nrm][1]).contiguous()
             return d
         cc["dino"] = [blk(f"patch_embed.blocks.{i}.", False) for i in range(self.dino_depth)]
         cc["frame"] = [blk(f"frame_blocks.{i}.", True) for i in range(self.depth)]
@@ -202,8 +215,29 @@ class Aggregator(nn.Module):
         return self._rope_cache[maxpos]
 
     # ------------------------------------------------------------------ one transformer block
-    def _block(self, x, w, N, *, rope, eps, P, Wp):
+    def _block(self, x, w, N, *, rope, eps, P, Wp, st=None):
+        """One pre-norm block. Returns (x_out, statistics of x_out's rows for the next block's first LayerNorm, or None)."""
         NH = self.num_heads
+        if self._ln_fold:
+            # no LayerNorm launch, no normalised copy of x: the q|k|v and fc1 GEMMs read the raw rows and apply (mu, rstd) in their
+            # epilogues; the residual GEMMs that form x leave the (sum, sum of squares) pairs the next fold needs
+            T, C = x.shape
+            if st is None:
+                st = ops.rowstats128(x)
+            kw = dict(ln_fold=ops.ln_fold(stats_in=st, eps=eps, colsum=w["qkv_c"]))
+            if rope is not None:
+                Q, K, V = ops.linear_vit_qkv(x, w["qkv_wf"], w["qkv_d"], N, NH, qn=w["qn"], kn=w["kn"], cos=rope[0], sin=rope[1],
+                                             tokens_per_frame=P, patch_start=self.patch_start_idx, Wp=Wp, eps=1e-5, **kw)
+            else:
+                Q, K, V = ops.linear_vit_qkv(x, w["qkv_wf"], w["qkv_d"], N, NH, **kw)
+            o = ops.flash_attn(Q, K, V)
+            st2 = torch.empty((T, C // 128, 2), device=x.device, dtype=torch.float32)
+            x = ops.linear(o, w["proj_w"], bias=w["proj_b"], colscale=w["ls1"], residual=x, ln_fold=ops.ln_fold(stats_out=st2))
+            h = ops.linear(x, w["fc1_wf"], bias=w["fc1_d"], act=ops.ACT_GELU,
+                           ln_fold=ops.ln_fold(stats_in=st2, eps=eps, colsum=w["fc1_c"]))
+            st3 = torch.empty_like(st2)
+            x = ops.linear(h, w["fc2_w"], bias=w["fc2_b"], colscale=w["ls2"], residual=x, ln_fold=ops.ln_fold(stats_out=st3))
+            return x, st3
         xn, _ = ops.layernorm_fwd(x, w["n1"][0], w["n1"][1], eps)
         # qkv projection with the head split, q/k LayerNorm and 2-D RoPE fused into the GEMM epilogue (one launch, no [T, 3C] tensor)
         if rope is not None:
@@ -215,7 +249,7 @@ class Aggregator(nn.Module):
         x = ops.linear(o, w["proj_w"], bias=w["proj_b"], colscale=w["ls1"], residual=x)
         xn2, _ = ops.layernorm_fwd(x, w["n2"][0], w["n2"][1], eps)
         h = ops.linear(xn2, w["fc1_w"], bias=w["fc1_b"], act=ops.ACT_GELU)
-        return ops.linear(h, w["fc2_w"], bias=w["fc2_b"], colscale=w["ls2"], residual=x)
+        return ops.linear(h, w["fc2_w"], bias=w["fc2_b"], colscale=w["ls2"], residual=x), None
 
     def _dino(self, cc, images: torch.Tensor):
         """ImageNet normalisation + DINOv2-with-registers backbone (`patch_embed`): images [B, S, 3, H, W] in [0,1] ->
@@ -237,8 +271,9 @@ class Aggregator(nn.Module):
                      ldr=C, nb1=BS, sA=(Np * self.kp, 0), sC=(P * C, 0), c_off=self.patch_start_idx * C)
         tok[:, : self.patch_start_idx] = special  # row copy (data movement)
         x = tok.view(BS * P, C)
+        st = None
         for w in cc["dino"]:
-            x = self._block(x, w, P, rope=None, eps=1e-6, P=P, Wp=Wp)
+            x, st = self._block(x, w, P, rope=None, eps=1e-6, P=P, Wp=Wp, st=st)
         x, _ = ops.layernorm_fwd(x, cc["dino_norm"][0], cc["dino_norm"][1], 1e-6)
         return x
 
@@ -270,10 +305,11 @@ class Aggregator(nn.Module):
         xv[:, :, : self.patch_start_idx] = sp[sel][None]
         rope = self._rope_tables(max(Hp, Wp))
         outs = []
+        st = None                                          # (the special-token rows were just rewritten: fresh statistics)
         for i in range(self.depth):
-            x = self._block(x, cc["frame"][i], P, rope=rope, eps=1e-5, P=P, Wp=Wp)
+            x, st = self._block(x, cc["frame"][i], P, rope=rope, eps=1e-5, P=P, Wp=Wp, st=st)
             fr = x
-            x = self._block(x, cc["global"][i], S * P, rope=rope, eps=1e-5, P=P, Wp=Wp)
+            x, st = self._block(x, cc["global"][i], S * P, rope=rope, eps=1e-5, P=P, Wp=Wp, st=st)
             if return_all or i == self.depth - 1:
                 outs.append(torch.cat([fr.view(B, S, P, C), x.view(B, S, P, C)], dim=-1))
         return outs, self.patch_start_idx
