@@ -25,10 +25,11 @@ def timeit(fn, n=20, rounds=5):
 
 def main():
     cfg = int(sys.argv[1]) if len(sys.argv) > 1 else -3
+    Mrows = int(sys.argv[2]) if len(sys.argv) > 2 else 6174
     ops.gemm_force_config(cfg)
     torch.manual_seed(0)
-    M, C = 6174, 1024
-    nw = 40
+    M, C = Mrows, 1024
+    nw = 40 if M < 10000 else 12
     x = torch.randn(M, C, device="cuda").to(torch.bfloat16)
     h = torch.randn(M, 4 * C, device="cuda").to(torch.bfloat16)
     res = torch.randn(M, C, device="cuda").to(torch.bfloat16)
@@ -42,7 +43,7 @@ def main():
     o3 = torch.empty(M, 3 * C, device="cuda", dtype=torch.bfloat16)
     o1 = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
     qn = (torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"))
-    N, NH = 1029, 16
+    N, NH = (1029 if M % 1029 == 0 else M), 16
     cos = torch.randn(33, 32, device="cuda").to(torch.bfloat16); sin = torch.randn(33, 32, device="cuda").to(torch.bfloat16)
     rows = [
         ("fc1 plain", 2.0 * M * 4 * C * C, lambda i: ops.linear(x, w1[i % nw], out=o4)),

@@ -66,6 +66,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
   const int wm = (wid % NW) / WN, wn = wid % WN;
   int m0, n0;
   tile_coords(p, BM, BN, m0, n0);
+  // folded LayerNorm: thread r < BM fetches row r's statistics now (two registers through the main loop) - at the epilogue the
+  // round trip to L2 / HBM would be exposed on every tile
+  static_assert(BM <= 64 * WM * WN, "one statistics thread per tile row");
+  float ln_mu = 0.f, ln_rs = 0.f;
+  if (p.ln_in && tid < BM) ln_row(p, m0 + tid, ln_mu, ln_rs);
   const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
   const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
   const bf16_t* B = p.B + b1 * p.sB1 + (long)(b2 / p.b2divB) * p.sB2;
@@ -331,8 +336,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
       float mu[TM], rs[TM];
 #pragma unroll
       for (int j = 0; j < TN; ++j) cc[j] = ln_colsum(p, n0 + wn * (BN / WN) + j * 16 + 4 * fq);
+      if (tid < BM) reinterpret_cast<float2*>(smem)[tid] = float2{ln_mu, ln_rs};   // (barrier above: the last stage's reads are done)
+      __syncthreads();
 #pragma unroll
-      for (int i = 0; i < TM; ++i) ln_row(p, m0 + wm * (BM / WM) + i * 16 + fr, mu[i], rs[i]);
+      for (int i = 0; i < TM; ++i) {
+        const float2 v = reinterpret_cast<const float2*>(smem)[wm * (BM / WM) + i * 16 + fr];
+        mu[i] = v.x; rs[i] = v.y;
+      }
+      __syncthreads();                                       // before the C image overwrites the pairs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -268,6 +268,32 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   // ---- epilogue
   if (!OUT_F32 && staged_ok(p, coff, roff)) {
     // through LDS (the operand buffers are dead: every wave passed the last phase's barrier), out as whole rows
+    if (p.ln_in) {      // folded LayerNorm: rstd (acc - mu c) per lane-owned row, before the usual epilogue
+      // Register-frugal on purpose (this kernel sits at 256 VGPRs): the statistics are fetched here, one thread per tile row, not at
+      // the kernel's start, and a row's (mu, rstd) pair is applied as it is read back - only the four colsum quads stay live.
+      __syncthreads();                                       // operand buffers are dead for every wave
+      if (tid < BM) {
+        float mu_t, rs_t;
+        ln_row(p, m0 + tid, mu_t, rs_t);
+        reinterpret_cast<float2*>(smem)[tid] = float2{mu_t, rs_t};
+      }
+      f32x4 cc[BH * 2];
+#pragma unroll
+      for (int j = 0; j < BH; ++j)
+#pragma unroll
+        for (int nt2 = 0; nt2 < 2; ++nt2) cc[j * 2 + nt2] = ln_colsum(p, n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < AH; ++i)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const float2 v = reinterpret_cast<const float2*>(smem)[i * 128 + wr * 64 + mt * 16 + fr];
+#pragma unroll
+          for (int q = 0; q < BH * 2; ++q) acc[i * 4 + mt][q] = ln_apply(acc[i * 4 + mt][q], v.x, v.y, cc[q]);
+        }
+      __syncthreads();                                       // before the C image overwrites the pairs
+      __builtin_amdgcn_sched_barrier(0);                     // (keeps the bias / LayerScale loads below from being hoisted into this block)
+    }
     f32x4 bias_r[BH][2], cs_r[BH][2];
 #pragma unroll
     for (int j = 0; j < BH; ++j)
@@ -278,22 +304,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
         if (p.bias) bias_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.colscale) cs_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.colscale + n);
       }
-    if (p.ln_in) {      // folded LayerNorm: rstd (acc - mu c) per lane-owned row, before the usual epilogue
-      f32x4 cc[BH * 2];
-      float mu[AH * 4], rs[AH * 4];
-#pragma unroll
-      for (int j = 0; j < BH; ++j)
-#pragma unroll
-        for (int nt2 = 0; nt2 < 2; ++nt2) cc[j * 2 + nt2] = ln_colsum(p, n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq);
-#pragma unroll
-      for (int i = 0; i < AH; ++i)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) ln_row(p, m0 + i * 128 + wr * 64 + mt * 16 + fr, mu[i * 4 + mt], rs[i * 4 + mt]);
-#pragma unroll
-      for (int r = 0; r < AH * 4; ++r)
-#pragma unroll
-        for (int q = 0; q < BH * 2; ++q) acc[r][q] = ln_apply(acc[r][q], mu[r], rs[r], cc[q]);
-    }
 #pragma unroll
     for (int i = 0; i < AH; ++i)
 #pragma unroll

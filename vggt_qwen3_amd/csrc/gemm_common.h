@@ -72,6 +72,9 @@ __device__ __forceinline__ void ln_row(const GemmParams& p, int m, float& mu, fl
   mu = sm * inv;
   rs = rsqrtf(fmaxf(sq * inv - mu * mu, 0.f) + p.ln_eps);
 }
+// The kernels fetch the statistics one thread per tile row at their start (two registers through the main loop), pass the (mu, rstd)
+// pairs through LDS at the epilogue and every lane reads its own rows' pair from there. Loaded per lane instead, the 16 lanes that
+// share a row would each request its 64 bytes - 256 KB of load traffic per 256-row tile through the texture path (+3.7 us per tile).
 __device__ __forceinline__ f32x4 ln_colsum(const GemmParams& p, int n) {
   n = n + 3 < p.N ? n : (p.N >= 4 ? p.N - 4 : 0);     // columns past N are never stored
   return *reinterpret_cast<const f32x4*>(p.ln_c + n);
