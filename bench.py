@@ -223,16 +223,19 @@ def main():
     nwarm = (max(args.warmup, 1) + accum - 1) // accum * accum
     trainer.grad_accum = accum
     nxt = batch if args.vision_prefetch else None   # next micro-batch's (frozen) vision forward overlaps this one
-    for _ in range(nwarm):
-        loss = trainer.micro_step(batch, nxt)
+    vg = max(1, trainer.vision_group)
+    up = [batch] * (vg - 1)     # the following micro-batches (the same synthetic batch): one vision-tower pass per vg micro-batches
+    for i in range(nwarm):
+        loss = trainer.micro_step(batch, nxt, upcoming=up[: nwarm - 1 - i])
     assert trainer.micro % accum == 0
     trainer.micro = 0
     sync()
+    assert not model._vis_group, "no precomputed vision result may cross into the timed region"
     t0 = time.perf_counter()
     for clen in cycles:
         trainer.grad_accum, trainer.micro = clen, 0
-        for _ in range(clen):
-            loss = trainer.micro_step(batch, nxt)   # K vision forwards + K text fwd/bwd inside the window
+        for i in range(clen):
+            loss = trainer.micro_step(batch, nxt, upcoming=up[: clen - 1 - i])   # K vision forwards (in groups) + K text fwd/bwd in the window
     sync()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -249,14 +252,14 @@ def main():
     if not args.trim_pad and not args.no_trim_variant:
         model.trim_padding = True
         trainer.grad_accum, trainer.micro = cycles[0], 0
-        for _ in range(cycles[0]):
-            loss_t = trainer.micro_step(batch, nxt)  # warm the trimmed shapes over one whole window (allocator, LDS attributes, autotuner)
+        for i in range(cycles[0]):
+            loss_t = trainer.micro_step(batch, nxt, upcoming=up[: cycles[0] - 1 - i])  # warm the trimmed shapes over one whole window
         sync()
         t0 = time.perf_counter()
         for clen in cycles:
             trainer.grad_accum, trainer.micro = clen, 0
-            for _ in range(clen):
-                loss_t = trainer.micro_step(batch, nxt)
+            for i in range(clen):
+                loss_t = trainer.micro_step(batch, nxt, upcoming=up[: clen - 1 - i])
         sync()
         dtt = time.perf_counter() - t0
         if use_dist:
@@ -313,9 +316,16 @@ def main():
                 model.text_model.enable_fp8_forward(fp8)
                 n8 = max(1, args.variant_steps)
                 trainer.grad_accum, trainer.micro = n8, 0                # one accumulation cycle: n8 micro-batches + one AdamW
-                for _ in range(n8):
-                    trainer.micro_step(b8)                               # warm the 8-view shapes over the same cycle
-                dt8, l8 = timed(lambda: trainer.micro_step(b8), n8)
+                for i in range(n8):
+                    trainer.micro_step(b8, upcoming=[b8] * min(vg - 1, n8 - 1 - i))    # warm the 8-view shapes over the same cycle
+                assert not model._vis_group
+                left = [n8]
+
+                def step8():
+                    left[0] -= 1
+                    return trainer.micro_step(b8, upcoming=[b8] * min(vg - 1, left[0]))
+                dt8, l8 = timed(step8, n8)
+                assert not model._vis_group
                 variants[key] = {"value": round(B / dt8, 3), "unit": "samples/s", "ms_per_step": round(dt8 * 1e3, 2), "steps": n8,
                                  "views": 8, "geom_tokens": 8, "fp8_text_forward": fp8, "batch_per_gpu": B, "loss": round(float(l8.item()), 4),
                                  "executed_tflop_per_sample": round(tf8, 3),
@@ -335,13 +345,13 @@ def main():
         # rows): per-step figures below are the group's totals / nroof
         nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)), accum))
         trainer.grad_accum, trainer.micro = nroof, 0
-        for _ in range(nroof):
-            trainer.micro_step(batch)               # (the serial schedule's shapes are tuned before the events go in)
+        for i in range(nroof):
+            trainer.micro_step(batch, upcoming=up[: nroof - 1 - i])   # (the serial schedule's shapes are tuned before the events go in)
         torch.cuda.synchronize()
         ops.GEMM_PROFILE = []
         trainer.micro = 0
-        for _ in range(nroof):
-            trainer.micro_step(batch)
+        for i in range(nroof):
+            trainer.micro_step(batch, upcoming=up[: nroof - 1 - i])
         torch.cuda.synchronize()
         fl = sum(g[0] for g in ops.GEMM_PROFILE) / nroof
         by = sum(g[1] for g in ops.GEMM_PROFILE) / nroof
@@ -374,8 +384,8 @@ def main():
     elif world > 1:
         nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)), accum))
         trainer.grad_accum, trainer.micro = nroof, 0
-        for _ in range(2 * nroof):
-            trainer.micro_step(batch)  # keep collectives matched across ranks
+        for i in range(2 * nroof):
+            trainer.micro_step(batch, upcoming=up[: (nroof - 1 - i % nroof)])  # keep collectives matched across ranks
     if use_dist:
         dist.barrier()
 

@@ -312,3 +312,48 @@ def test_deferred_weight_gradients_match_per_microbatch_gemms():
     with pytest.raises(RuntimeError, match="alternate"):
         model._backward_text(st1, 1.0, False)
     model._backward_text(st2, 1.0, False)                       # the latest forward's operands are intact
+
+
+def test_vision_group_matches_per_microbatch_tower():
+    """Stage1Trainer(vision_group=n) + micro_step(upcoming=...): the frozen aggregator runs once over n micro-batches' concatenated
+    images; every micro-batch must get exactly the visual tokens (and so loss and gradients) its own pass would have produced,
+    results are handed out to the right batch (different images per micro-batch), and nothing is left waiting afterwards."""
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z, m, build, batch = _vlm()
+    mbs = []
+    for k in range(3):
+        b = dict(batch)
+        g = torch.Generator().manual_seed(7 + k)
+        b["pixel_values"] = (batch["pixel_values"] * 0.5 + 0.5 * torch.rand(batch["pixel_values"].shape, generator=g).cuda()).contiguous()
+        mbs.append(b)
+    class _Tower(torch.nn.Module):
+        """A stand-in tower whose output depends on its input, sample by sample (the goldens' stub returns a constant)."""
+        def __init__(self, base):
+            super().__init__()
+            self.base, self.embed_dim = base, base.shape[-1]
+
+        def aggregator(self, images):
+            scale = 1.0 + images.float().mean(dim=(1, 2, 3, 4))                       # [B']
+            out = self.base[:1].float() * scale.view(-1, *([1] * (self.base.dim() - 1)))
+            return [out.to(self.base.dtype)], 5
+
+    out = {}
+    for vg in (1, 3):
+        model = build()
+        model.vision_model = _Tower(model.vision_model.agg)
+        tr = Stage1Trainer(model, lr=0.0, proj_lr=0.0, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=3, wgrad_defer=1,
+                           vision_group=vg, max_grad_norm=None)
+        losses = [float(tr.micro_step(b, upcoming=mbs[i + 1:]).item()) for i, b in enumerate(mbs)]
+        assert not model._vis_group
+        out[vg] = (losses, model.text_model.flat_g.float().clone())
+        # the aggregator output itself, grouped vs alone (bitwise: every row of every GEMM sees the same operands in the same order)
+        if vg == 3:
+            model.precompute_vision([b["pixel_values"] for b in mbs])
+            grouped = [model._take_grouped(b["pixel_values"]) for b in mbs]
+            for b, ga in zip(mbs, grouped):
+                alone = model.vision_model.aggregator(b["pixel_values"])[0][-1]
+                assert relerr(ga, alone) < 2e-3
+    assert len(set(out[1][0])) == 3                                  # the three micro-batches really differ
+    for a, b in zip(out[1][0], out[3][0]):
+        assert abs(a - b) < 2e-3 * abs(a), (out[1][0], out[3][0])
+    assert relerr(out[3][1], out[1][1]) < 2e-2

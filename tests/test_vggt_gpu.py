@@ -211,3 +211,20 @@ def test_fused_qkv_epilogue_with_row_tail_launch():
         assert ((af - bf).norm() / bf.norm()).item() < 2e-3, name
         # the tail rows are the last 248 tokens of the last group
         assert ((af[-1, :, -248:] - bf[-1, :, -248:]).norm() / bf[-1, :, -248:].norm()).item() < 2e-3, name
+
+
+def test_aggregator_is_batch_invariant():
+    """precompute_vision() runs the tower once over several micro-batches' images: every sample must come out as in its own
+    micro-batch (frame attention per (sample, view), global attention per sample, GEMM rows independent of M - the tile configuration
+    may change with M, the k order of a row's dot products does not)."""
+    from vggt_qwen3_amd.vggt import VGGT
+    model = VGGT(img_size=70, patch_size=14, embed_dim=128, depth=2, dino_depth=2, device="cuda", seed=3)
+    agg = model.aggregator
+    g = torch.Generator().manual_seed(9)
+    a = torch.rand(2, 3, 3, 70, 84, generator=g).cuda()
+    b = torch.rand(1, 3, 3, 70, 84, generator=g).cuda()
+    ya, yb = agg(a)[0][-1], agg(b)[0][-1]
+    yab = agg(torch.cat([a, b], dim=0))[0][-1]
+    assert yab.shape[0] == 3
+    assert relerr(yab[:2], ya) < 1e-3 and relerr(yab[2:], yb) < 1e-3
+    assert (yab[:2].float() - ya.float()).abs().max() <= 2 ** -6 * ya.float().abs().max()

@@ -300,7 +300,7 @@ int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int tr
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return -1; }
   int best = -1;
   float best_ms = 1e30f;
-  const int reps = 3;
+  const int reps = 5;       // (the minimum of 5 cold launches: with 3 the ranking of near-ties flipped from box to box)
   for (int cand : cands) {
     if (launch_candidate(p, cand, transA, transB, nbatch, s) != 0) continue;      // warm-up (attribute set-up, code load)
     float tmin = 1e30f;

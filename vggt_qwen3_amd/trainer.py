@@ -49,7 +49,7 @@ class Stage1Trainer:
     def __init__(self, model: VGGTQwen3VLM, *, lr=5e-6, proj_lr=1e-4, weight_decay=0.1, warmup_ratio=0.03,
                  max_steps=30000, grad_accum=32, betas=(0.9, 0.999), eps=1e-8, bucket_layers: int = 4,
                  process_group=None, max_grad_norm: Optional[float] = 1.0, accelerate_scheduler_rule: bool = True,
-                 wgrad_defer: Optional[int] = None):
+                 wgrad_defer: Optional[int] = None, vision_group: Optional[int] = None):
         self.model = model
         self.tm = model.text_model
         self.lr, self.proj_lr, self.wd = lr, proj_lr, weight_decay
@@ -71,6 +71,11 @@ class Stage1Trainer:
         if wgrad_defer is None:
             wgrad_defer = int(os.environ.get("VQ3_WGRAD_DEFER", "8"))
         self.tm.enable_wgrad_deferral(min(max(1, wgrad_defer), max(1, grad_accum)))
+        # the frozen vision tower runs once per `vision_group` micro-batches on their concatenated images (vlm.py: precompute_vision)
+        # when micro_step() is given the upcoming batches; fit() looks ahead by itself
+        if vision_group is None:
+            vision_group = int(os.environ.get("VQ3_VISION_GROUP", "4"))      # measured: 1: 91.9, 2: 94.8, 4: 96.0, 8 / 16: 95.8 samples/s
+        self.vision_group = max(1, vision_group)
         self.micro = 0       # micro-batches seen (the reference's `step`)
         self.opt_step = 0    # optimiser / scheduler steps
         dev = self.tm.flat_w.device
@@ -127,11 +132,17 @@ class Stage1Trainer:
             self._allreduce_span(*self.buckets[i])
 
     # ------------------------------------------------------------------ one micro-batch
-    def micro_step(self, batch: dict, next_batch: Optional[dict] = None) -> torch.Tensor:
+    def micro_step(self, batch: dict, next_batch: Optional[dict] = None, upcoming=None) -> torch.Tensor:
         """forward + backward (+ gradient all-reduce, AdamW, schedule on accumulation boundaries). Returns the loss.
         next_batch (optional): its frozen vision-tower forward is enqueued on a second stream now, overlapping this
-        micro-batch's text forward/backward; pass the same dict to the next call."""
+        micro-batch's text forward/backward; pass the same dict to the next call.
+        upcoming (optional): the batches of the following micro-steps, in order. When this batch's images have no aggregator result
+        waiting, the tower runs once over this batch + the first vision_group - 1 of them; they must then be passed to the next
+        micro_step() calls as the very same dicts / tensors."""
         model, tm = self.model, self.tm
+        if self.vision_group > 1 and upcoming and not any(im is batch["pixel_values"] for im, _ in model._vis_group):
+            group = [batch["pixel_values"]] + [b["pixel_values"] for b in list(upcoming)[: self.vision_group - 1]]
+            model.precompute_vision(group)
         if next_batch is not None:
             model.prefetch_images(next_batch["pixel_values"])
         k = self.micro % self.grad_accum
@@ -215,13 +226,22 @@ class Stage1Trainer:
         it = iter(batches)
         t0 = time.perf_counter()
         start = self.micro
-        while self.micro < self.max_steps:
+        from collections import deque
+        ahead: deque = deque()          # look-ahead of vision_group batches: their images share one pass of the frozen vision tower
+
+        def pull():
+            nonlocal it
             try:
-                batch = next(it)
+                return next(it)
             except StopIteration:
                 it = iter(batches)
-                batch = next(it)
-            loss = self.micro_step(batch)
+                return next(it)
+
+        while self.micro < self.max_steps:
+            while len(ahead) < self.vision_group and self.micro + len(ahead) < self.max_steps:
+                ahead.append(pull())
+            batch = ahead.popleft()
+            loss = self.micro_step(batch, upcoming=list(ahead))
             step = self.micro - 1
             if rank == 0 and step % log_every_steps == 0:
                 dt = time.perf_counter() - t0

@@ -165,6 +165,7 @@ class VGGTQwen3VLM(nn.Module):
             self.text_model.enable_fp8_forward(True)
         self._vis_stream = None
         self._prefetched = None
+        self._vis_group = []          # [(images tensor, aggregator tokens)]: precompute_vision() results waiting for their micro-batch
         self._text_param_names = [n for n, _ in self.text_model.named_parameters()]
 
     def _apply(self, fn, recurse=True):
@@ -205,11 +206,42 @@ class VGGTQwen3VLM(nn.Module):
 
     # ------------------------------------------------------------------ encoders
     @torch.no_grad()
-    def encode_images(self, images: torch.Tensor) -> torch.Tensor:
+    @torch.no_grad()
+    def precompute_vision(self, images_list) -> None:
+        """The frozen aggregator (vggt_qwen3_vlm.py:44-45,128-144: no_grad, eval-mode arithmetic, no dropout) for SEVERAL upcoming
+        micro-batches in one pass: their images are concatenated along the batch axis - every sample's frame / global attention and
+        every token row of the GEMMs is computed exactly as in its own micro-batch - so that the tower's GEMMs run at 4 x 6174 rows
+        instead of 6174 (at 8 x: fc1 713 vs 620 TF/s, q|k|v 711 vs 553, proj 634 vs 557; whole rounds of 256 x 256 tiles). Results wait in
+        FIFO order; encode_images() of the SAME tensor object picks its slice up and runs only the (train-mode dropout) projector."""
+        imgs = [im.to(self.device_) for im in images_list]
+        if not imgs:
+            return
+        shapes = {tuple(im.shape[1:]) for im in imgs}
+        if len(shapes) != 1:                               # different view counts / sizes cannot share a pass
+            return
+        toks, _ = self.vision_model.aggregator(torch.cat(imgs, dim=0) if len(imgs) > 1 else imgs[0])
+        agg = toks[-1]
+        if agg.shape[0] != sum(im.shape[0] for im in imgs):    # (a tower that does not keep the batch axis first: no sharing)
+            return
+        b0 = 0
+        for orig, im in zip(images_list, imgs):
+            self._vis_group.append((orig, agg[b0:b0 + im.shape[0]]))
+            b0 += im.shape[0]
+
+    def _take_grouped(self, images: torch.Tensor):
+        for k, (im, agg) in enumerate(self._vis_group):
+            if im is images:
+                del self._vis_group[k]
+                return agg
+        return None
+
+    def encode_images(self, images: torch.Tensor, _orig: Optional[torch.Tensor] = None) -> torch.Tensor:
         """images [B, V, C, H, W] -> [B, num_vis_tokens, hidden] (vggt_qwen3_vlm.py:128-162)."""
         B, V = images.shape[:2]
-        toks, _ = self.vision_model.aggregator(images)
-        agg = toks[-1]
+        agg = self._take_grouped(images if _orig is None else _orig) if self._vis_group else None
+        if agg is None:
+            toks, _ = self.vision_model.aggregator(images)
+            agg = toks[-1]
         if agg.dim() == 3:
             agg = agg[:, : self.num_vis_tokens, :]
         elif agg.dim() == 4:
@@ -280,10 +312,11 @@ class VGGTQwen3VLM(nn.Module):
         labels = labels.to(self.device_)
         attention_mask0, labels0 = attention_mask, labels       # the caller's tensors: keys of the remembered host-side facts
         B, L = input_ids.shape
+        images0 = images
         images = images.to(self.device_)
         vis = self._take_prefetched(images)
         if vis is None:
-            vis = self.encode_images(images)                                                  # [B, Nv, H] fp32
+            vis = self.encode_images(images, _orig=images0)                                   # [B, Nv, H] fp32
         gfeat = self._geom_inputs(geom_token)
         geom_ctx, gy = None, None
         if gfeat is not None:
