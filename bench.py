@@ -223,7 +223,7 @@ def main():
     nwarm = (max(args.warmup, 1) + accum - 1) // accum * accum
     trainer.grad_accum = accum
     nxt = batch if args.vision_prefetch else None   # next micro-batch's (frozen) vision forward overlaps this one
-    vg = max(1, trainer.vision_group)
+    vg = max(1, trainer.vision_group, trainer.text_group)
     up = [batch] * (vg - 1)     # the following micro-batches (the same synthetic batch): one vision-tower pass per vg micro-batches
     for i in range(nwarm):
         loss = trainer.micro_step(batch, nxt, upcoming=up[: nwarm - 1 - i])
@@ -343,7 +343,7 @@ def main():
         model.text_model._wgrad_stream = None   # serial launches: per-launch event times are not inflated by overlap
         # one group of the deferred weight-gradient schedule (every projection's weight-gradient GEMM runs over nroof micro-batches'
         # rows): per-step figures below are the group's totals / nroof
-        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)), accum))
+        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)) * max(1, trainer.text_group), accum))
         trainer.grad_accum, trainer.micro = nroof, 0
         for i in range(nroof):
             trainer.micro_step(batch, upcoming=up[: nroof - 1 - i])   # (the serial schedule's shapes are tuned before the events go in)
@@ -382,7 +382,7 @@ def main():
                 "algorithmic_bytes_per_launch": round(by / nlaunch), "launches_per_step": round(nlaunch, 1), "avg_launch_us": round(ms * 1e3 / nlaunch, 2),
                 "gemm_ms_per_step": round(ms, 2), "gemm_tflop_per_step": round(fl / 1e12, 3)}
     elif world > 1:
-        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)), accum))
+        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)) * max(1, trainer.text_group), accum))
         trainer.grad_accum, trainer.micro = nroof, 0
         for i in range(2 * nroof):
             trainer.micro_step(batch, upcoming=up[: (nroof - 1 - i % nroof)])  # keep collectives matched across ranks

@@ -206,6 +206,11 @@ int vq3_scatter_rows(const void* src, const int32_t* idx, void* dst, int32_t n, 
  * columns V..ldl-1 zeroed. Caller zeroes loss_sum and divides by n. */
 int vq3_cross_entropy_fwd_bwd(void* logits, const int32_t* targets, float* loss_sum_f32, int32_t n, int32_t V,
                               int32_t ldl, float gscale, void* stream);
+/* The same with a per-row gradient scale and the per-row losses written out (row_loss_f32[i] = logsumexp_i - logit_i[target_i]):
+ * rows of several micro-batches in one launch, each micro-batch's mean taken over its own labelled rows (loss_utils.py:49-71 per
+ * micro-batch, train_sft.py:213 scaling). */
+int vq3_cross_entropy_rows(void* logits, const int32_t* targets, const float* row_scale_f32, float* row_loss_f32, int32_t n, int32_t V,
+                           int32_t ldl, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * VGGT aggregator (un-vendored `vggt` package: vggt.models.aggregator.Aggregator, vggt.layers.{block,attention,rope,

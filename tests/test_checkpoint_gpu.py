@@ -180,6 +180,8 @@ def test_trainer_fit_loop_like_train_sft(tmp_path):
     z = load("vlm_tiny.npz")
     m = meta(z)
     model = _build_vlm(z, m).train()
+    from tests.test_trainer_gpu import _Tower
+    model.vision_model = _Tower(model.vision_model.agg)      # a tower that follows its input's batch axis: fit() merges micro-batches
     b = _batch(z)
     half = {k: (v[:3] if torch.is_tensor(v) else v) for k, v in b.items()}
     half["geom_token"] = {k: v[:3] for k, v in b["geom_token"].items()}

@@ -282,7 +282,7 @@ def test_deferred_weight_gradients_match_per_microbatch_gemms():
     for depth in (1, 2, 3, 4):
         model = build()
         tr = Stage1Trainer(model, lr=0.0, proj_lr=0.0, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=4,
-                           wgrad_defer=depth, max_grad_norm=None)
+                           wgrad_defer=depth, text_group=1, max_grad_norm=None)
         assert model.text_model._wd_depth == depth
         for b in mbs:
             tr.micro_step(b)
@@ -314,6 +314,18 @@ def test_deferred_weight_gradients_match_per_microbatch_gemms():
     model._backward_text(st2, 1.0, False)                       # the latest forward's operands are intact
 
 
+class _Tower(torch.nn.Module):
+    """A stand-in tower whose output depends on its input, sample by sample (the goldens' stub returns a constant)."""
+    def __init__(self, base):
+        super().__init__()
+        self.base, self.embed_dim = base, base.shape[-1]
+
+    def aggregator(self, images):
+        scale = 1.0 + images.float().mean(dim=(1, 2, 3, 4))                       # [B']
+        out = self.base[:1].float() * scale.view(-1, *([1] * (self.base.dim() - 1)))
+        return [out.to(self.base.dtype)], 5
+
+
 def test_vision_group_matches_per_microbatch_tower():
     """Stage1Trainer(vision_group=n) + micro_step(upcoming=...): the frozen aggregator runs once over n micro-batches' concatenated
     images; every micro-batch must get exactly the visual tokens (and so loss and gradients) its own pass would have produced,
@@ -326,23 +338,12 @@ def test_vision_group_matches_per_microbatch_tower():
         g = torch.Generator().manual_seed(7 + k)
         b["pixel_values"] = (batch["pixel_values"] * 0.5 + 0.5 * torch.rand(batch["pixel_values"].shape, generator=g).cuda()).contiguous()
         mbs.append(b)
-    class _Tower(torch.nn.Module):
-        """A stand-in tower whose output depends on its input, sample by sample (the goldens' stub returns a constant)."""
-        def __init__(self, base):
-            super().__init__()
-            self.base, self.embed_dim = base, base.shape[-1]
-
-        def aggregator(self, images):
-            scale = 1.0 + images.float().mean(dim=(1, 2, 3, 4))                       # [B']
-            out = self.base[:1].float() * scale.view(-1, *([1] * (self.base.dim() - 1)))
-            return [out.to(self.base.dtype)], 5
-
     out = {}
     for vg in (1, 3):
         model = build()
         model.vision_model = _Tower(model.vision_model.agg)
         tr = Stage1Trainer(model, lr=0.0, proj_lr=0.0, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=3, wgrad_defer=1,
-                           vision_group=vg, max_grad_norm=None)
+                           vision_group=vg, text_group=1, max_grad_norm=None)
         losses = [float(tr.micro_step(b, upcoming=mbs[i + 1:]).item()) for i, b in enumerate(mbs)]
         assert not model._vis_group
         out[vg] = (losses, model.text_model.flat_g.float().clone())
@@ -357,3 +358,52 @@ def test_vision_group_matches_per_microbatch_tower():
     for a, b in zip(out[1][0], out[3][0]):
         assert abs(a - b) < 2e-3 * abs(a), (out[1][0], out[3][0])
     assert relerr(out[3][1], out[1][1]) < 2e-2
+
+
+def test_merged_micro_batches_match_one_by_one():
+    """Stage1Trainer(text_group=n) + micro_step(upcoming=...): n micro-batches of a window run as ONE forward/backward over their
+    concatenated samples. Each micro-batch's loss must be the mean over ITS OWN labelled rows, the gradient that of their sum (what
+    the micro-batches give one by one) - with different images, ids and label counts per micro-batch, one micro-batch without labels,
+    a window (5) that is not a multiple of the group (3), and geom_head gradients included."""
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z, m, build, batch = _vlm()
+    mbs = []
+    for k in range(5):
+        b = dict(batch)
+        g = torch.Generator().manual_seed(50 + k)
+        lab = batch["labels"].clone()
+        ids = batch["input_ids"].clone()
+        keep = lab != -100
+        if k == 1:
+            lab[:] = -100                                        # no labelled row at all
+        elif k:
+            noise = torch.randint(5, 200, ids.shape, generator=g).to(ids.device)
+            drop = (torch.rand(ids.shape, generator=g) < 0.15 * k).to(ids.device) & keep      # different label counts per micro-batch
+            ids = torch.where(keep, noise, ids)
+            lab = torch.where(keep & ~drop, noise, torch.full_like(lab, -100))
+        b["input_ids"], b["labels"] = ids, lab
+        b["pixel_values"] = (batch["pixel_values"] * 0.5 + 0.5 * torch.rand(batch["pixel_values"].shape, generator=g).cuda()).contiguous()
+        mbs.append(b)
+    res = {}
+    for tg in (1, 3):
+        model = build()
+        model.vision_model = _Tower(model.vision_model.agg)
+        tr = Stage1Trainer(model, lr=0.0, proj_lr=0.0, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=5, wgrad_defer=1,
+                           vision_group=1, text_group=tg, max_grad_norm=None)
+        losses = [float(tr.micro_step(b, upcoming=mbs[i + 1:]).item()) for i, b in enumerate(mbs)]
+        assert not tr._merged_pending and tr.micro == 5 and tr.opt_step == 1
+        res[tg] = (losses, model.text_model.flat_g.float().clone(), tr.geom_grad.clone())
+    l1, l3 = res[1][0], res[3][0]
+    assert l1[1] != l1[1] and l3[1] != l3[1]                     # NaN for the unlabelled micro-batch, as the reference's mean over nothing
+    for k in (0, 2, 3, 4):
+        assert abs(l1[k] - l3[k]) < 2e-3 * abs(l1[k]), (k, l1, l3)
+    assert relerr(res[3][1], res[1][1]) < 2e-2, relerr(res[3][1], res[1][1])
+    assert relerr(res[3][2][:-1], res[1][2][:-1]) < 2e-2
+    # out-of-order hand-back is refused
+    model = build()
+    model.vision_model = _Tower(model.vision_model.agg)
+    tr = Stage1Trainer(model, lr=0.0, proj_lr=0.0, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=4, text_group=2,
+                       max_grad_norm=None)
+    tr.micro_step(mbs[0], upcoming=[mbs[2]])
+    with pytest.raises(RuntimeError, match="same objects"):
+        tr.micro_step(mbs[3])

@@ -78,6 +78,7 @@ SIGNATURES = {
     "vq3_gather_rows": [c_p, c_p, c_p, i32, i32, i32, c_p],
     "vq3_scatter_rows": [c_p, c_p, c_p, i32, i32, i32, c_p],
     "vq3_cross_entropy_fwd_bwd": [c_p, c_p, c_p, i32, i32, i32, f32, c_p],
+    "vq3_cross_entropy_rows": [c_p, c_p, c_p, c_p, i32, i32, i32, c_p],
     "vq3_im2col_norm": [c_p, c_p, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), c_p],
     "vq3_vit_qkprep": [c_p] * 10 + [i64, i32, i32, i32, i32, i32, i32, i32, i32, f32, c_p],
     "vq3_flash_attn_fwd": [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i64, f32, c_p],

@@ -303,8 +303,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
 // ---------------------------------------------------------------- cross entropy (one block per row)
 // 1024 threads, 16-byte accesses: a 152k-entry row is 19 vector loads per thread and pass (three passes: max, sum of
 // exponentials, gradient written in place). Rows start 16-byte aligned (ldl % 8 == 0, checked on the host).
+// row_scale / row_loss (both optional): a per-row gradient scale instead of the uniform one, and the row's loss written out instead
+// of added to loss_sum - several micro-batches share one launch, each normalised by its own number of labelled rows.
 __global__ __launch_bounds__(1024) void cross_entropy_kernel(bf16_t* __restrict__ logits, const int32_t* __restrict__ tgt,
-                                                             float* __restrict__ loss_sum, int V, int ldl, float gscale) {
+                                                             float* __restrict__ loss_sum, int V, int ldl, float gscale,
+                                                             const float* __restrict__ row_scale, float* __restrict__ row_loss) {
   __shared__ float red[16];
   bf16_t* lr = logits + (long)blockIdx.x * ldl;
   const int t = tgt[blockIdx.x];
@@ -326,7 +329,11 @@ __global__ __launch_bounds__(1024) void cross_entropy_kernel(bf16_t* __restrict_
   }
   sum = block_sum<16>(sum, red);
   const float lse = mx + __logf(sum);
-  if (threadIdx.x == 0) atomicAdd(loss_sum, lse - bf2f(lr[t]));
+  if (row_scale) gscale = row_scale[blockIdx.x];
+  if (threadIdx.x == 0) {
+    if (row_loss) row_loss[blockIdx.x] = lse - bf2f(lr[t]);
+    else atomicAdd(loss_sum, lse - bf2f(lr[t]));
+  }
   __syncthreads();  // the target logit has been read before any thread rewrites the row
   for (int c = threadIdx.x; c < nv; c += 1024) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + c * 8);
@@ -573,8 +580,18 @@ extern "C" int vq3_cross_entropy_fwd_bwd(void* logits, const int32_t* targets, f
   VQ3_CHECK_ARG(logits && targets && loss_sum_f32 && n > 0 && V > 0 && ldl >= V, "cross_entropy: bad args");
   VQ3_CHECK_ARG(ldl % 8 == 0 && (uintptr_t)logits % 16 == 0, "cross_entropy: rows must be 16-byte aligned (ldl %% 8 == 0)");
   hipLaunchKernelGGL(cross_entropy_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, (bf16_t*)logits, targets,
-                     loss_sum_f32, V, ldl, gscale);
+                     loss_sum_f32, V, ldl, gscale, (const float*)nullptr, (float*)nullptr);
   VQ3_CHECK_LAUNCH("cross_entropy");
+  return 0;
+}
+
+extern "C" int vq3_cross_entropy_rows(void* logits, const int32_t* targets, const float* row_scale, float* row_loss, int32_t n,
+                                      int32_t V, int32_t ldl, void* stream) {
+  VQ3_CHECK_ARG(logits && targets && row_scale && row_loss && n > 0 && V > 0 && ldl >= V, "cross_entropy_rows: bad args");
+  VQ3_CHECK_ARG(ldl % 8 == 0 && (uintptr_t)logits % 16 == 0, "cross_entropy_rows: rows must be 16-byte aligned (ldl %% 8 == 0)");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, (bf16_t*)logits, targets,
+                     (float*)nullptr, V, ldl, 0.f, row_scale, row_loss);
+  VQ3_CHECK_LAUNCH("cross_entropy_rows");
   return 0;
 }
 

@@ -368,6 +368,14 @@ def cross_entropy_fwd_bwd(logits: torch.Tensor, targets: torch.Tensor, loss_sum:
                                                 logits.stride(0), gscale, _stream()), "vq3_cross_entropy_fwd_bwd")
 
 
+def cross_entropy_rows(logits: torch.Tensor, targets: torch.Tensor, row_scale: torch.Tensor, row_loss: torch.Tensor, n: int, V: int) -> None:
+    """Per-row form: dlogits[i] = (softmax_i - onehot_i) * row_scale[i] in place, row_loss[i] = the row's cross entropy."""
+    _req(logits, BF16, "ce logits"); _req(targets, torch.int32, "ce targets"); _req(row_scale, F32, "ce row_scale"); _req(row_loss, F32, "ce row_loss")
+    assert logits.dim() == 2 and logits.stride(1) == 1 and row_scale.numel() >= n and row_loss.numel() >= n
+    check(_lib.load().vq3_cross_entropy_rows(logits.data_ptr(), targets.data_ptr(), row_scale.data_ptr(), row_loss.data_ptr(), n, V,
+                                             logits.stride(0), _stream()), "vq3_cross_entropy_rows")
+
+
 def adamw_step(master, m, v, grad, w, lr, beta1, beta2, eps, wd, step, gscale=1.0, clip=None) -> None:
     """clip = (sumsq f32[1] device tensor, max_norm): global-norm clipping, coefficient computed on the device as
     min(1, max_norm / (sqrt(sumsq) * gscale + 1e-6)) (torch.nn.utils.clip_grad_norm_'s formula on the scaled gradients)."""

@@ -445,10 +445,14 @@ class Qwen3ForCausalLM(nn.Module):
         idx = (flat != -100).nonzero(as_tuple=False).squeeze(1)
         return idx.to(torch.int32), flat[idx].to(torch.int32)
 
-    def loss_head(self, h_last: torch.Tensor, labels: torch.Tensor, save: bool, L: Optional[int] = None, plan_key=None):
+    def loss_head(self, h_last: torch.Tensor, labels: torch.Tensor, save: bool, L: Optional[int] = None, plan_key=None,
+                  groups: Optional[List[int]] = None):
         """Final RMSNorm + tied lm_head + shifted mean cross-entropy, evaluated only on the rows that carry a label
         (the other rows of the reference's [B,L,V] logits never reach the loss). Also leaves d(loss)/d(logits) in
-        place for the backward."""
+        place for the backward.
+        groups (sample counts, sum = B): the batch is several of the reference's micro-batches concatenated; each one's loss is the
+        mean over ITS labelled rows (loss_utils.py:49-71 is applied per micro-batch) and the gradient of the SUM of those losses is
+        prepared - exactly what the micro-batches produce one by one. Returns a loss vector [len(groups)] then."""
         c = self.config
         H = c.hidden_size
         if L is not None and labels.shape[1] < L:   # h_last rows follow the padded length of forward_hidden
@@ -459,16 +463,32 @@ class Qwen3ForCausalLM(nn.Module):
             idx, tgt = self.label_rows(labels)
         n = int(idx.numel())
         if n == 0:
-            return torch.full((), float("nan"), device=h_last.device, dtype=F32), None
+            return torch.full((len(groups),) if groups is not None else (), float("nan"), device=h_last.device, dtype=F32), None
         n8 = round_up(n, 8)                                  # zero rows: contribute nothing, keep K % 8 == 0 in backward
         hs = ops.gather_rows(h_last, idx, n, n8)
         hn, rstd = ops.rmsnorm_fwd(hs, self._w["norm"], c.rms_norm_eps, want_rstd=True)
         ldl = self.vocab_p
         logits = torch.zeros((n8, ldl), device=h_last.device, dtype=BF16)
         ops.gemm_raw(hn, self._w["embed"], logits, n, self.vocab, H, H, H, ldl)
-        loss_sum = torch.zeros(1, device=h_last.device, dtype=F32)
-        ops.cross_entropy_fwd_bwd(logits, tgt, loss_sum, n, self.vocab, 1.0 / n)
-        loss = (loss_sum / n).reshape(())
+        if groups is not None and len(groups) > 1:
+            def rows_of_groups():
+                edges = torch.tensor(groups, device=idx.device).cumsum(0)                          # sample index where each group ends
+                gid = torch.bucketize(idx.long() // labels.shape[1], edges, right=True)          # group of every labelled row
+                cnt = torch.bincount(gid, minlength=len(groups)).to(F32)
+                scale = torch.zeros(n8, device=idx.device, dtype=F32)
+                scale[:n] = 1.0 / cnt[gid]
+                return gid, cnt, scale
+            gid, cnt, scale = PLAN.get(("label_groups", tuple(labels.shape), tuple(groups)), plan_key, rows_of_groups) \
+                if plan_key is not None else rows_of_groups()
+            row_loss = torch.zeros(n8, device=h_last.device, dtype=F32)
+            ops.cross_entropy_rows(logits, tgt, scale, row_loss, n, self.vocab)
+            loss = torch.zeros(len(groups), device=h_last.device, dtype=F32).index_add_(0, gid, row_loss[:n]) / cnt   # 0/0 = NaN: no labels
+        else:
+            loss_sum = torch.zeros(1, device=h_last.device, dtype=F32)
+            ops.cross_entropy_fwd_bwd(logits, tgt, loss_sum, n, self.vocab, 1.0 / n)
+            loss = (loss_sum / n).reshape(())
+            if groups is not None:
+                loss = loss.reshape(1)
         ctx = dict(idx=idx, n=n, n8=n8, hs=hs, hn=hn, rstd=rstd, dlogits=logits) if save else None
         return loss, ctx
 

@@ -49,7 +49,7 @@ class Stage1Trainer:
     def __init__(self, model: VGGTQwen3VLM, *, lr=5e-6, proj_lr=1e-4, weight_decay=0.1, warmup_ratio=0.03,
                  max_steps=30000, grad_accum=32, betas=(0.9, 0.999), eps=1e-8, bucket_layers: int = 4,
                  process_group=None, max_grad_norm: Optional[float] = 1.0, accelerate_scheduler_rule: bool = True,
-                 wgrad_defer: Optional[int] = None, vision_group: Optional[int] = None):
+                 wgrad_defer: Optional[int] = None, vision_group: Optional[int] = None, text_group: Optional[int] = None):
         self.model = model
         self.tm = model.text_model
         self.lr, self.proj_lr, self.wd = lr, proj_lr, weight_decay
@@ -68,9 +68,19 @@ class Stage1Trainer:
             self.tm.enable_dgrad_transposes(True)
         # weight-gradient GEMMs once per `wgrad_defer` micro-batches of a window over their concatenated token rows (qwen3.py,
         # "deferred weight gradients"): +32 % on those GEMMs at depth 4, +35 % at 8, for 4.2 GB of operand slabs per micro-batch held
+        # `text_group` micro-batches of a window run as ONE forward/backward over their concatenated samples when micro_step() is given
+        # the upcoming batches (fit() looks ahead): every GEMM of the text model sees 8 x 1200 token rows (256 x 256 tiles instead of
+        # 200 under-filled 128 x 128 ones), the tower 8 x 6174; each micro-batch's loss stays the mean over ITS labelled rows and the
+        # gradient is that of their sum - what the micro-batches produce one by one (Qwen3ForCausalLM.loss_head(groups=...)).
+        if text_group is None:
+            text_group = int(os.environ.get("VQ3_TEXT_GROUP", "8"))     # measured: 1: 96.6, 2: 106.5, 4: 115.1, 8: 119.1, 16: 115.3 samples/s
+        self.text_group = max(1, text_group)
+        self._merged_pending: List = []     # [(batch dict, loss)] of a merged pass, handed out by the following micro_step() calls
+        self._merge_cache = None
         if wgrad_defer is None:
             wgrad_defer = int(os.environ.get("VQ3_WGRAD_DEFER", "8"))
-        self.tm.enable_wgrad_deferral(min(max(1, wgrad_defer), max(1, grad_accum)))
+        # (depth counts backward passes: with merged passes the same number of token rows per weight-gradient product)
+        self.tm.enable_wgrad_deferral(min(max(1, wgrad_defer // self.text_group), max(1, grad_accum)))
         # the frozen vision tower runs once per `vision_group` micro-batches on their concatenated images (vlm.py: precompute_vision)
         # when micro_step() is given the upcoming batches; fit() looks ahead by itself
         if vision_group is None:
@@ -140,16 +150,34 @@ class Stage1Trainer:
         waiting, the tower runs once over this batch + the first vision_group - 1 of them; they must then be passed to the next
         micro_step() calls as the very same dicts / tensors."""
         model, tm = self.model, self.tm
-        if self.vision_group > 1 and upcoming and not any(im is batch["pixel_values"] for im, _ in model._vis_group):
-            group = [batch["pixel_values"]] + [b["pixel_values"] for b in list(upcoming)[: self.vision_group - 1]]
-            model.precompute_vision(group)
+        if self._merged_pending:            # this micro-batch already ran as part of a merged pass: hand its loss out
+            expected, loss = self._merged_pending[0]
+            if expected is not batch:
+                raise RuntimeError("micro_step: the batches passed as `upcoming` must come back, in order, as the same objects")
+            self._merged_pending.pop(0)
+            self.micro += 1
+            return loss
+        k = self.micro % self.grad_accum
+        members = [batch]
+        if self.text_group > 1 and upcoming:
+            cand = [batch] + list(upcoming)[: min(self.text_group, self.grad_accum - k) - 1]     # never across a window boundary
+            if len(cand) > 1 and self._mergeable(cand):
+                members = cand
+        gsize = len(members)
+        sizes = None
+        if gsize > 1:
+            batch_run, sizes = self._merge(members)
+        else:
+            batch_run = batch
+            if self.vision_group > 1 and upcoming and not any(im is batch["pixel_values"] for im, _ in model._vis_group):
+                group = [batch["pixel_values"]] + [b["pixel_values"] for b in list(upcoming)[: self.vision_group - 1]]
+                model.precompute_vision(group)
         if next_batch is not None:
             model.prefetch_images(next_batch["pixel_values"])
-        k = self.micro % self.grad_accum
-        boundary = (k == self.grad_accum - 1)
+        boundary = (k + gsize - 1 == self.grad_accum - 1)
         accumulate = k != 0
-        st = model.forward_state(batch["pixel_values"], batch.get("geom_token"), batch["input_ids"],
-                                 batch["attention_mask"], batch["labels"], need_grad=True)
+        st = model.forward_state(batch_run["pixel_values"], batch_run.get("geom_token"), batch_run["input_ids"],
+                                 batch_run["attention_mask"], batch_run["labels"], need_grad=True, loss_groups=sizes)
         hook = self._layer_done if (boundary and self.dist_on) else None
         self._fired = []
         if not accumulate:
@@ -161,11 +189,40 @@ class Stage1Trainer:
             g = model.geom_head_backward(st, d_geom)
             self.geom_grad[: self._gn] += torch.cat([g["0.weight"].reshape(-1), g["0.bias"].reshape(-1),
                                                      g["2.weight"].reshape(-1), g["2.bias"].reshape(-1)])
-            self.geom_grad[self._gn:] += 1.0
+            self.geom_grad[self._gn:] += float(gsize)
         if boundary:
             self._optimizer_step()
         self.micro += 1
+        if gsize > 1:
+            losses = st["loss"]
+            self._merged_pending = [(members[j], losses[j]) for j in range(1, gsize)]
+            return losses[0]
         return st["loss"]
+
+    @staticmethod
+    def _mergeable(members) -> bool:
+        b0 = members[0]
+        for b in members[1:]:
+            for key in ("pixel_values", "input_ids", "attention_mask", "labels"):
+                if tuple(b[key].shape[1:]) != tuple(b0[key].shape[1:]) or b[key].dtype != b0[key].dtype or b[key].device != b0[key].device:
+                    return False
+            if (b.get("geom_token") is None) != (b0.get("geom_token") is None):
+                return False
+        return True
+
+    def _merge(self, members):
+        """Concatenate the collator dicts of several micro-batches along the sample axis (remembered for the last group of batch
+        OBJECTS, so that a loop that re-feeds the same batches re-uses the tensors and the host-side facts memoised on them)."""
+        ids = tuple(id(b) for b in members)
+        mc = self._merge_cache
+        if mc is not None and mc[0] == ids and all(a is b for a, b in zip(mc[1], members)):
+            return mc[2], mc[3]
+        merged = {k: torch.cat([b[k] for b in members], dim=0) for k in ("pixel_values", "input_ids", "attention_mask", "labels")}
+        if members[0].get("geom_token") is not None:
+            merged["geom_token"] = {k: torch.cat([b["geom_token"][k] for b in members], dim=0) for k in members[0]["geom_token"]}
+        sizes = [int(b["input_ids"].shape[0]) for b in members]
+        self._merge_cache = (ids, list(members), merged, sizes)
+        return merged, sizes
 
     def lr_mult(self, opt_step: int) -> float:
         """Schedule multiplier used BY optimiser step `opt_step` (1-based): the schedule has been ticked
@@ -238,7 +295,7 @@ class Stage1Trainer:
                 return next(it)
 
         while self.micro < self.max_steps:
-            while len(ahead) < self.vision_group and self.micro + len(ahead) < self.max_steps:
+            while len(ahead) < max(self.vision_group, self.text_group) and self.micro + len(ahead) < self.max_steps:
                 ahead.append(pull())
             batch = ahead.popleft()
             loss = self.micro_step(batch, upcoming=list(ahead))

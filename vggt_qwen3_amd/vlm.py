@@ -303,8 +303,10 @@ class VGGTQwen3VLM(nn.Module):
         return PLAN.get(("srcmap", self.image_id, S), (input_ids,), lambda: build_srcmap(input_ids, self.image_id, S))
 
     # ------------------------------------------------------------------ forward / backward
-    def forward_state(self, images, geom_token, input_ids, attention_mask, labels, need_grad: bool) -> dict:
-        """Runs the whole path on the HIP kernels and returns a state dict with `loss` (+ what backward needs)."""
+    def forward_state(self, images, geom_token, input_ids, attention_mask, labels, need_grad: bool, loss_groups=None) -> dict:
+        """Runs the whole path on the HIP kernels and returns a state dict with `loss` (+ what backward needs).
+        loss_groups (sample counts): the batch is several micro-batches concatenated; `loss` is then the vector of their losses and
+        the backward differentiates their sum (Qwen3ForCausalLM.loss_head)."""
         tm = self.text_model
         H = tm.config.hidden_size
         input_ids = input_ids.to(self.device_)
@@ -344,7 +346,7 @@ class VGGTQwen3VLM(nn.Module):
         self._last_L = L
         emb = ops.embed_splice_fwd(input_ids.contiguous(), tm._w["embed"], feats16, srcmap, B, L, H, S)
         h_last, saved = tm.forward_hidden(emb, attention_mask, save=need_grad, plan_key=(attention_mask0,))
-        loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad, L=saved["L"], plan_key=(labels0,))
+        loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad, L=saved["L"], plan_key=(labels0,), groups=loss_groups)
         return dict(loss=loss, saved=saved, head=head_ctx, srcmap=srcmap, input_ids=input_ids, B=B, L=L, S=S,
                     geom_ctx=geom_ctx, geom_y=gy, emb=emb, h_last=h_last)
 
