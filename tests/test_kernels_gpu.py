@@ -195,6 +195,26 @@ def test_gemm_layernorm_fold(ops, cfg):
         ops.gemm_force_config(-3)
 
 
+def test_colsum_multi_tall_slabs(ops):
+    """vq3_colsum_multi on the slabs a merged pass of 8 micro-batches leaves (9600 x 128 from the q/k-prep backward, 480 x 2560 from
+    RMSNorm): rows split over several workgroups, combined by the last arriver in split order - equal to the f32 column sums,
+    bit-identical when repeated (tickets reset themselves), accumulate honoured; small slabs keep the one-workgroup path."""
+    torch.manual_seed(0)
+    for shapes in (((9600, 128), (9600, 128), (480, 2560), (480, 2560)), ((300, 2560), (1200, 128)), ((20000, 64),)):
+        parts = [torch.randn(r, c, device="cuda") for r, c in shapes]
+        outs = [torch.randn(c, device="cuda").to(BF16) for _, c in shapes]
+        old = [o.clone() for o in outs]
+        acc = [i % 2 == 1 for i in range(len(shapes))]
+        ops.colsum_flush([(p, p.shape[0], p.shape[1], o, a) for p, o, a in zip(parts, outs, acc)])
+        for p, o, o0, a in zip(parts, outs, old, acc):
+            ref = p.double().sum(0) + (o0.double() if a else 0.0)
+            assert _relerr(o, ref.float()) < 4e-3, (p.shape, _relerr(o, ref.float()))
+        outs2 = [o0.clone() for o0 in old]
+        ops.colsum_flush([(p, p.shape[0], p.shape[1], o, a) for p, o, a in zip(parts, outs2, acc)])
+        for o, o2 in zip(outs, outs2):
+            assert torch.equal(o, o2)
+
+
 @pytest.mark.parametrize("sched", [102, 103, 105])
 def test_gemm_kmajor_layouts_all_schedules(ops, sched):
     """The any-layout kernel (gemm3.hip) in each of its schedules - 128x128 two-stage, 128x128 loader ring, 256x128 loader ring -

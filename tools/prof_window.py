@@ -1,5 +1,5 @@
 """Steady-state window of a rocprofv3 CSV of bench.py: the rows between the last two optimiser steps (the big adamw_kernel
-launch ends every accumulation cycle) and the number of micro-batches in it (one embed_splice_fwd_kernel per micro-batch).
+launch ends every accumulation cycle) and the number of micro-batches in it (one embed_splice_fwd_kernel per forward pass x micro-batches per merged pass).
 Everything before it - warm-up, the GEMM autotuner's trial launches - is left out."""
 import csv
 
@@ -23,7 +23,9 @@ def load_window(path):
         if n >= best:
             best, t_lo, t_hi = n, a, b
     win = [r for r in rows if t_lo <= int(r["Start_Timestamp"]) and int(r["End_Timestamp"]) <= t_hi]
-    nmicro = max(1, sum(1 for r in win if "embed_splice_fwd_kernel" in r["Kernel_Name"]) // ncnt)
+    # one embed_splice_fwd_kernel per forward pass; a pass is VQ3_PROF_MERGE micro-batches when the trainer merges them (default 8)
+    import os
+    nmicro = max(1, sum(1 for r in win if "embed_splice_fwd_kernel" in r["Kernel_Name"]) // ncnt) * int(os.environ.get("VQ3_PROF_MERGE", "8"))
     wall_ms = (t_hi - t_lo) / 1e6
     return win, nmicro, wall_ms
 

@@ -1,5 +1,8 @@
 // RMSNorm (fwd/bwd) and LayerNorm (fwd) for gfx950. HBM-bound row kernels: one 64-lane wave per row,
 // 16-byte vector loads, wave shuffles for the row reductions (no LDS on the forward path).
+#include <map>
+#include <mutex>
+
 #include "common.h"
 #include "vq3_hip.h"
 
@@ -159,22 +162,33 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 
 // Several column sums in ONE launch (blockIdx.y = job): a decoder layer's backward leaves four partial slabs (two RMSNorm
 // weights, q_norm, k_norm) - four 6 us launches and their boundaries become one.
+// With merged micro-batches the slabs are tall (9600 partial rows of 128 columns from the q/k-prep backward: two workgroups walking
+// 600 iterations each took 84 us): the rows are split over gridDim.z workgroups; each leaves its partial sums in a scratch slab
+// (sc1 stores, drained before the ticket) and the last one to arrive adds them in split order - deterministic, one launch.
+constexpr int CS_MAX_SPLIT = 32, CS_MAX_COLS = 4096;
 struct ColsumJobs {
   const float* part[8];
   bf16_t* out[8];
   int nrows[8], cols[8], accumulate[8];
+  float* scratch;     // [8 jobs][CS_MAX_SPLIT][CS_MAX_COLS] (gridDim.z > 1)
+  int* tickets;       // [8 jobs][CS_MAX_COLS / 64], zero between launches
 };
 __global__ __launch_bounds__(1024) void colsum_multi_kernel(ColsumJobs jobs) {
   __shared__ float red[16][64];
+  __shared__ int ticket_s;
   const int job = blockIdx.y;
   const float* __restrict__ part = jobs.part[job];
-  const int nrows = jobs.nrows[job], cols = jobs.cols[job];
+  const int cols = jobs.cols[job];
   if ((int)blockIdx.x * 64 >= cols) return;
+  const int nsplit = gridDim.z, sp = blockIdx.z;
+  const int chunk = ((jobs.nrows[job] + nsplit - 1) / nsplit + 15) / 16 * 16;
+  const int r0 = sp * chunk;
+  const int nrows = jobs.nrows[job] < r0 + chunk ? jobs.nrows[job] : r0 + chunk;       // this workgroup walks rows r0 .. nrows - 1
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < cols) {
-    int r = rg;
+    int r = r0 + rg;
     for (; r + 48 < nrows; r += 64) {
       a0 += part[(long)r * cols + c];
       a1 += part[(long)(r + 16) * cols + c];
@@ -185,10 +199,29 @@ __global__ __launch_bounds__(1024) void colsum_multi_kernel(ColsumJobs jobs) {
   }
   red[rg][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (rg == 0 && c < cols) {
-    float v = 0.f;
+  float v = 0.f;
+  if (rg == 0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) v += red[i][lane];
+  }
+  if (nsplit > 1) {
+    float* sc = jobs.scratch + ((long)job * CS_MAX_SPLIT) * CS_MAX_COLS;
+    if (rg == 0 && c < cols) __hip_atomic_store(sc + (long)sp * CS_MAX_COLS + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int* tk = jobs.tickets + job * (CS_MAX_COLS / 64) + blockIdx.x;
+      const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == nsplit - 1) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket_s = t;
+    }
+    __syncthreads();
+    if (ticket_s != nsplit - 1) return;
+    v = 0.f;
+    if (rg == 0 && c < cols)
+      for (int s2 = 0; s2 < nsplit; ++s2) v += __hip_atomic_load(sc + (long)s2 * CS_MAX_COLS + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (rg == 0 && c < cols) {
     bf16_t* out = jobs.out[job];
     if (jobs.accumulate[job]) v += bf2f(out[c]);
     out[c] = f2bf(v);
@@ -388,17 +421,45 @@ extern "C" int vq3_layernorm_fwd(const void* x, const void* res, int32_t x_f32, 
   return 0;
 }
 
+namespace {
+struct CsWs { float* scratch = nullptr; int* tickets = nullptr; };
+std::mutex g_cs_mutex;
+std::map<hipStream_t, CsWs> g_cs;     // one scratch per stream: launches of a stream run in order
+bool colsum_scratch(hipStream_t s, float** scratch, int** tickets) {
+  std::lock_guard<std::mutex> lock(g_cs_mutex);
+  CsWs& w = g_cs[s];
+  if (!w.scratch) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+    const size_t nt = 8 * (CS_MAX_COLS / 64);
+    if (hipMalloc(&w.scratch, (size_t)8 * CS_MAX_SPLIT * CS_MAX_COLS * sizeof(float)) != hipSuccess ||
+        hipMalloc(&w.tickets, nt * sizeof(int)) != hipSuccess || hipMemset(w.tickets, 0, nt * sizeof(int)) != hipSuccess) {
+      (void)hipGetLastError();
+      w.scratch = nullptr;
+      return false;
+    }
+  }
+  *scratch = w.scratch; *tickets = w.tickets;
+  return true;
+}
+}  // namespace
+
 extern "C" int vq3_colsum_multi(const vq3_colsum_job* jobs, int32_t njobs, void* stream) {
   VQ3_CHECK_ARG(jobs && njobs >= 1 && njobs <= 8, "colsum_multi: 1..8 jobs");
   ColsumJobs j;
-  int maxcols = 0;
+  int maxcols = 0, maxrows = 0;
   for (int i = 0; i < njobs; ++i) {
     VQ3_CHECK_ARG(jobs[i].part && jobs[i].out_bf16 && jobs[i].nrows > 0 && jobs[i].cols > 0, "colsum_multi: bad job %d", i);
     j.part[i] = jobs[i].part; j.out[i] = (bf16_t*)jobs[i].out_bf16;
     j.nrows[i] = jobs[i].nrows; j.cols[i] = jobs[i].cols; j.accumulate[i] = jobs[i].accumulate;
     maxcols = jobs[i].cols > maxcols ? jobs[i].cols : maxcols;
+    maxrows = jobs[i].nrows > maxrows ? jobs[i].nrows : maxrows;
   }
-  hipLaunchKernelGGL(colsum_multi_kernel, dim3((maxcols + 63) / 64, njobs), dim3(1024), 0, (hipStream_t)stream, j);
+  int nsplit = maxrows / 512;                            // ~512 partial rows per workgroup
+  nsplit = nsplit < 1 ? 1 : (nsplit > CS_MAX_SPLIT ? CS_MAX_SPLIT : nsplit);
+  j.scratch = nullptr; j.tickets = nullptr;
+  if (nsplit > 1 && (maxcols > CS_MAX_COLS || !colsum_scratch((hipStream_t)stream, &j.scratch, &j.tickets))) nsplit = 1;
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3((maxcols + 63) / 64, njobs, nsplit), dim3(1024), 0, (hipStream_t)stream, j);
   VQ3_CHECK_LAUNCH("colsum_multi");
   return 0;
 }
