@@ -10,8 +10,10 @@ One step = one micro-batch of B=6 synthetic samples per GPU through the whole ho
 RCCL, fused AdamW with fp32 master weights, refresh of the transposed weight copies. The timed window is whole
 accumulation cycles: grad_accum defaults to min(32, --steps) (the reference's stage-1 schedule is 32), so every
 window contains exactly steps/grad_accum optimiser steps + all-reduces and never zero; --grad-accum 1 puts them in
-every step. Weights are random-init at the exact Qwen3-4B / VGGT-1B / Perceiver shapes, inputs synthetic and
-already resident in HBM. Prints one JSON line on rank 0.
+every step. The trainer runs 8 consecutive micro-batches of a window as ONE forward/backward pass over their 48 samples
+(each micro-batch's loss normalised by its own labelled rows - the reference's arithmetic; tests/test_trainer_gpu.py), so a
+window of 32 steps is 4 passes; steps and ms_per_step still count micro-batches. Weights are random-init at the exact
+Qwen3-4B / VGGT-1B / Perceiver shapes, inputs synthetic and already resident in HBM. Prints one JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -397,9 +399,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8-e4m3 fwd / bf16 bwd" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": ("Stage-1 ScanQA bf16: VGGT-1B aggregator @%dpx x %d view(s) + 128-latent/6-layer "
                                     "Perceiver + Qwen3-4B fwd+bwd + RCCL all-reduce + AdamW(fp32 master); random-init "
-                                    "weights" % (args.image_size, V)),
+                                    "weights; a step = one micro-batch of %d samples, run %d micro-batches per forward/backward pass "
+                                    "with each micro-batch's loss normalised by its own labelled rows" % (args.image_size, V, B, trainer.text_group)),
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": L, "views": V,
-                       "grad_accum": accum, "optimizer_steps_timed": len(cycles), "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
+                       "grad_accum": accum, "optimizer_steps_timed": len(cycles), "micro_batches_per_pass": int(trainer.text_group),
+                       "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
                        "trim_padding": bool(args.trim_pad), "fp8_text_forward": bool(args.fp8), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),
             # utilisation counts EXECUTED FLOPs: the lm_head + CE run on the labelled rows only (same loss and gradients);
