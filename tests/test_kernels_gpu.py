@@ -86,7 +86,12 @@ def test_gemm_forced_configs_with_epilogues(ops, cfg):
     edges inside a tile, an odd number of K tiles, strided C and batches: all must agree with the automatic choice's contract."""
     try:
         ops.gemm_force_config(cfg)
-        for (M, N, K) in ((300, 520, 192), (1029, 1024, 1024), (257, 264, 64)):
+        shapes = ((300, 520, 192), (1029, 1024, 1024), (257, 264, 64))
+        if cfg in (21, 22):
+            # more tiles than CUs: the two-phase kernels are persistent (a workgroup walks several tiles and requests the next tile's
+            # first K tiles during the current epilogue) - 65 x 8 / 129 x 4 tiles, ragged last row tile, 1 / 3 / 4 K tiles per tile
+            shapes += ((16500, 1024, 256), (16500, 1000, 64), (33000, 520, 192))
+        for (M, N, K) in shapes:
             A = _rand((M, K), 0.5, seed=3); W = _rand((N, K), 0.5, seed=4)
             bias = _rand((N,), 1.0, F32, seed=5); cs = _rand((N,), 1.0, F32, seed=6)
             R16 = _rand((M, N), 1.0, seed=7)
@@ -162,7 +167,7 @@ def test_gemm_layernorm_fold(ops, cfg):
     configuration; M with a ragged last tile; GELU on the consumer; statistics also from vq3_rowstats128 and bit-identical twice."""
     try:
         ops.gemm_force_config(cfg)
-        M, C, N2 = (16500 if cfg == 30 else 1029), 1024, 512
+        M, C, N2 = (16500 if cfg in (30, 21, 22) else 1029), 1024, (1024 if cfg in (21, 22) else 512)
         eps = 1e-5
         h = _rand((M, 256), 0.5, seed=1); Wp = _rand((C, 256), 0.3, seed=2)
         R = _rand((M, C), 1.0, seed=3) + 0.7                      # non-zero row means

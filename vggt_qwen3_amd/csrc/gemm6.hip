@@ -41,8 +41,18 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
-  int m0, n0;
-  tile_coords(p, BM, BN, m0, n0);
+  // The two-phase variants are PERSISTENT: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x = #CUs, a multiple of 8, so
+  // it stays on its XCD's slice of the tile order) and requests the next tile's first two K tiles BEFORE it runs the current
+  // tile's epilogue: the C image lives above the two buffers they land in (160 KiB of LDS), so at K = 1024 - 16 K steps per tile,
+  // the VGGT blocks - a tile no longer starts with an empty pipeline (the round trip was 2-3 us of a 21-26 us tile).
+  constexpr bool PERSIST = (AH + BH) < 4;
+  char* const smem_c = PERSIST ? smem + 2 * BUF : smem;       // C image / epilogue scratch
+  const int ntile = p.mtiles * p.ntiles;
+  int m0 = 0, n0 = 0;
+  // folded LayerNorm: the two-phase variants (199 VGPRs) fetch row r's statistics at the tile's start, thread r < BM - two registers
+  // through the main loop; the 256 x 256 kernel has none to spare (spills, 3 % on every launch) and fetches them inside the epilogue
+  constexpr bool LN_EARLY = (AH + BH) < 4;
+  float ln_mu = 0.f, ln_rs = 0.f;
   const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z % p.nb2;
   const bf16_t* A = p.A + b1 * p.sA1 + b2 * p.sA2;
   const bf16_t* B = p.B + b1 * p.sB1 + (long)(b2 / p.b2divB) * p.sB2;
@@ -54,20 +64,22 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   const int prow = lane >> 3;
   const int kch = (lane & 7) ^ prow;
   unsigned offA[AH][2], offB[BH][2];     // byte offsets from A / B, [half][piece]
+  auto set_offsets = [&](int tm0, int tn0) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (wid + 8 * j) * 8 + prow;
+    for (int j = 0; j < 2; ++j) {
+      const int r = (wid + 8 * j) * 8 + prow;
 #pragma unroll
-    for (int h = 0; h < AH; ++h) {
-      int ra = m0 + h * 128 + r; ra = ra < p.M ? ra : p.M - 1;
-      offA[h][j] = (unsigned)(((long)ra * p.lda + kch * 8) * 2);
+      for (int h = 0; h < AH; ++h) {
+        int ra = tm0 + h * 128 + r; ra = ra < p.M ? ra : p.M - 1;
+        offA[h][j] = (unsigned)(((long)ra * p.lda + kch * 8) * 2);
+      }
+#pragma unroll
+      for (int h = 0; h < BH; ++h) {
+        int rb = tn0 + h * 128 + r; rb = rb < p.N ? rb : p.N - 1;
+        offB[h][j] = (unsigned)(((long)rb * p.ldb + kch * 8) * 2);
+      }
     }
-#pragma unroll
-    for (int h = 0; h < BH; ++h) {
-      int rb = n0 + h * 128 + r; rb = rb < p.N ? rb : p.N - 1;
-      offB[h][j] = (unsigned)(((long)rb * p.ldb + kch * 8) * 2);
-    }
-  }
+  };
   auto stage = [&](const bf16_t* base, const unsigned (&off)[2], int tile, char* slot) {
     const char* g = reinterpret_cast<const char*>(base) + (long)tile * (BK6 * 2);
 #pragma unroll
@@ -77,10 +89,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   };
 
   f32x4 acc[AH * 4][BH * 2];
-#pragma unroll
-  for (int i = 0; i < AH * 4; ++i)
-#pragma unroll
-    for (int j = 0; j < BH * 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
   const int a_base = (wr * 64 + fr) * 128 + ((fq ^ (fr & 7)) << 4);
@@ -126,7 +134,30 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   } while (0)
 
   const int nt = p.K / BK6;
+  // two-phase variants keep THREE K-tile buffers (3 x 48 KiB): tile t+2 is staged whole while tile t is multiplied, into the
+  // buffer tile t-1 left a full tile ago. Slots: A0 A1 B (256 x 128) or A B0 B1 (128 x 256).
+  auto stage_tile = [&](int t, char* buf) {
+    if constexpr (AH == 2 && BH == 1) {
+      stage(A, offA[0], t, buf + 0 * HALF);
+      stage(B, offB[0], t, buf + 2 * HALF);
+      stage(A, offA[1], t, buf + 1 * HALF);
+    } else if constexpr (AH == 1 && BH == 2) {
+      stage(A, offA[0], t, buf + 0 * HALF);
+      stage(B, offB[0], t, buf + 1 * HALF);
+      stage(B, offB[1], t, buf + 2 * HALF);
+    }
+  };
+  bool prefetched = false;         // this tile's first K tiles were requested during the previous tile's epilogue (and have landed)
+  int tile = blockIdx.x;           // (< ntile: the grid never exceeds the tile count)
+  do {                             // one pass for the 256 x 256 kernel (PERSIST is a compile-time false there: no loop is generated)
+  tile_coords_id(p, tile, BM, BN, m0, n0);
+  if (LN_EARLY && p.ln_in && tid < BM) ln_row(p, m0 + tid, ln_mu, ln_rs);
+#pragma unroll
+  for (int i = 0; i < AH * 4; ++i)
+#pragma unroll
+    for (int j = 0; j < BH * 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // ---- prologue: all of tile 0, then the half-tiles of tile 1 that the steady state stages ahead of a tile's last phase
+  if (!prefetched) set_offsets(m0, n0);
   if constexpr (AH == 2 && BH == 2) {
     stage(A, offA[0], 0, smem + 0 * HALF);
     stage(B, offB[0], 0, smem + 2 * HALF);
@@ -140,20 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  } else {
-    // two-phase variants keep THREE K-tile buffers (3 x 48 KiB): tile t+2 is staged whole while tile t is multiplied, into the
-    // buffer tile t-1 left a full tile ago. Slots: A0 A1 B (256 x 128) or A B0 B1 (128 x 256).
-    auto stage_tile = [&](int t, char* buf) {
-      if constexpr (AH == 2) {
-        stage(A, offA[0], t, buf + 0 * HALF);
-        stage(B, offB[0], t, buf + 2 * HALF);
-        stage(A, offA[1], t, buf + 1 * HALF);
-      } else {
-        stage(A, offA[0], t, buf + 0 * HALF);
-        stage(B, offB[0], t, buf + 1 * HALF);
-        stage(B, offB[1], t, buf + 2 * HALF);
-      }
-    };
+  } else if (!prefetched) {
     stage_tile(0, smem);
     if (nt > 1) {
       stage_tile(1, smem + BUF);
@@ -266,6 +284,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   }
 
   // ---- epilogue
+  const int next_tile = tile + (int)gridDim.x;
+  const bool more = PERSIST && next_tile < ntile;
   if (!OUT_F32 && staged_ok(p, coff, roff)) {
     // through LDS (the operand buffers are dead: every wave passed the last phase's barrier), out as whole rows
     if (p.ln_in) {      // folded LayerNorm: rstd (acc - mu c) per lane-owned row, before the usual epilogue
@@ -273,9 +293,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       // the kernel's start, and a row's (mu, rstd) pair is applied as it is read back - only the four colsum quads stay live.
       __syncthreads();                                       // operand buffers are dead for every wave
       if (tid < BM) {
-        float mu_t, rs_t;
-        ln_row(p, m0 + tid, mu_t, rs_t);
-        reinterpret_cast<float2*>(smem)[tid] = float2{mu_t, rs_t};
+        float mu_t = ln_mu, rs_t = ln_rs;
+        if (!LN_EARLY) ln_row(p, m0 + tid, mu_t, rs_t);
+        reinterpret_cast<float2*>(smem_c)[tid] = float2{mu_t, rs_t};
       }
       f32x4 cc[BH * 2];
 #pragma unroll
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       for (int i = 0; i < AH; ++i)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          const float2 v = reinterpret_cast<const float2*>(smem)[i * 128 + wr * 64 + mt * 16 + fr];
+          const float2 v = reinterpret_cast<const float2*>(smem_c)[i * 128 + wr * 64 + mt * 16 + fr];
 #pragma unroll
           for (int q = 0; q < BH * 2; ++q) acc[i * 4 + mt][q] = ln_apply(acc[i * 4 + mt][q], v.x, v.y, cc[q]);
         }
@@ -304,6 +324,17 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
         if (p.bias) bias_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.colscale) cs_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.colscale + n);
       }
+    if (more) {
+      // the next tile's first two K tiles: requested AFTER this epilogue's own operands (vmcnt counts in order: a wait for a younger
+      // load would also wait for these), into the two buffers below the C image
+      __builtin_amdgcn_sched_barrier(0);
+      int nm0, nn0;
+      tile_coords_id(p, next_tile, BM, BN, nm0, nn0);
+      set_offsets(nm0, nn0);
+      stage_tile(0, smem);
+      if (nt > 1) stage_tile(1, smem + BUF);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < AH; ++i)
 #pragma unroll
@@ -312,32 +343,47 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
         for (int j = 0; j < BH; ++j)
 #pragma unroll
           for (int nt2 = 0; nt2 < 2; ++nt2)
-            stage_quad<BN>(p, smem, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq,
+            stage_quad<BN>(p, smem_c, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq,
                            acc[i * 4 + mt][j * 2 + nt2], bias_r[j][nt2], cs_r[j][nt2]);
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's K tiles 0 and 1 has landed
     __syncthreads();
-    staged_store<BM, BN>(p, smem, coff, roff, m0, n0, tid, 512);
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < AH; ++i)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + i * 128 + wr * 64 + mt * 16 + fr;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < BH; ++j)
-#pragma unroll
-        for (int nt2 = 0; nt2 < 2; ++nt2) {
-          const int n = n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq;
-          if (n >= p.N) continue;
-          store_quad<OUT_F32>(p, coff, roff, m, n, acc[i * 4 + mt][j * 2 + nt2]);
-        }
+    staged_store<BM, BN>(p, smem_c, coff, roff, m0, n0, tid, 512);
+  } else {
+    if (more) {
+      int nm0, nn0;
+      tile_coords_id(p, next_tile, BM, BN, nm0, nn0);
+      set_offsets(nm0, nn0);
+      stage_tile(0, smem);
+      if (nt > 1) stage_tile(1, smem + BUF);
     }
+#pragma unroll
+    for (int i = 0; i < AH; ++i)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + i * 128 + wr * 64 + mt * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < BH; ++j)
+#pragma unroll
+          for (int nt2 = 0; nt2 < 2; ++nt2) {
+            const int n = n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq;
+            if (n >= p.N) continue;
+            store_quad<OUT_F32>(p, coff, roff, m, n, acc[i * 4 + mt][j * 2 + nt2]);
+          }
+      }
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  prefetched = more;
+  if (more) __syncthreads();      // everybody's DMA pieces are visible; the C image's readers are done before K tile 2 lands on it
+  tile = next_tile;
+  } while (PERSIST && tile < ntile);
 }
 
 template <int AH, int BH>
 int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
-  constexpr int SMEM = (AH + BH == 4 ? 2 : 3) * (AH + BH) * HALF;
+  // (two-phase variants: two K-tile buffers of the NEXT tile + the C image of the current one, or three K-tile buffers: 160 KiB)
+  constexpr int SMEM = (AH + BH == 4) ? 2 * 4 * HALF : 2 * 3 * HALF + 128 * AH * 128 * BH * 2;
+  static_assert(SMEM <= 160 * 1024 && (AH + BH == 4 || SMEM >= 3 * (AH + BH) * HALF), "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -351,7 +397,17 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
   p.mtiles = (p.M + 128 * AH - 1) / (128 * AH);
   p.ntiles = (p.N + 128 * BH - 1) / (128 * BH);
   p.xm = choose_xm(p.mtiles, p.ntiles);
-  dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    (void)hipGetLastError();
+    ncu = n / 8 * 8;                 // persistent workgroups stride over the tile order by a multiple of 8: they stay on their XCD's slice
+  }
+  int nwg = p.mtiles * p.ntiles;
+  if (AH + BH < 4 && nwg > ncu && getenv("VQ3_V6_PERSIST") == nullptr) nwg = ncu;      // (VQ3_V6_PERSIST=0: one tile per workgroup, for A/B runs)
+  else if (AH + BH < 4 && nwg > ncu && atoi(getenv("VQ3_V6_PERSIST")) != 0) nwg = ncu;
+  dim3 grid(nwg, 1, nbatch);
   if (p.out_f32)
     hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, true>), grid, dim3(512), SMEM, stream, p);
   else
