@@ -326,7 +326,9 @@ class Qwen3ForCausalLM(nn.Module):
                 self._fp8[name] = ops.quant_fp8_rows(w)
 
     # ------------------------------------------------------------------ W^T copies for the dgrad GEMMs
-    DGRAD_NT = ("qkv", "o", "gu")   # measured cold: NT beats the k-major form by 10-18 % on these, loses on down_proj
+    # measured cold at 1200 rows: NT beats the k-major form by 10-18 % on q|k|v, o, gate|up and loses on down_proj; at the 9600 rows
+    # of a merged pass the SwiGLU-fused down_proj dgrad runs at 0.77 PF/s k-major against > 1 PF/s NT, so it gets its copy too
+    DGRAD_NT = tuple(os.environ.get("VQ3_DGRAD_NT_SET", "qkv,o,gu,down").split(","))
 
     def enable_dgrad_transposes(self, on: bool = True) -> None:
         """dX = dY . W reads W k-major (as stored) through transposed LDS reads - 10-18 % slower than the NT form on the
