@@ -268,7 +268,7 @@ def test_perceiver_layer_full_width_vs_oracle():
 
 
 def test_dgrad_transposed_copies_match_kmajor_path():
-    """With W^T copies (Stage1Trainer enables them when grad_accum >= 4) the three dgrad GEMMs run in NT form: same
+    """With W^T copies (Stage1Trainer enables them when grad_accum >= 4) the four dgrad GEMMs run in NT form: same
     gradients as the k-major path to bf16 rounding, and the copies follow every weight update."""
     from vggt_qwen3_amd.trainer import Stage1Trainer
     z = load("vlm_tiny.npz")
@@ -291,7 +291,7 @@ def test_dgrad_transposed_copies_match_kmajor_path():
     model = _build_vlm(z, m).train()
     tr = Stage1Trainer(model, lr=1e-3, proj_lr=1e-3, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=4)
     tm = model.text_model
-    assert tm._wt is not None and set(k.split(".")[1] for k in tm._wt) == {"qkv", "o", "gu"}
+    assert tm._wt is not None and set(k.split(".")[1] for k in tm._wt) == {"qkv", "o", "gu", "down"}
     for _ in range(4):
         tr.micro_step(batch)
     assert tr.opt_step == 1
