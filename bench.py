@@ -308,6 +308,24 @@ def main():
                         "note": "eval mode, no_grad, dense L (no padding trimmed); MFMA fraction counts executed FLOPs only "
                                 "(lm_head on the %.1f labelled rows per sample)" % head_rows}
 
+        # the same forward over 8 micro-batches at once (48 samples): what the tower / text GEMMs reach when the batch is not the limit
+        if trainer.text_group > 1:
+            big, _sizes = trainer._merge([batch] * trainer.text_group)
+            nb = trainer.text_group
+
+            def fwd_big():
+                with torch.no_grad():
+                    return model(images=big["pixel_values"], geom_token=big.get("geom_token"), input_ids=big["input_ids"],
+                                 attention_mask=big["attention_mask"], labels=big["labels"])
+            model.eval()
+            fwd_big()
+            dtb, _ = timed(fwd_big, 4)
+            model.train()
+            forward_only["batched_%d_micro_batches" % nb] = {
+                "forward_samples_per_s": round(nb * B / dtb, 2), "ms_per_forward": round(dtb * 1e3, 2),
+                "forward_mfma_frac": round(nb * B / dtb * tf_exec_fwd / BF16_DENSE_PEAK_TFLOPS, 4),
+                "note": "one forward over %d samples (%d micro-batches concatenated), eval mode, no_grad" % (nb * B, nb)}
+
         # ---- configs C4 (8 views + geometry tokens) and C5 (C4 with the e4m3 forward) on this one GPU, same B and L
         if not args.geom and V == 1:
             b8 = synthetic_batch(B, 8, L, args.image_size, 151936, model.image_id, 151643, 198, 4321, dev, True)
