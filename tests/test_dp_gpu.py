@@ -49,7 +49,7 @@ def _batches(z, rank):
     return out
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, merge=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
@@ -60,6 +60,9 @@ def _worker(rank, world, port, outdir):
         from vggt_qwen3_amd.trainer import Stage1Trainer
         z = load("vlm_tiny.npz")
         model = _build_vlm(z, meta(z)).train()
+        if merge:
+            from tests.test_trainer_gpu import _Tower
+            model.vision_model = _Tower(model.vision_model.agg)          # a tower that follows its input's batch axis
         tr = Stage1Trainer(model, grad_accum=2, **KW)
         assert tr.dist_on and tr.world == 2 and len(tr.buckets) == model.text_model.config.num_hidden_layers
         fired, spans = [], []
@@ -67,8 +70,10 @@ def _worker(rank, world, port, outdir):
         tr._layer_done = lambda i: (fired.append((tr.micro, i)), orig_done(i))[1]
         dp.allreduce_tensor = lambda t, group=None: (spans.append((tr.micro, t.numel())), orig_ar(t, group=group))[1]
         losses = []
-        for b in _batches(z, rank):
-            losses.append(float(tr.micro_step(b).item()))
+        bs = _batches(z, rank)
+        for i, b in enumerate(bs):
+            # merge: the two micro-batches of a window run as one pass (micro_step(upcoming=...)); the hooks then fire in that pass
+            losses.append(float(tr.micro_step(b, upcoming=bs[i + 1:] if merge else None).item()))
         torch.cuda.synchronize()
         torch.save({"master": tr.master.cpu(), "geom_master": tr.geom_master.cpu(), "flat_w": model.text_model.flat_w.cpu(),
                     "fired": fired, "spans": spans, "losses": losses, "opt_step": tr.opt_step,
@@ -77,9 +82,10 @@ def _worker(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-def test_stage1_trainer_two_ranks_equal_single_rank(tmp_path):
+@pytest.mark.parametrize("merge", [False, True])
+def test_stage1_trainer_two_ranks_equal_single_rank(tmp_path, merge):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), merge), nprocs=world, join=True)
     r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=False) for i in range(world)]
     # identical replicas after two optimiser steps
     assert r[0]["opt_step"] == r[1]["opt_step"] == 2
@@ -88,9 +94,11 @@ def test_stage1_trainer_two_ranks_equal_single_rank(tmp_path):
     for i in range(world):
         nb = r[i]["nbuckets"]
         # hooks: only on the boundary micro-batches (micro index 1 and 3), once per layer each (bucket_layers = 1)
-        assert sorted(r[i]["fired"]) == sorted([(m, l) for m in (1, 3) for l in range(nb)]), (i, r[i]["fired"])
+        # (merged: the pass that starts at micro index 0 / 2 contains the boundary micro-batch)
+        bm = (0, 2) if merge else (1, 3)
+        assert sorted(r[i]["fired"]) == sorted([(m, l) for m in bm for l in range(nb)]), (i, r[i]["fired"])
         # collectives per optimiser step: one per layer bucket + embedding + geom_head (+count slot), same on both ranks
-        per_step = [s for s in r[i]["spans"] if s[0] == 1]
+        per_step = [s for s in r[i]["spans"] if s[0] == bm[0]]
         assert len(per_step) == nb + 2 and any(n == r[i]["geom_n"] for _, n in per_step), per_step
     assert [s[1] for s in r[0]["spans"]] == [s[1] for s in r[1]["spans"]]
     assert np.isnan(r[1]["losses"][1]) and np.isnan(r[0]["losses"][2]) and np.isfinite(r[0]["losses"][0])
@@ -100,6 +108,9 @@ def test_stage1_trainer_two_ranks_equal_single_rank(tmp_path):
     from vggt_qwen3_amd.trainer import Stage1Trainer
     z = load("vlm_tiny.npz")
     model = _build_vlm(z, meta(z)).train()
+    if merge:
+        from tests.test_trainer_gpu import _Tower
+        model.vision_model = _Tower(model.vision_model.agg)
     tr = Stage1Trainer(model, grad_accum=4, **KW)
     w0, g0 = tr.master.clone(), tr.geom_master.clone()
     b0, b1 = _batches(z, 0), _batches(z, 1)
