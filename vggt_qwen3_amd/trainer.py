@@ -146,9 +146,11 @@ class Stage1Trainer:
         """forward + backward (+ gradient all-reduce, AdamW, schedule on accumulation boundaries). Returns the loss.
         next_batch (optional): its frozen vision-tower forward is enqueued on a second stream now, overlapping this
         micro-batch's text forward/backward; pass the same dict to the next call.
-        upcoming (optional): the batches of the following micro-steps, in order. When this batch's images have no aggregator result
-        waiting, the tower runs once over this batch + the first vision_group - 1 of them; they must then be passed to the next
-        micro_step() calls as the very same dicts / tensors."""
+        upcoming (optional): the batches of the following micro-steps, in order. With text_group > 1 this call then runs ONE
+        forward/backward over this batch + the next text_group - 1 of them that still belong to the current accumulation window
+        (every micro-batch's loss is the mean over its own labelled rows; the gradient is that of their sum) and the following
+        micro_step() calls - which must receive those very dicts, in order - only return their loss. With text_group == 1 the
+        frozen vision tower alone is shared: it runs once over this batch + the first vision_group - 1 upcoming ones."""
         model, tm = self.model, self.tm
         if self._merged_pending:            # this micro-batch already ran as part of a merged pass: hand its loss out
             expected, loss = self._merged_pending[0]
