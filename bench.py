@@ -157,7 +157,8 @@ def main():
     ap.add_argument("--no-trim-variant", action="store_true", help="skip the second timed window (exact padding shortcut)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra result objects (forward_only, c4_variant, c5_variant); they run at --gpus 1 only")
-    ap.add_argument("--variant-steps", type=int, default=4, help="timed steps of the 8-view C4 / C5 variant windows")
+    ap.add_argument("--variant-steps", type=int, default=8, help="timed steps of the 8-view C4 / C5 variant windows (one accumulation cycle "
+                                                                     "= one merged pass at the default text_group)")
     ap.add_argument("--layers", type=int, default=36, help="debug only; anything but 36 marks the line invalid")
     args = ap.parse_args()
 

@@ -555,7 +555,13 @@ extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, v
   static int qb_forced = -1;
   if (qb_forced < 0) { const char* e = getenv("VQ3_FLASH_QB"); qb_forced = e ? atoi(e) : 0; }
   // two query blocks per wave (every K / V fragment read feeds two MFMA chains) once there are enough rows to fill them
-  const int qb = qb_forced ? qb_forced : (N >= 512 ? 2 : 1);
+  int qb = qb_forced ? qb_forced : (N >= 512 ? 2 : 1);
+  if (!qb_forced && qb == 2) {
+    // 512 workgroup slots (2 per CU at 2 query blocks per wave): a grid of 1 .. 2 rounds whose last round is mostly empty - one
+    // 8 232-token sample: 33 x 16 = 528 workgroups - runs better as 3-per-CU workgroups of half the rows (602 -> 670 TF/s)
+    const double r = (double)((N + 255) / 256) * G * NH / 512.0;
+    if (r > 1.0 && r < 2.0 && (double)(long)(r + 0.999999) - r > 0.4) qb = 1;
+  }
   dim3 grid((N + 128 * qb - 1) / (128 * qb), G * NH);
   if (qb == 2)
     hipLaunchKernelGGL(flash_attn_hd64_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
