@@ -427,7 +427,7 @@ def main():
             "loss": round(float(loss.item()), 4),
             # utilisation counts EXECUTED FLOPs: the lm_head + CE run on the labelled rows only (same loss and gradients);
             # the reference's figure (logits for all L positions) is kept beside it, never used for a utilisation number
-            "executed_tflop_per_sample": round(tf_exec_train, 3),
+            "executed_tflop_per_sample": round(tf_exec_train, 3), "peak_hbm_gb_torch_allocator": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             "reference_algorithmic_tflop_per_sample": round(tf_train, 3),
             "model_flops_utilisation": round(value * tf_exec_train / (world * BF16_DENSE_PEAK_TFLOPS), 4),
             "build_s": round(t_build, 1),
