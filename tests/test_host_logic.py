@@ -273,3 +273,57 @@ def test_scheduler_rule_matches_accelerated_scheduler(monkeypatch):
                 opt.step()
             sch.step()
         sch.gradient_state._set_sync_gradients(True)
+
+
+def test_hostplan_remembers_per_tensor_object_and_version():
+    """hostplan.PLAN: a host-side fact is reused only for the very same, unmodified tensor object."""
+    import gc
+    from vggt_qwen3_amd.hostplan import HostPlan
+    plan, calls = HostPlan(capacity=4), []
+
+    def fact(t):
+        return plan.get("nnz", (t,), lambda: (calls.append(1), int((t != 0).sum()))[1])
+
+    a = torch.tensor([1, 0, 2, 0])
+    assert fact(a) == 2 and fact(a) == 2 and len(calls) == 1          # second look is free
+    a[1] = 5                                                          # in-place write bumps _version: recomputed
+    assert fact(a) == 3 and len(calls) == 2
+    b = a.clone()                                                     # equal contents, another object: its own entry
+    assert fact(b) == 3 and len(calls) == 3
+    ida = id(a)
+    del a
+    gc.collect()
+    c = torch.tensor([0, 0, 0, 7])
+    assert fact(c) == 1                                               # (even if the allocator hands out the same id, the dead weakref misses)
+    for _ in range(10):                                               # capacity: the table is cleared, never grows without bound
+        fact(torch.zeros(3))
+    assert len(plan._d) <= 4
+    assert ida is not None
+
+
+def test_trainer_batch_merge_helpers():
+    """Stage1Trainer._mergeable / _merge on CPU tensors: what may share a pass, what the merged dict looks like, and the reuse of the
+    merged tensors for the same group of batch OBJECTS."""
+    from types import SimpleNamespace
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+
+    def mk(B, L=6, geom=True, views=1):
+        d = {"pixel_values": torch.rand(B, views, 3, 8, 8), "input_ids": torch.randint(0, 9, (B, L)),
+             "attention_mask": torch.ones(B, L, dtype=torch.long), "labels": torch.full((B, L), -100)}
+        if geom:
+            d["geom_token"] = {"R": torch.rand(B, views, 9), "t": torch.rand(B, views, 3)}
+        return d
+
+    a, b, c = mk(2), mk(3), mk(2)
+    assert Stage1Trainer._mergeable([a, b, c])                        # different sample counts are fine
+    assert not Stage1Trainer._mergeable([a, mk(2, L=7)])              # different padded length
+    assert not Stage1Trainer._mergeable([a, mk(2, views=2)])          # different view count
+    assert not Stage1Trainer._mergeable([a, mk(2, geom=False)])       # geometry tokens on one side only
+    holder = SimpleNamespace(_merge_cache=None)
+    merged, sizes = Stage1Trainer._merge(holder, [a, b, c])
+    assert sizes == [2, 3, 2] and merged["input_ids"].shape == (7, 6) and merged["pixel_values"].shape[0] == 7
+    assert torch.equal(merged["labels"][2:5], b["labels"]) and torch.equal(merged["geom_token"]["R"][5:], c["geom_token"]["R"])
+    again, _ = Stage1Trainer._merge(holder, [a, b, c])
+    assert again is merged                                            # same batch objects: same merged tensors (memoised host facts hit)
+    other, _ = Stage1Trainer._merge(holder, [a, c, b])
+    assert other is not merged and torch.equal(other["input_ids"][2:4], c["input_ids"])
