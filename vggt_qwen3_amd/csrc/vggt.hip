@@ -209,16 +209,20 @@ constexpr float FA_THR = 6.0f;
 __device__ __forceinline__ int fa_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int fa_vswz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
 
-template <int QB>
-__global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+// NT threads per workgroup: 256 (four waves, 128 * QB query rows) or 64 - ONE wave for the ragged last rows of a sequence whose
+// length is a multiple of 256 plus a few (1029 = 5 special tokens + 1024 patches): as a fifth four-wave block those 5 rows held a
+// workgroup slot (222 VGPRs x 4 waves, 32 KiB LDS) for a whole key loop in every (sample, head) pair; as a one-wave workgroup on a
+// second stream they run beside the 4 exact blocks. Query rows q_begin <= q < q_end are processed, keys 0 .. N - 1.
+template <int QB, int NT>
+__global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-                                                                 int N, int NH, long ldo, float scale_log2e) {
+                                                                 int N, int NH, long ldo, float scale_log2e, int q_begin, int q_end) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * FA_KV * 128];   // 2 stages x (K tile | V tile)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const long nb = blockIdx.y;
-  const int q0 = blockIdx.x * (128 * QB) + wid * (32 * QB);
+  const int q0 = q_begin + blockIdx.x * (NT / 2 * QB) + wid * (32 * QB);
   const bf16_t* Qb = Q + nb * (long)N * 64;
   const bf16_t* Kb = K + nb * (long)N * 64;
   const bf16_t* Vb = V + nb * (long)N * 64;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     int qr = q0 + 32 * qb + r;
-    qr = qr < N ? qr : N - 1;
+    qr = qr < q_end ? qr : q_end - 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bf16x8 raw = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 16 * s + 8 * h);
@@ -254,14 +258,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
     }
   }
 
-  // staging: 512 16-byte chunks per tile and operand, 2 per thread: row = tid >> 3 (+32), chunk = tid & 7
+  // staging: 512 16-byte chunks per tile and operand, NS = 512 / NT per thread: row = tid >> 3 (+ NT / 8 per step), chunk = tid & 7
+  constexpr int NS = 512 / NT, RSTEP = NT / 8;
   const int srow0 = tid >> 3, sch = tid & 7;
   const int nt = (N + FA_KV - 1) / FA_KV;
-  u32x4 kreg[2], vreg[2];
+  u32x4 kreg[NS], vreg[NS];
   auto load_tile = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int kr = t * FA_KV + srow0 + 32 * i;
+    for (int i = 0; i < NS; ++i) {
+      int kr = t * FA_KV + srow0 + RSTEP * i;
       kr = kr < N ? kr : N - 1;
       kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (long)kr * 64 + sch * 8);
       vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (long)kr * 64 + sch * 8);
@@ -271,8 +276,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
     char* Ks = smem + buf * (2 * FA_KV * 128);
     char* Vs = Ks + FA_KV * 128;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = srow0 + 32 * i;
+    for (int i = 0; i < NS; ++i) {
+      const int row = srow0 + RSTEP * i;
       *reinterpret_cast<u32x4*>(Ks + fa_swz(row, sch)) = kreg[i];
       *reinterpret_cast<u32x4*>(Vs + fa_vswz(row, sch)) = vreg[i];
     }
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
 
   // a wave whose 32 * QB query rows all lie past N (the ragged last block: N = 1029 leaves 5 rows for wave 0 and none for waves
   // 1-3) only helps to stage K / V: its SIMD's MFMA and VALU slots go to the other workgroup on the CU
-  const bool active = q0 < N;
+  const bool active = q0 < q_end;
   for (int t = 0; t < nt; ++t) {
     const bool more = t + 1 < nt;
     const char* sb = smem + (t & 1) * (2 * FA_KV * 128);
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_hd64_kernel(const bf16_t* _
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q0 + 32 * qb + r;
-    if (q < N) {
+    if (q < q_end) {
       const float inv = 1.f / l_run[qb];
       const long g = nb / NH;
       const int hd = (int)(nb % NH);
@@ -562,13 +567,41 @@ extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, v
     const double r = (double)((N + 255) / 256) * G * NH / 512.0;
     if (r > 1.0 && r < 2.0 && (double)(long)(r + 0.999999) - r > 0.4) qb = 1;
   }
-  dim3 grid((N + 128 * qb - 1) / (128 * qb), G * NH);
+  const float sl2 = scale * 1.44269504088896340736f;
+  int q_main = N;
+  // ragged tail of <= 32 rows past a multiple of 256 (and >= 512 (sample, head) pairs, so that the saved slots matter): the four-wave
+  // launch takes the exact blocks, a one-wave launch on a side stream (forked from / joined to `stream` by events) the tail
+  const int tail = N % 256;
+  static int tail_split = -1;
+  static hipStream_t side = nullptr;
+  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  if (tail_split < 0) { const char* e = getenv("VQ3_FLASH_TAIL"); tail_split = e ? atoi(e) : 1; }
+  // (measured: 48 x 16 pairs 409 -> 364 us; 6 x 16 pairs 51 -> 61 us - the one-wave launch is as long as the main one there)
+  if (tail_split && qb == 2 && tail > 0 && tail <= 32 && N > 256 && (long)G * NH >= (tail_split > 1 ? tail_split : 512)) {
+    if (!side) {
+      if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        side = nullptr;
+      }
+    }
+    if (side) {
+      q_main = N - tail;
+      (void)hipEventRecord(ev_fork, (hipStream_t)stream);
+      (void)hipStreamWaitEvent(side, ev_fork, 0);
+      hipLaunchKernelGGL((flash_attn_hd64_kernel<1, 64>), dim3(1, G * NH), dim3(64), 0, side, (const bf16_t*)Q, (const bf16_t*)K,
+                         (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N);
+      (void)hipEventRecord(ev_join, side);
+    }
+  }
+  dim3 grid((q_main + 128 * qb - 1) / (128 * qb), G * NH);
   if (qb == 2)
-    hipLaunchKernelGGL(flash_attn_hd64_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, scale * 1.44269504088896340736f);
+    hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main);
   else
-    hipLaunchKernelGGL(flash_attn_hd64_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, scale * 1.44269504088896340736f);
+    hipLaunchKernelGGL((flash_attn_hd64_kernel<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main);
+  if (q_main != N) (void)hipStreamWaitEvent((hipStream_t)stream, ev_join, 0);
   VQ3_CHECK_LAUNCH("flash_attn_fwd");
   return 0;
 }
