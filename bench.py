@@ -72,6 +72,39 @@ def synthetic_batch(B, V, L, img, vocab, image_id, pad_id, nl_id, seed, device, 
     return batch
 
 
+class BatchStream:
+    """What a DataLoader hands the trainer: a stream of DISTINCT micro-batches, each a dict of fresh tensor objects. A pool of
+    `npool` synthetic batches (seeds seed0 .. seed0 + npool - 1: different images, ids and label counts) is rotated; the integer
+    tensors of every draw are new objects (clones), so nothing memoised per tensor object (hostplan.PLAN: <image> positions,
+    labelled rows, live key tiles; Stage1Trainer._merge: the concatenated pass) can hit - each pass pays its device -> host
+    reads and its torch.cat, as a real data stream makes it. Inputs stay resident in HBM (the contract's timed region)."""
+
+    def __init__(self, npool, make):
+        self.pool = [make(i) for i in range(npool)]
+        self.queue = []
+        self.n = 0
+
+    def _draw(self):
+        b = self.pool[self.n % len(self.pool)]
+        self.n += 1
+        d = dict(b)
+        for k in ("input_ids", "attention_mask", "labels"):
+            d[k] = b[k].clone()
+        return d
+
+    def peek(self, n):
+        while len(self.queue) < n:
+            self.queue.append(self._draw())
+        return self.queue[:n]
+
+    def pop(self):
+        self.peek(1)
+        return self.queue.pop(0)
+
+    def drop(self):
+        self.queue = []
+
+
 def cpu_baseline(model, batch, L):
     """The CPU oracle (PyTorch-CPU restatement of the reference's path) timed on this host's cores on a bounded
     sample, extrapolated to one full training sample. Reported baseline only."""
@@ -136,8 +169,8 @@ def cpu_baseline(model, batch, L):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=2)   # rounded up to whole accumulation windows
     ap.add_argument("--grad-accum", type=int, default=0,
                     help="micro-batches per optimiser step; 0 = min(32, --steps): the timed window is one accumulation "
                          "cycle of the reference's stage-1 schedule (grad_accum 32) with exactly one all-reduce + AdamW")
@@ -204,12 +237,16 @@ def main():
     cycles = [accum] * (args.steps // accum) + ([args.steps % accum] if args.steps % accum else [])
     trainer = Stage1Trainer(model, grad_accum=accum, max_steps=30000)
     B, V, L = args.batch, args.views, args.seq_len
-    batch = synthetic_batch(B, V, L, args.image_size, 151936, model.image_id, 151643, 198, 1234 + rank, dev, args.geom)
+    # >= 2 x text_group distinct micro-batches per rank (seeds 1234 + 1000 * rank + i), rotated as a data stream
+    npool = max(2, 2 * trainer.text_group)
+    stream = BatchStream(npool, lambda i: synthetic_batch(B, V, L, args.image_size, 151936, model.image_id, 151643, 198,
+                                                          1234 + 1000 * rank + i, dev, args.geom))
+    batch = stream.pool[0]
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     # labelled rows per sample: the lm_head + CE run on these rows only (identical loss and gradients),
-    # so utilisation figures count 2*rows*H*V for the head, not the reference's 2*L*H*V
-    head_rows = float((batch["labels"][:, 1:] != -100).sum().item()) / B
+    # so utilisation figures count 2*rows*H*V for the head, not the reference's 2*L*H*V (mean over the pool's batches)
+    head_rows = sum(float((b["labels"][:, 1:] != -100).sum().item()) for b in stream.pool) / (B * npool)
 
     use_dist = world > 1 or force_dist
 
@@ -225,20 +262,30 @@ def main():
     # contraction length the window's flush pattern produces: the warm-up is rounded UP to whole windows of the timed schedule)
     nwarm = (max(args.warmup, 1) + accum - 1) // accum * accum
     trainer.grad_accum = accum
-    nxt = batch if args.vision_prefetch else None   # next micro-batch's (frozen) vision forward overlaps this one
-    vg = max(1, trainer.vision_group, trainer.text_group)
-    up = [batch] * (vg - 1)     # the following micro-batches (the same synthetic batch): one vision-tower pass per vg micro-batches
-    for i in range(nwarm):
-        loss = trainer.micro_step(batch, nxt, upcoming=up[: nwarm - 1 - i])
-    assert trainer.micro % accum == 0
-    trainer.micro = 0
+
+    def run_window(clen, src=None):
+        """One accumulation window of `clen` micro-batches drawn from the stream: forward/backward passes (merged per text_group),
+        the gradient all-reduce and the optimiser step. The look-ahead never crosses the window's end."""
+        src = stream if src is None else src
+        vg = max(1, trainer.vision_group, trainer.text_group)
+        trainer.grad_accum, trainer.micro = clen, 0
+        out = None
+        for i in range(clen):
+            b = src.pop()
+            ahead = src.peek(min(vg - 1, clen - 1 - i))
+            nxt = ahead[0] if (args.vision_prefetch and ahead) else None   # next micro-batch's (frozen) vision forward overlaps this one
+            out = trainer.micro_step(b, nxt, upcoming=ahead)
+        assert not trainer._merged_pending and not trainer._opt_due
+        return out
+
+    for _ in range(nwarm // accum):
+        loss = run_window(accum)
     sync()
     assert not model._vis_group, "no precomputed vision result may cross into the timed region"
+    stream.drop()
     t0 = time.perf_counter()
     for clen in cycles:
-        trainer.grad_accum, trainer.micro = clen, 0
-        for i in range(clen):
-            loss = trainer.micro_step(batch, nxt, upcoming=up[: clen - 1 - i])   # K vision forwards (in groups) + K text fwd/bwd in the window
+        loss = run_window(clen)       # K vision forwards (in groups) + K text fwd/bwd + len(cycles) all-reduces / AdamW steps in the window
     sync()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -254,15 +301,11 @@ def main():
     trimmed = None
     if not args.trim_pad and not args.no_trim_variant:
         model.trim_padding = True
-        trainer.grad_accum, trainer.micro = cycles[0], 0
-        for i in range(cycles[0]):
-            loss_t = trainer.micro_step(batch, nxt, upcoming=up[: cycles[0] - 1 - i])  # warm the trimmed shapes over one whole window
+        loss_t = run_window(cycles[0])        # warm the trimmed shapes over one whole window
         sync()
         t0 = time.perf_counter()
         for clen in cycles:
-            trainer.grad_accum, trainer.micro = clen, 0
-            for i in range(clen):
-                loss_t = trainer.micro_step(batch, nxt, upcoming=up[: clen - 1 - i])
+            loss_t = run_window(clen)
         sync()
         dtt = time.perf_counter() - t0
         if use_dist:
@@ -276,6 +319,70 @@ def main():
                        (flops_vggt(V, args.image_size) + flops_perceiver() + 3 * flops_qwen(L_eff, head_rows=head_rows)) / 1e12, 3),
                    "note": "exact: columns that are padding for every row of the batch are not computed; same loss and gradients"}
         model.trim_padding = False
+
+    def timed_windows(clens, warm):
+        """warm-up windows (new shapes meet the GEMM tuner there), then the timed ones; MAX over ranks."""
+        for c in warm:
+            run_window(c)
+        sync()
+        stream.drop()
+        t0 = time.perf_counter()
+        last = None
+        for c in clens:
+            last = run_window(c)
+        sync()
+        d = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([d], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d, last
+
+    def comm_summary(prof, nopt):
+        """HIP-event time of the gradient all-reduces (events on the communication stream) per optimiser step; bus bandwidth with the
+        ring factor 2 (N - 1) / N, as RCCL's own tests quote it."""
+        if not prof:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof) / nopt
+        by = sum(b for _, _, b in prof) / nopt
+        return {"allreduce_ms_per_opt_step": round(ms, 3), "allreduce_bytes_per_opt_step": int(by), "collectives_per_opt_step": round(len(prof) / nopt, 1),
+                "bus_gb_per_s": round(2.0 * (world - 1) / world * by / (ms * 1e-3) / 1e9, 1) if ms > 0 and world > 1 else None}
+
+    # ---- the same job under the schedules SURVEY 8(d) / the reference name: one micro-batch per forward/backward pass (what the
+    # reference's loop does, train_sft.py:208-220) and one optimiser step + gradient exchange per micro-batch (C3 "accum = 1").
+    # Reported beside `value`, never instead of it. Every rank runs them (the collectives stay matched).
+    sched_variants = {}
+    comm = None
+    if not args.no_variants and not args.trim_pad:
+        tg0 = trainer.text_group
+        if use_dist:                                   # one more window of the headline schedule with events on the comm stream
+            trainer.comm_profile = []
+            run_window(cycles[0])
+            torch.cuda.synchronize()
+            comm = comm_summary(trainer.comm_profile, 1)
+            trainer.comm_profile = None
+        if tg0 > 1:
+            trainer.set_schedule(text_group=1, grad_accum=accum)
+            d1, l1 = timed_windows(cycles, [cycles[0]])
+            sched_variants["text_group_1_variant"] = {
+                "value": round(world * B * args.steps / d1, 3), "unit": "samples/s", "ms_per_step": round(d1 / args.steps * 1e3, 2),
+                "micro_batches_per_pass": 1, "grad_accum": accum, "loss": round(float(l1.item()), 4),
+                "note": "one micro-batch of %d samples per forward/backward pass, as the reference's loop runs them; the vision tower still "
+                        "shares one pass per %d micro-batches" % (B, trainer.vision_group)}
+        n1 = min(args.steps, 16)
+        trainer.set_schedule(text_group=1, grad_accum=1)
+        if use_dist:
+            trainer.comm_profile = []
+        d1, l1 = timed_windows([1] * n1, [1, 1])
+        sched_variants["accum1_variant"] = {
+            "value": round(world * B * n1 / d1, 3), "unit": "samples/s", "ms_per_step": round(d1 / n1 * 1e3, 2), "steps": n1, "grad_accum": 1,
+            "loss": round(float(l1.item()), 4),
+            "note": "gradient all-reduce + clipping + AdamW after EVERY micro-batch (SURVEY 8(d) C3: accum = 1 beside the schedule's 32)"}
+        if use_dist:
+            torch.cuda.synchronize()
+            sched_variants["accum1_variant"]["comm"] = comm_summary(trainer.comm_profile[2 * len(trainer.comm_profile) // (n1 + 2):], n1)
+            trainer.comm_profile = None
+        trainer.set_schedule(text_group=tg0, grad_accum=accum)
 
     def timed(fn, n):
         sync()
@@ -294,9 +401,10 @@ def main():
     variants = {}
     if world == 1 and not args.no_variants:
         def fwd():
+            b = stream.pop()                     # a fresh micro-batch per forward (distinct inputs, new tensor objects)
             with torch.no_grad():
-                return model(images=batch["pixel_values"], geom_token=batch["geom_token"], input_ids=batch["input_ids"],
-                             attention_mask=batch["attention_mask"], labels=batch["labels"])
+                return model(images=b["pixel_values"], geom_token=b["geom_token"], input_ids=b["input_ids"],
+                             attention_mask=b["attention_mask"], labels=b["labels"])
         model.eval()
         fwd()
         dtf, lf = timed(fwd, max(4, min(args.steps, 16)))
@@ -311,10 +419,10 @@ def main():
 
         # the same forward over 8 micro-batches at once (48 samples): what the tower / text GEMMs reach when the batch is not the limit
         if trainer.text_group > 1:
-            big, _sizes = trainer._merge([batch] * trainer.text_group)
             nb = trainer.text_group
 
             def fwd_big():
+                big, _sizes = trainer._merge([stream.pop() for _ in range(nb)])      # (the torch.cat is inside the timed call)
                 with torch.no_grad():
                     return model(images=big["pixel_values"], geom_token=big.get("geom_token"), input_ids=big["input_ids"],
                                  attention_mask=big["attention_mask"], labels=big["labels"])
@@ -329,23 +437,21 @@ def main():
 
         # ---- configs C4 (8 views + geometry tokens) and C5 (C4 with the e4m3 forward) on this one GPU, same B and L
         if not args.geom and V == 1:
-            b8 = synthetic_batch(B, 8, L, args.image_size, 151936, model.image_id, 151643, 198, 4321, dev, True)
-            hr8 = float((b8["labels"][:, 1:] != -100).sum().item()) / B
+            stream8 = BatchStream(npool, lambda i: synthetic_batch(B, 8, L, args.image_size, 151936, model.image_id, 151643, 198,
+                                                                   4321 + i, dev, True))
+            hr8 = sum(float((b["labels"][:, 1:] != -100).sum().item()) for b in stream8.pool) / (B * npool)
             tf8 = (flops_vggt(8, args.image_size) + flops_perceiver() + 3 * flops_qwen(L, head_rows=hr8)) / 1e12
             model.geom_tokens, trainer.geom_on = 8, True
             for key, fp8 in (("c4_variant", False), ("c5_variant", True)):
                 model.text_model.enable_fp8_forward(fp8)
                 n8 = max(1, args.variant_steps)
-                trainer.grad_accum, trainer.micro = n8, 0                # one accumulation cycle: n8 micro-batches + one AdamW
-                for i in range(n8):
-                    trainer.micro_step(b8, upcoming=[b8] * min(vg - 1, n8 - 1 - i))    # warm the 8-view shapes over the same cycle
+                run_window(n8, stream8)                                  # warm the 8-view shapes over the same cycle
                 assert not model._vis_group
-                left = [n8]
-
-                def step8():
-                    left[0] -= 1
-                    return trainer.micro_step(b8, upcoming=[b8] * min(vg - 1, left[0]))
-                dt8, l8 = timed(step8, n8)
+                sync()
+                t0 = time.perf_counter()
+                l8 = run_window(n8, stream8)                             # one accumulation cycle: n8 micro-batches + one AdamW
+                sync()
+                dt8 = (time.perf_counter() - t0) / n8
                 assert not model._vis_group
                 variants[key] = {"value": round(B / dt8, 3), "unit": "samples/s", "ms_per_step": round(dt8 * 1e3, 2), "steps": n8,
                                  "views": 8, "geom_tokens": 8, "fp8_text_forward": fp8, "batch_per_gpu": B, "loss": round(float(l8.item()), 4),
@@ -354,6 +460,7 @@ def main():
                                  "workload": ("BASELINE config %s on 1 GPU: VGGT aggregator @%dpx x 8 views (8 232-token global attention) "
                                               "+ 8 geometry tokens + Perceiver + Qwen3-4B fwd+bwd + AdamW%s"
                                               % ("C5" if fp8 else "C4", args.image_size, "; Qwen3 forward projections in e4m3" if fp8 else ""))}
+            del stream8
             model.text_model.enable_fp8_forward(args.fp8)
             model.geom_tokens, trainer.geom_on = (8 if args.geom else 0), bool(args.geom)
             trainer.geom_grad.zero_()
@@ -365,14 +472,10 @@ def main():
         # one group of the deferred weight-gradient schedule (every projection's weight-gradient GEMM runs over nroof micro-batches'
         # rows): per-step figures below are the group's totals / nroof
         nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)) * max(1, trainer.text_group), accum))
-        trainer.grad_accum, trainer.micro = nroof, 0
-        for i in range(nroof):
-            trainer.micro_step(batch, upcoming=up[: nroof - 1 - i])   # (the serial schedule's shapes are tuned before the events go in)
+        run_window(nroof)       # (the serial schedule's shapes are tuned before the events go in)
         torch.cuda.synchronize()
         ops.GEMM_PROFILE = []
-        trainer.micro = 0
-        for i in range(nroof):
-            trainer.micro_step(batch, upcoming=up[: nroof - 1 - i])
+        run_window(nroof)
         torch.cuda.synchronize()
         fl = sum(g[0] for g in ops.GEMM_PROFILE) / nroof
         by = sum(g[1] for g in ops.GEMM_PROFILE) / nroof
@@ -404,9 +507,8 @@ def main():
                 "gemm_ms_per_step": round(ms, 2), "gemm_tflop_per_step": round(fl / 1e12, 3)}
     elif world > 1:
         nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)) * max(1, trainer.text_group), accum))
-        trainer.grad_accum, trainer.micro = nroof, 0
-        for i in range(2 * nroof):
-            trainer.micro_step(batch, upcoming=up[: (nroof - 1 - i % nroof)])  # keep collectives matched across ranks
+        run_window(nroof)       # keep collectives matched across ranks
+        run_window(nroof)
     if use_dist:
         dist.barrier()
 
@@ -434,7 +536,9 @@ def main():
             "roofline": roof,
             "forward_only": forward_only,
             "trimmed_padding_variant": trimmed,
+            "comm": comm,
         }
+        out.update(sched_variants)
         out.update(variants)
         if world == 1 and not args.no_cpu_baseline:
             try:

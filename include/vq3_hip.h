@@ -367,6 +367,15 @@ int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* 
  * (gemm3.hip: 128x128 2-stage, 128x128 loader ring, 256x128 loader ring; -3 releases it too). Process-wide; not meant for concurrent use with launches on other threads. */
 int vq3_gemm_force_config(int32_t cfg);
 
+/* Host-only test hook (no launch, no GPU needed): the workgroup -> tile map the GEMM kernels use for an M x N output cut into
+ * bm x bn tiles with wg_per_cu workgroups resident per CU. Workgroup id b runs on XCD b % 8; each XCD owns one rectangle of an
+ * xm x (8 / xm) blocking of the tile grid and walks it in bands of `band` n-tiles (n-fastest inside a band, then m), so the tiles
+ * an XCD has in flight together share few row panels of A and few panels of B in its private 4 MiB L2. Writes the chosen xm / band
+ * and, when `order` is non-null, (m-tile, n-tile) of workgroup ids 0 .. mtiles * ntiles - 1 into order[2 * id], order[2 * id + 1].
+ * There is no counterpart in the reference (cuBLAS picks its own rasterisation behind torch.nn.functional.linear). */
+int vq3_gemm_tile_order(int32_t M, int32_t N, int32_t bm, int32_t bn, int32_t wg_per_cu, int32_t* xm_out, int32_t* band_out,
+                        int32_t* order);
+
 #ifdef __cplusplus
 }
 #endif

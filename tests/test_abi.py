@@ -39,3 +39,38 @@ def test_bad_args_fail_loudly_without_gpu():
     d = _lib.GemmDesc()
     assert lib.vq3_gemm_bf16_nt(ctypes.byref(d), None) != 0
     assert b"null" in lib.vq3_last_error()
+
+
+def _tile_order(lib, M, N, bm, bn, wg):
+    import numpy as np
+    mt, nt = (M + bm - 1) // bm, (N + bn - 1) // bn
+    o = np.zeros((mt * nt, 2), np.int32)
+    xm, nb = ctypes.c_int32(), ctypes.c_int32()
+    assert lib.vq3_gemm_tile_order(M, N, bm, bn, wg, ctypes.byref(xm), ctypes.byref(nb), o.ctypes.data_as(ctypes.c_void_p)) == 0
+    return o, xm.value, nb.value, mt, nt
+
+
+def test_gemm_tile_order_is_a_bijection_and_blocks_per_xcd():
+    """The workgroup -> tile map of the GEMM kernels (gemm_common.h: tile_coords_id, host twin behind vq3_gemm_tile_order): every tile
+    exactly once for any grid (ragged XCD rectangles, ragged last band, grids smaller than the chip), and - the point of the banded
+    walk - the 32 tiles an XCD has in flight together on the tall VGGT-tower shapes form a block of few A row panels x few B panels
+    (round 2's m-fastest walk had 25-32 different A panels per n-tile in flight)."""
+    from vggt_qwen3_amd import _lib
+    lib = _lib.load()
+    shapes = [(49392, 4096, 256, 256, 1), (49392, 4096, 128, 256, 1), (49392, 3072, 128, 256, 1), (49392, 1024, 256, 128, 1),
+              (9600, 19456, 256, 256, 1), (1200, 2560, 128, 128, 2), (2560, 9728, 256, 256, 1), (300, 520, 128, 128, 2),
+              (77, 200, 128, 128, 2), (6174, 1024, 128, 128, 2), (152000, 2560, 128, 128, 1), (112, 151937, 128, 128, 2)]
+    for M, N, bm, bn, wg in shapes:
+        o, xm, nb, mt, nt = _tile_order(lib, M, N, bm, bn, wg)
+        assert xm in (1, 2, 4, 8) and nb >= 1
+        ids = (o[:, 0].astype("int64") * nt + o[:, 1]).tolist()
+        assert sorted(ids) == list(range(mt * nt)), (M, N, bm, bn)
+        assert int(o[:, 0].max()) == mt - 1 and int(o[:, 1].max()) == nt - 1
+    for M, N, bm, bn in ((49392, 4096, 256, 256), (49392, 4096, 128, 256), (49392, 3072, 128, 256)):
+        o, xm, nb, mt, nt = _tile_order(lib, M, N, bm, bn, 1)
+        for xcd in range(8):
+            mine = o[xcd::8]                              # workgroup b runs on XCD b % 8, in order
+            for r in range(0, min(len(mine), 320) - 32, 32):
+                blk = mine[r:r + 32]
+                na, nbp = len(set(blk[:, 0].tolist())), len(set(blk[:, 1].tolist()))
+                assert na * bm + nbp * bn <= 12 * 256 + 256, (M, N, bm, bn, xcd, r, na, nbp)   # ~square block: (8 + 4) x 256 rows of panels

@@ -200,6 +200,35 @@ def test_gemm_layernorm_fold(ops, cfg):
         ops.gemm_force_config(-3)
 
 
+def test_gemm_layernorm_fold_adversarial_rows(ops):
+    """the folded LayerNorm takes the variance as sum(x^2)/C - mu^2 (f32, one pass) and its output as the difference of two
+    large terms, rstd (x.B^T - mu colsum). Rows a real residual stream has and random initialisation does not: a large common offset
+    (mean 50, std 0.5), massive-activation channels (a few columns at +-1e3) and both together - against LayerNorm in f64 statistics ->
+    bf16 -> GEMM. Tolerance: 2e-2 relative (the offset rows keep only ~3 significant bits of their deviation in bf16 - for both paths)."""
+    M, C, N2, eps = 2048, 1024, 512, 1e-5
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(M, C, device="cuda", generator=g) * 0.5
+    x[: M // 4] += 50.0                                           # common offset
+    x[M // 4: M // 2, [3, 517, 900]] = torch.tensor([1e3, -1e3, 7e2], device="cuda")    # massive activations
+    x[M // 2: 3 * M // 4] += 50.0
+    x[M // 2: 3 * M // 4, [3, 517, 900]] = torch.tensor([1e3, -1e3, 7e2], device="cuda")
+    x = x.to(BF16)
+    gamma = (torch.rand(C, device="cuda", generator=g) + 0.5); beta = torch.randn(C, device="cuda", generator=g) * 0.2
+    W = _rand((N2, C), 0.05, seed=4).float(); b = torch.randn(N2, device="cuda", generator=g) * 0.1
+    st = ops.rowstats128(x)
+    Bw = (W * gamma[None, :]).to(BF16)
+    colsum = Bw.float().sum(1).contiguous()
+    dvec = (b + W @ beta).contiguous()
+    y = ops.linear(x, Bw, bias=dvec, ln_fold=ops.ln_fold(stats_in=st, eps=eps, colsum=colsum))
+    xd = x.double()
+    mu = xd.mean(1, keepdim=True); var = xd.var(1, unbiased=False, keepdim=True)
+    xn = ((xd - mu) / torch.sqrt(var + eps) * gamma.double() + beta.double())
+    ref = (xn.float().to(BF16).float() @ W.to(BF16).float().t() + b)
+    for lo, hi, what in ((0, M // 4, "offset"), (M // 4, M // 2, "outliers"), (M // 2, 3 * M // 4, "both"), (3 * M // 4, M, "plain")):
+        e = _relerr(y[lo:hi], ref[lo:hi])
+        assert e < 2e-2, (what, e)
+
+
 def test_colsum_multi_tall_slabs(ops):
     """vq3_colsum_multi on the slabs a merged pass of 8 micro-batches leaves (9600 x 128 from the q/k-prep backward, 480 x 2560 from
     RMSNorm): rows split over several workgroups, combined by the last arriver in split order - equal to the f32 column sums,

@@ -407,3 +407,34 @@ def test_merged_micro_batches_match_one_by_one():
     tr.micro_step(mbs[0], upcoming=[mbs[2]])
     with pytest.raises(RuntimeError, match="same objects"):
         tr.micro_step(mbs[3])
+    # ... and the interrupted group can be accounted for: the gradient of mbs[2] is already in flat_g
+    rest = tr.flush_pending()
+    assert len(rest) == 1 and tr.micro == 2 and not tr._merged_pending and tr.opt_step == 0
+    tr.micro_step(mbs[3])                                        # a different batch is accepted again
+    assert tr.micro == 3
+
+
+def test_merged_group_keeps_counters_and_weights_in_phase():
+    """with merged micro-batches the window's AdamW step must run with the micro_step() call that returns the window's LAST
+    loss - for every call before it `micro`, `opt_step`, lrs() and the weights are those of a loop that runs the micro-batches
+    one by one (a step_N save inside the group must not contain the window's update)."""
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z, m, build, batch = _vlm()
+    mbs = [dict(batch) for _ in range(6)]
+    model = build()
+    model.vision_model = _Tower(model.vision_model.agg)
+    tr = Stage1Trainer(model, lr=1e-3, proj_lr=1e-3, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=3, text_group=3)
+    w0 = model.text_model.flat_w.clone()
+    for i in range(3):
+        tr.micro_step(mbs[i], upcoming=mbs[i + 1:3])
+        assert tr.micro == i + 1
+        if i < 2:
+            assert tr.opt_step == 0 and torch.equal(model.text_model.flat_w, w0), i     # the update waits for the last loss
+    assert tr.opt_step == 1 and not torch.equal(model.text_model.flat_w, w0) and not tr._opt_due
+    # an interrupted group: flush_pending() runs the deferred step exactly once
+    w1 = model.text_model.flat_w.clone()
+    tr.micro_step(mbs[3], upcoming=mbs[4:6])
+    assert tr.opt_step == 1 and torch.equal(model.text_model.flat_w, w1) and tr._opt_due
+    tr.flush_pending()
+    assert tr.micro == 6 and tr.opt_step == 2 and not tr._opt_due and not torch.equal(model.text_model.flat_w, w1)
+    assert tr.flush_pending() == [] and tr.opt_step == 2

@@ -490,7 +490,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   }
   p.mtiles = (d->M + BM - 1) / BM;
   p.ntiles = (d->N + BN - 1) / BN;
-  p.xm = choose_xm(p.mtiles, p.ntiles);
+  choose_tile_order(p, BM, BN, 2);
   VQ3_CHECK_ARG((long)p.mtiles * p.ntiles < (1L << 31), "gemm: too many tiles");
   dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
   if (d->out_f32)
@@ -520,6 +520,29 @@ extern "C" int vq3_gemm_vit_qkv_ln(const vq3_gemm_desc* d, const vq3_vit_qkv_epi
 extern "C" int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* d, const void* gu, void* dgu, void* stream) {
   VQ3_CHECK_ARG(dgu != nullptr, "gemm_swiglu_bwd: null output pointer");
   return gemm_dispatch(d, nullptr, stream, gu, dgu);
+}
+
+extern "C" int vq3_gemm_tile_order(int32_t M, int32_t N, int32_t bm, int32_t bn, int32_t wg_per_cu, int32_t* xm_out, int32_t* band_out,
+                                   int32_t* order) {
+  VQ3_CHECK_ARG(M > 0 && N > 0 && bm > 0 && bn > 0 && wg_per_cu >= 1, "gemm_tile_order: bad arguments");
+  GemmParams p;
+  p.M = M; p.N = N;
+  p.mtiles = (M + bm - 1) / bm;
+  p.ntiles = (N + bn - 1) / bn;
+  VQ3_CHECK_ARG((long)p.mtiles * p.ntiles < (1L << 28), "gemm_tile_order: too many tiles");
+  choose_tile_order(p, bm, bn, wg_per_cu);
+  if (xm_out) *xm_out = p.xm;
+  if (band_out) *band_out = p.nbw;
+  if (order) {
+    const int n = p.mtiles * p.ntiles;
+    for (int i = 0; i < n; ++i) {
+      int m0 = 0, n0 = 0;
+      tile_coords_id(p, i, bm, bn, m0, n0);
+      order[2 * i] = m0 / bm;
+      order[2 * i + 1] = n0 / bn;
+    }
+  }
+  return 0;
 }
 
 extern "C" int vq3_gemm_force_config(int32_t cfg) {

@@ -284,7 +284,7 @@ int launch_cfg(GemmParams& p, int nbatch, hipStream_t stream) {
   }
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = (p.N + BN - 1) / BN;
-  p.xm = choose_xm(p.mtiles, p.ntiles);
+  choose_tile_order(p, BM, BN, NSTAGE == 2 ? 2 : 1);
   dim3 grid(p.mtiles * p.ntiles, 1, nbatch);
   if (p.out_f32)
     hipLaunchKernelGGL((gemm_v2_kernel<BM, BN, WM, WN, NSTAGE, NLOAD, true>), grid, dim3(64 * (WM * WN + NLOAD)), SMEM, stream, p);

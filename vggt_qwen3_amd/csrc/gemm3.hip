@@ -183,6 +183,21 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
     }
     if (AKM || BKM) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // The transposed reads' destinations carry no data dependence on the wait ("memory" orders memory operations only, and the
+      // MFMAs below are register-only): every destination passes through an empty volatile statement BEHIND the wait (volatile
+      // statements keep their order), so no use of it can be scheduled above the wait (cdna guide 5.7 item 1, form ii / item 3).
+      if (AKM) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(alo[ks][i]), "+v"(ahi[ks][i]));
+      }
+      if (BKM) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(blo[ks][j]), "+v"(bhi[ks][j]));
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -389,7 +404,7 @@ int launch_v3(GemmParams& p, int nbatch, hipStream_t stream) {
   }
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = (p.N + BN - 1) / BN;
-  p.xm = choose_xm(p.mtiles, p.ntiles);
+  choose_tile_order(p, BM, BN, NSTAGE == 2 ? 2 : 1);
   dim3 grid(p.mtiles * p.ntiles, p.nsplit, nbatch);
   if (p.out_f32)
     hipLaunchKernelGGL((gemm_v3_kernel<BM, 4, 2, NSTAGE, NLOAD, AKM, BKM, true>), grid, dim3(64 * (8 + NLOAD)), SMEM, stream, p);

@@ -396,7 +396,7 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
   }
   p.mtiles = (p.M + 128 * AH - 1) / (128 * AH);
   p.ntiles = (p.N + 128 * BH - 1) / (128 * BH);
-  p.xm = choose_xm(p.mtiles, p.ntiles);
+  choose_tile_order(p, 128 * AH, 128 * BH, 1);
   static int ncu = 0;
   if (!ncu) {
     int dev = 0, n = 0;

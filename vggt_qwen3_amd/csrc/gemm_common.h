@@ -1,5 +1,6 @@
 // Shared by the GEMM kernels: launch parameters, the XCD-aware tile order and the fused epilogue.
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -29,6 +30,7 @@ struct GemmParams {
   int nb2, b2divB;
   int mtiles, ntiles;
   int xm;          // XCD blocking of the tile grid along M (1, 2, 4 or 8)
+  int nbw;         // band width (n-tiles) of the walk inside an XCD's rectangle: n-fastest inside a band, then m, bands in turn
   int kper;        // split-K: K range per blockIdx.y slice (multiple of 64); == K when not split
   int nsplit;      // number of K slices (gridDim.y); > 1 => f32 output combined with atomics
   int act;         // 0 none, 1 gelu(erf), 2 silu
@@ -94,10 +96,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // XCD-aware tile order. Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own 4 MiB
 // L2), so workgroup b runs on XCD b % 8 as its (b / 8)-th tile. Each XCD is given one rectangle of an xm x (8/xm)
-// blocking of the tile grid (walked m-fastest): the tiles sharing an L2 then re-read only mtiles/xm row panels of A
-// and ntiles/xn panels of B. The host picks xm in {1,2,4,8} minimising mtiles/xm + ntiles/xn (xm = 1 is "n-tile
-// major" order). Bijective for any grid size; placement only ever affects speed.
-__device__ __forceinline__ void tile_coords_id(const GemmParams& p, int orig, int BM, int BN, int& m0, int& n0) {
+// blocking of the tile grid. Inside its rectangle an XCD walks BANDS of nbw n-tiles: n-fastest inside a band, then down
+// m, one band after the other - so the c tiles an XCD has in flight together (consecutive positions: 32 CUs x workgroups per
+// CU) form a (c / nbw) x nbw block that shares c / nbw row panels of A and nbw panels of B. Round 2's m-fastest walk put up to
+// 25-48 m-tiles of ONE n-tile in flight: every A panel was fetched again for every n-tile (fc1, 49 392 x 4096 x 1024: 1.68 GB
+// through the fabric per launch for 0.11 GB of operands, L2 hit rate 0.58: profiles/r3_gemm_fetch_by_shape.txt). The host picks
+// (xm, nbw) from a traffic model (choose_tile_order). Bijective for any grid size; placement only ever affects speed.
+__host__ __device__ __forceinline__ void tile_coords_id(const GemmParams& p, int orig, int BM, int BN, int& m0, int& n0) {
   const int nwg = p.mtiles * p.ntiles;
   const int xcd = orig & 7, idx = orig >> 3;
   const int q = nwg >> 3, r = nwg & 7;
@@ -111,8 +116,19 @@ __device__ __forceinline__ void tile_coords_id(const GemmParams& p, int orig, in
     int ncnt = p.ntiles - xj * nc; ncnt = ncnt < 0 ? 0 : (ncnt > nc ? nc : ncnt);
     const int sz = mcnt * ncnt;
     if (s < sz) {
-      mt = xi * mc + s % mcnt;
-      ntl = xj * nc + s / mcnt;
+      const int nb = p.nbw < 1 ? 1 : (p.nbw > ncnt ? ncnt : p.nbw);
+      const int full = (ncnt / nb) * nb;            // columns covered by whole bands
+      int band0, bw, rr;
+      if (s < full * mcnt) {
+        const int per = mcnt * nb;
+        const int b = s / per;
+        band0 = b * nb; bw = nb; rr = s - b * per;
+      } else {
+        band0 = full; bw = ncnt - full; rr = s - full * mcnt;
+      }
+      const int mi = rr / bw;
+      mt = xi * mc + mi;
+      ntl = xj * nc + band0 + (rr - mi * bw);
       break;
     }
     s -= sz;
@@ -569,7 +585,12 @@ __device__ __forceinline__ bool staged_ok(const GemmParams& p, long coff, long r
          (!p.R || ((p.ldr % 8 == 0) && (roff % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.R) & 15) == 0)));
 }
 
-// host: pick the XCD blocking for a tile grid
+// host: pick the XCD blocking (xm) and the band width (nbw) of the walk for a tile grid. Model of the bytes one XCD pulls through
+// the fabric: its rectangle is mR x nR tiles, `conc` of them in flight together as a (conc / nbw) x nbw block; a row panel of A
+// (BM x K) is fetched once per band it appears in, a panel of B (BN x K) once per block row of a band (nothing is assumed to survive
+// a round in the 4 MiB L2: per round the block streams its A panels and writes its C tiles through it):
+//   bytes = BM K 2 * mR * ceil(nR / nbw)  +  BN K 2 * nR * ceil(mR / (conc / nbw))
+// VQ3_GEMM_XM / VQ3_GEMM_BAND override (A/B runs); VQ3_GEMM_BAND=0 restores round 2's m-fastest walk (nbw = 1 with xm by panel count).
 inline int choose_xm(int mtiles, int ntiles) {
   int best = 1;
   double bc = 1e30;
@@ -578,6 +599,30 @@ inline int choose_xm(int mtiles, int ntiles) {
     if (c < bc - 1e-9) { bc = c; best = xm; }
   }
   return best;
+}
+inline void choose_tile_order(GemmParams& p, int BM, int BN, int wg_per_cu) {
+  static int env_band = -2, env_xm = -2;
+  if (env_band == -2) { const char* e = getenv("VQ3_GEMM_BAND"); env_band = e ? atoi(e) : -1; }
+  if (env_xm == -2) { const char* e = getenv("VQ3_GEMM_XM"); env_xm = e ? atoi(e) : -1; }
+  if (env_band == 0) { p.xm = choose_xm(p.mtiles, p.ntiles); p.nbw = 1; return; }
+  const int conc = 32 * (wg_per_cu < 1 ? 1 : wg_per_cu);
+  double best = 1e300;
+  int bxm = 1, bnb = 1;
+  for (int xm = 1; xm <= 8; xm *= 2) {
+    if (env_xm > 0 && xm != env_xm) continue;
+    const int xn = 8 / xm;
+    const int mR = (p.mtiles + xm - 1) / xm, nR = (p.ntiles + xn - 1) / xn;
+    for (int nb = 1; nb <= 64; nb *= 2) {
+      if (env_band > 0 && nb != env_band) continue;
+      const int nbe = nb > nR ? nR : nb;
+      int a = conc / nbe; a = a < 1 ? 1 : a;
+      const double bytes = (double)BM * mR * ((nR + nbe - 1) / nbe) + (double)BN * nR * ((mR + a - 1) / a);
+      // (regions that are not full - a grid smaller than the chip - cost what they cost: the model only ranks)
+      if (bytes < best - 1e-9) { best = bytes; bxm = xm; bnb = nbe; }
+      if (nb >= nR) break;
+    }
+  }
+  p.xm = bxm; p.nbw = bnb;
 }
 
 // v2 (LDS-DMA pipelined) launcher, defined in gemm2.hip. cfg: 0 = 256x128 tile, 1 = 128x256, 2 = 128x128.

@@ -164,7 +164,7 @@ int launch_fp8(GemmParams& p, const float* rs, const float* cs, hipStream_t stre
   }
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = (p.N + BN - 1) / BN;
-  p.xm = choose_xm(p.mtiles, p.ntiles);
+  choose_tile_order(p, BM, BN, 1);
   hipLaunchKernelGGL((gemm_fp8_kernel<BM, BN, WM, WN, NSTAGE, NLOAD>), dim3(p.mtiles * p.ntiles), dim3(64 * (WM * WN + NLOAD)),
                      SMEM, stream, p, rs, cs);
   return 0;

@@ -433,11 +433,19 @@ bool colsum_scratch(hipStream_t s, float** scratch, int** tickets) {
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
     const size_t nt = 8 * (CS_MAX_COLS / 64);
     if (hipMalloc(&w.scratch, (size_t)8 * CS_MAX_SPLIT * CS_MAX_COLS * sizeof(float)) != hipSuccess ||
-        hipMalloc(&w.tickets, nt * sizeof(int)) != hipSuccess || hipMemset(w.tickets, 0, nt * sizeof(int)) != hipSuccess) {
+        hipMalloc(&w.tickets, nt * sizeof(int)) != hipSuccess) {
       (void)hipGetLastError();
       w.scratch = nullptr;
       return false;
     }
+  }
+  // The arrival tickets are zeroed on the CALLER's stream before every launch that uses them (a memset node when captured): ordered
+  // with the kernel by the stream itself, and a launch that died half-way cannot poison the next one (cdna guide, Guideline 16
+  // "Re-initialise every call"; the block starts at its allocation's start and is a multiple of 16 bytes).
+  static_assert((8 * (CS_MAX_COLS / 64) * sizeof(int)) % 16 == 0, "ticket block: multiple of 16 bytes");
+  if (hipMemsetAsync(w.tickets, 0, 8 * (CS_MAX_COLS / 64) * sizeof(int), s) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
   }
   *scratch = w.scratch; *tickets = w.tickets;
   return true;

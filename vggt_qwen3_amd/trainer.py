@@ -76,9 +76,11 @@ class Stage1Trainer:
             text_group = int(os.environ.get("VQ3_TEXT_GROUP", "8"))     # measured: 1: 96.6, 2: 106.5, 4: 115.1, 8: 119.1, 16: 115.3 samples/s
         self.text_group = max(1, text_group)
         self._merged_pending: List = []     # [(batch dict, loss)] of a merged pass, handed out by the following micro_step() calls
+        self._opt_due = False               # the merged pass held the window's boundary: AdamW runs when its last loss is handed out
         self._merge_cache = None
         if wgrad_defer is None:
             wgrad_defer = int(os.environ.get("VQ3_WGRAD_DEFER", "8"))
+        self._wgrad_defer = wgrad_defer
         # (depth counts backward passes: with merged passes the same number of token rows per weight-gradient product)
         self.tm.enable_wgrad_deferral(min(max(1, wgrad_defer // self.text_group), max(1, grad_accum)))
         # the frozen vision tower runs once per `vision_group` micro-batches on their concatenated images (vlm.py: precompute_vision)
@@ -114,10 +116,23 @@ class Stage1Trainer:
         dp.check_cover(self.buckets, self.embed_span, n)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.dist_on else None
         self._works: List = []
+        self.comm_profile: Optional[List] = None    # set to [] to collect (start event, end event, bytes) per gradient all-reduce
         self._fired: List[int] = []     # buckets all-reduced from inside the backward of the current boundary micro-batch
         if not hasattr(model, "_trainers"):
             model._trainers = []
         model._trainers.append(weakref.ref(self))
+
+    def set_schedule(self, *, text_group: Optional[int] = None, grad_accum: Optional[int] = None) -> None:
+        """Change micro-batches per pass and / or per optimiser step between two accumulation windows (bench.py times the same job
+        under several schedules); the deferred weight-gradient depth follows as in __init__."""
+        if self._merged_pending or self._opt_due or any(self.tm._wd_rows):
+            raise RuntimeError("set_schedule: only on an accumulation boundary (flush_pending() first)")
+        if grad_accum is not None:
+            self.grad_accum = max(1, int(grad_accum))
+        if text_group is not None:
+            self.text_group = max(1, int(text_group))
+        self.micro = 0
+        self.tm.enable_wgrad_deferral(min(max(1, self._wgrad_defer // self.text_group), max(1, self.grad_accum)))
 
     def resync_master_from_weights(self) -> None:
         """The bf16 weights were replaced behind the trainer's back (a checkpoint load): re-derive the fp32 master copy, or
@@ -134,7 +149,14 @@ class Stage1Trainer:
             return
         self.comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
+            prof = self.comm_profile
+            if prof is not None:        # HIP events on the stream the collective runs on (bench.py: allreduce_ms_per_opt_step)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dp.allreduce_span(self.tm.flat_g, lo, hi, group=self.pg)
+            if prof is not None:
+                e1.record()
+                prof.append((e0, e1, (hi - lo) * self.tm.flat_g.element_size()))
 
     def _layer_done(self, i: int):
         if i in self.buckets:
@@ -155,9 +177,15 @@ class Stage1Trainer:
         if self._merged_pending:            # this micro-batch already ran as part of a merged pass: hand its loss out
             expected, loss = self._merged_pending[0]
             if expected is not batch:
-                raise RuntimeError("micro_step: the batches passed as `upcoming` must come back, in order, as the same objects")
+                raise RuntimeError("micro_step: the batches passed as `upcoming` must come back, in order, as the same objects "
+                                   "(flush_pending() accounts for the rest of the merged pass if the loop was interrupted)")
             self._merged_pending.pop(0)
             self.micro += 1
+            if not self._merged_pending and self._opt_due:
+                # the window's optimiser step runs with the call that returns the window's LAST loss: `micro`, `opt_step`, lrs() and
+                # the weights stay in phase for every call in between (a step_N save inside the group sees pre-step weights)
+                self._opt_due = False
+                self._optimizer_step()
             return loss
         k = self.micro % self.grad_accum
         members = [batch]
@@ -192,14 +220,27 @@ class Stage1Trainer:
             self.geom_grad[: self._gn] += torch.cat([g["0.weight"].reshape(-1), g["0.bias"].reshape(-1),
                                                      g["2.weight"].reshape(-1), g["2.bias"].reshape(-1)])
             self.geom_grad[self._gn:] += float(gsize)
-        if boundary:
-            self._optimizer_step()
         self.micro += 1
         if gsize > 1:
             losses = st["loss"]
             self._merged_pending = [(members[j], losses[j]) for j in range(1, gsize)]
+            self._opt_due = boundary        # deferred to the micro_step() call that hands out the group's last loss
             return losses[0]
+        if boundary:
+            self._optimizer_step()
         return st["loss"]
+
+    def flush_pending(self) -> List[torch.Tensor]:
+        """Account for the micro-batches of a merged pass whose micro_step() calls never came (the loop was interrupted, or is
+        about to feed different batches): their gradient contribution is already in flat_g, so `micro` advances over them, the
+        window's deferred optimiser step runs if it was due, and their losses are returned. A no-op outside a merged group."""
+        losses = [loss for _, loss in self._merged_pending]
+        self.micro += len(self._merged_pending)
+        self._merged_pending = []
+        if self._opt_due:
+            self._opt_due = False
+            self._optimizer_step()
+        return losses
 
     @staticmethod
     def _mergeable(members) -> bool:

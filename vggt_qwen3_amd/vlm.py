@@ -206,7 +206,6 @@ class VGGTQwen3VLM(nn.Module):
 
     # ------------------------------------------------------------------ encoders
     @torch.no_grad()
-    @torch.no_grad()
     def precompute_vision(self, images_list) -> None:
         """The frozen aggregator (vggt_qwen3_vlm.py:44-45,128-144: no_grad, eval-mode arithmetic, no dropout) for SEVERAL upcoming
         micro-batches in one pass: their images are concatenated along the batch axis - every sample's frame / global attention and
@@ -232,9 +231,14 @@ class VGGTQwen3VLM(nn.Module):
         for k, (im, agg) in enumerate(self._vis_group):
             if im is images:
                 del self._vis_group[k]
+                # precompute_vision() allocated the slice's block on the stream it ran on; a consumer on another stream
+                # (prefetch_images -> _vis_stream) must be known to the caching allocator before the last slice is dropped
+                if agg.is_cuda:
+                    agg.record_stream(torch.cuda.current_stream())
                 return agg
         return None
 
+    @torch.no_grad()
     def encode_images(self, images: torch.Tensor, _orig: Optional[torch.Tensor] = None) -> torch.Tensor:
         """images [B, V, C, H, W] -> [B, num_vis_tokens, hidden] (vggt_qwen3_vlm.py:128-162)."""
         B, V = images.shape[:2]
