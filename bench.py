@@ -255,6 +255,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        """MAX of a host-side duration over the ranks (the contract's timing rule); the gloo rehearsal backend reduces a host tensor."""
+        if not use_dist:
+            return seconds
+        on_dev = dist.get_backend() != "gloo"
+        t = torch.tensor([seconds], device=dev if on_dev else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     loss = None
     # warm-up runs whole accumulation cycles too (so the timed region starts on a cycle boundary); the first cycle
     # also pays the one-time costs (LDS attribute setup, allocator growth, RCCL channel setup)
@@ -287,11 +296,7 @@ def main():
     for clen in cycles:
         loss = run_window(clen)       # K vision forwards (in groups) + K text fwd/bwd + len(cycles) all-reduces / AdamW steps in the window
     sync()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
@@ -307,11 +312,7 @@ def main():
         for clen in cycles:
             loss_t = run_window(clen)
         sync()
-        dtt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dtt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtt = float(t.item())
+        dtt = max_over_ranks(time.perf_counter() - t0)
         L_eff = int(model._last_L) if hasattr(model, "_last_L") else None
         trimmed = {"value": round(world * B * args.steps / dtt, 3), "unit": "samples/s", "ms_per_step": round(dtt / args.steps * 1e3, 2),
                    "executed_seq_len": L_eff, "loss": round(float(loss_t.item()), 4),
@@ -331,12 +332,7 @@ def main():
         for c in clens:
             last = run_window(c)
         sync()
-        d = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([d], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            d = float(t.item())
-        return d, last
+        return max_over_ranks(time.perf_counter() - t0), last
 
     def comm_summary(prof, nopt):
         """HIP-event time of the gradient all-reduces (events on the communication stream) per optimiser step; bus bandwidth with the
@@ -353,14 +349,14 @@ def main():
     # Reported beside `value`, never instead of it. Every rank runs them (the collectives stay matched).
     sched_variants = {}
     comm = None
+    if use_dist:                                       # one more window of the headline schedule with events on the comm stream
+        trainer.comm_profile = []
+        run_window(cycles[0])
+        torch.cuda.synchronize()
+        comm = comm_summary(trainer.comm_profile, 1)
+        trainer.comm_profile = None
     if not args.no_variants and not args.trim_pad:
         tg0 = trainer.text_group
-        if use_dist:                                   # one more window of the headline schedule with events on the comm stream
-            trainer.comm_profile = []
-            run_window(cycles[0])
-            torch.cuda.synchronize()
-            comm = comm_summary(trainer.comm_profile, 1)
-            trainer.comm_profile = None
         if tg0 > 1:
             trainer.set_schedule(text_group=1, grad_accum=accum)
             d1, l1 = timed_windows(cycles, [cycles[0]])

@@ -135,9 +135,22 @@ int vq3_colsum_multi(const vq3_colsum_job* jobs, int32_t njobs, void* stream);
 int vq3_layernorm_fwd(const void* x, const void* res, int32_t x_f32, const float* w, const float* b, void* y_bf16,
                       float* y_f32, int64_t rows, int32_t cols, float eps, void* stream);
 
+/* Backward of torch.nn.LayerNorm over f32 rows (the Perceiver's post-norm LayerNorms, src/models/projector_perceiver.py:39-40,48-50,
+ * when the projector is trained - VisionLanguageConfig.train_projector; the reference's @torch.no_grad() never reaches it):
+ * x f32 [rows, cols] = the tensor that was normalised (residual already added), dy f32 = d(loss)/d(output), w f32 [cols].
+ * dx f32 [rows, cols]; dw_part, db_part f32 [ceil(rows / 16), cols]: one partial row per workgroup of sum(dy * xhat) / sum(dy)
+ * (plain stores, every slot written) - reduce them with vq3_colsum_f32. Statistics are recomputed from x. cols <= 4096, % 4 == 0. */
+int vq3_layernorm_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw_part, float* db_part, int64_t rows,
+                      int32_t cols, float eps, void* stream);
+/* out_f32[c] (+)= sum_{r < nrows} part[r*cols + c] (f32 twin of vq3_colsum_f32_to_bf16). */
+int vq3_colsum_f32(const float* part, int32_t nrows, int32_t cols, float* out_f32, int32_t accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Element-wise / data movement
  * ---------------------------------------------------------------------------------------------------------- */
+/* Backward of the exact (erf) GELU of projector_perceiver.py:36 on the bf16 pre-activation z the forward GEMM produced:
+ * dz = dh * (Phi(z) + z * phi(z)); dh, z, dz bf16 [n], n % 8 == 0. */
+int vq3_gelu_bwd(const void* dh, const void* z, void* dz, int64_t n, void* stream);
 /* Qwen3MLP (modeling_qwen3.py:81-83): act[m, i] = silu(gu[m, i]) * gu[m, I + i]; gu bf16 [rows, 2I]. */
 int vq3_silu_mul_fwd(const void* gu, void* act, int64_t rows, int32_t inter, void* stream);
 /* dgu[m, i] = dact * up * silu'(gate); dgu[m, I+i] = dact * silu(gate). */
@@ -363,7 +376,7 @@ int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* 
 
 /* Benchmarking / test hook for vq3_gemm_bf16_nt's kernel choice on NT, K % 64 == 0 shapes: cfg = -3 restores the automatic
  * choice (the default), -1 the register-staged reference kernel, 0..14 a gemm2.hip tile configuration, 20 / 21 / 22 the
- * 8-phase kernels of gemm6.hip (256x256 / 256x128 / 128x256 tiles); 102 / 103 / 105 pin the schedule of the any-layout kernel
+ * 8-phase kernels of gemm6.hip (256x256 / 256x128 / 128x256 tiles), 23 the overlapped-epilogue kernel of gemm8.hip; 102 / 103 / 105 pin the schedule of the any-layout kernel
  * (gemm3.hip: 128x128 2-stage, 128x128 loader ring, 256x128 loader ring; -3 releases it too). Process-wide; not meant for concurrent use with launches on other threads. */
 int vq3_gemm_force_config(int32_t cfg);
 

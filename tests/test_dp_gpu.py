@@ -49,9 +49,9 @@ def _batches(z, rank):
     return out
 
 
-def _worker(rank, world, port, outdir, merge=False):
+def _worker(rank, world, port, outdir, merge=False, mode="allreduce"):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), VQ3_DP_MODE=mode)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -64,7 +64,7 @@ def _worker(rank, world, port, outdir, merge=False):
             from tests.test_trainer_gpu import _Tower
             model.vision_model = _Tower(model.vision_model.agg)          # a tower that follows its input's batch axis
         tr = Stage1Trainer(model, grad_accum=2, **KW)
-        assert tr.dist_on and tr.world == 2 and len(tr.buckets) == model.text_model.config.num_hidden_layers
+        assert tr.dist_on and tr.world == 2 and len(tr.buckets) == model.text_model.config.num_hidden_layers and tr.dp_mode == mode
         fired, spans = [], []
         orig_done, orig_ar = tr._layer_done, dp.allreduce_tensor
         tr._layer_done = lambda i: (fired.append((tr.micro, i)), orig_done(i))[1]
@@ -74,6 +74,7 @@ def _worker(rank, world, port, outdir, merge=False):
         for i, b in enumerate(bs):
             # merge: the two micro-batches of a window run as one pass (micro_step(upcoming=...)); the hooks then fire in that pass
             losses.append(float(tr.micro_step(b, upcoming=bs[i + 1:] if merge else None).item()))
+        tr.gather_sharded_state()           # (sharded mode: the fp32 state is current inside each rank's shards only)
         torch.cuda.synchronize()
         torch.save({"master": tr.master.cpu(), "geom_master": tr.geom_master.cpu(), "flat_w": model.text_model.flat_w.cpu(),
                     "fired": fired, "spans": spans, "losses": losses, "opt_step": tr.opt_step,
@@ -82,10 +83,12 @@ def _worker(rank, world, port, outdir, merge=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("merge", [False, True])
-def test_stage1_trainer_two_ranks_equal_single_rank(tmp_path, merge):
+@pytest.mark.parametrize("merge,mode", [(False, "allreduce"), (True, "allreduce"), (False, "sharded"), (True, "sharded")])
+def test_stage1_trainer_two_ranks_equal_single_rank(tmp_path, merge, mode):
+    """mode "sharded" (dp.py: reduce-scatter of every bucket, clipping + AdamW on each rank's half, all-gather of the updated weights)
+    must leave both ranks with the same weights as the all-reduce mode's replicated step - and so as the single-process run."""
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), merge), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), merge, mode), nprocs=world, join=True)
     r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=False) for i in range(world)]
     # identical replicas after two optimiser steps
     assert r[0]["opt_step"] == r[1]["opt_step"] == 2
@@ -98,8 +101,13 @@ def test_stage1_trainer_two_ranks_equal_single_rank(tmp_path, merge):
         bm = (0, 2) if merge else (1, 3)
         assert sorted(r[i]["fired"]) == sorted([(m, l) for m in bm for l in range(nb)]), (i, r[i]["fired"])
         # collectives per optimiser step: one per layer bucket + embedding + geom_head (+count slot), same on both ranks
-        per_step = [s for s in r[i]["spans"] if s[0] == bm[0]]
-        assert len(per_step) == nb + 2 and any(n == r[i]["geom_n"] for _, n in per_step), per_step
+        # (merged: the bucket all-reduces fire in the pass, at micro index 0; the embedding / geom_head ones with the optimiser step,
+        # which runs with the call that returns the window's LAST loss, micro index 1)
+        per_step = [s for s in r[i]["spans"] if s[0] in ((bm[0], bm[0] + 1) if merge else (bm[0],))]
+        if mode == "allreduce":
+            assert len(per_step) == nb + 2 and any(n == r[i]["geom_n"] for _, n in per_step), per_step
+        else:                     # sharded: only the replicated tails, the geom_head gradient and the norm scalar are all-reduced
+            assert any(n == r[i]["geom_n"] for _, n in per_step) and any(n == 1 for _, n in per_step), per_step
     assert [s[1] for s in r[0]["spans"]] == [s[1] for s in r[1]["spans"]]
     assert np.isnan(r[1]["losses"][1]) and np.isnan(r[0]["losses"][2]) and np.isfinite(r[0]["losses"][0])
 
@@ -127,3 +135,43 @@ def test_stage1_trainer_two_ranks_equal_single_rank(tmp_path, merge):
     dg_dp = r[0]["geom_master"] - g0.cpu()
     assert dg_dp.abs().max() > 0                                # geom_head gradients were reduced and applied
     assert ((dg_dp - dg_single).norm() / dg_single.norm()).item() < 5e-2
+
+
+def test_bench_two_ranks_gloo_on_one_gpu():
+    """bench.py's N > 1 path end to end without an 8-GPU node: two fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    the environment, as torch.distributed.run sets them; started before anything in them touches the GPU) share the box's one card and
+    exchange gradients over gloo (VQ3_DIST_BACKEND=gloo; RCCL refuses two ranks on one device). Rank 0 must print exactly one JSON line
+    with n_gpus = 2, a whole-job value, the schedule variants and the all-reduce fields measured with HIP events on the communication
+    stream; rank 1 prints none; both exit 0 (matched collectives: a mismatch would hang until the timeout). 2 Qwen3 layers: plumbing,
+    not a measurement (the line says valid: false)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    port = _free_port()
+    base = dict(os.environ, VQ3_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
+                HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--layers", "2",
+           "--no-trim-variant", "--no-cpu-baseline"]
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              cwd=str(root), text=True) for r in range(2)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=900))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, (r, outs[r][1][-2000:])
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    lines1 = [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not lines1
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 12 and d["value"] > 0 and d["config"]["valid"] is False
+    c = d["comm"]
+    assert c and c["allreduce_ms_per_opt_step"] > 0 and c["allreduce_bytes_per_opt_step"] > 0 and c["bus_gb_per_s"] > 0
+    assert d["accum1_variant"]["comm"]["collectives_per_opt_step"] >= 2 and d["text_group_1_variant"]["value"] > 0

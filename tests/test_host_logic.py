@@ -113,6 +113,49 @@ def test_bucketed_allreduce_world2_gloo():
     assert all(ret[r][0] and ret[r][1] for r in range(world)), dict(ret)
 
 
+def _dp_shard_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vggt_qwen3_amd import dp
+        table, total = _fake_table()
+        buckets, emb = dp.plan_buckets(table, 6, 4)
+        g = [torch.randn(total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        ref = sum(g)
+        flat = g[rank].clone()
+        ok = True
+        spans = list(buckets.values()) + [emb, (7, 7 + 3 * world * dp.SHARD_ALIGN + 5)]      # (+ a span with a ragged tail; overlaps: reset below)
+        for lo, hi in spans[:-1]:
+            dp.reduce_scatter_span(flat, lo, hi, rank, world)
+            s, tail = dp.shard_layout(lo, hi, world)
+            assert s % dp.SHARD_ALIGN == 0 and lo + world * s == tail <= hi and hi - tail < world * dp.SHARD_ALIGN + world
+            mine = slice(lo + rank * s, lo + (rank + 1) * s)
+            ok = ok and torch.allclose(flat[mine], ref[mine], atol=1e-6) and torch.allclose(flat[tail:hi], ref[tail:hi], atol=1e-6)
+            flat[lo:tail] = float("nan")                     # only this rank's shard may be relied on ...
+            flat[mine] = ref[mine]
+            dp.all_gather_span(flat, lo, hi, rank, world)    # ... and the gather restores every shard on every rank
+            ok = ok and torch.allclose(flat[lo:hi], ref[lo:hi], atol=1e-6)
+        lo, hi = spans[-1]
+        flat = g[rank].clone()
+        dp.reduce_scatter_span(flat, lo, hi, rank, world)
+        s, tail = dp.shard_layout(lo, hi, world)
+        ok = ok and s == 3 * dp.SHARD_ALIGN and hi - tail == 5 and torch.allclose(flat[tail:hi], ref[tail:hi], atol=1e-6)
+        ok = ok and torch.allclose(flat[lo + rank * s: lo + (rank + 1) * s], ref[lo + rank * s: lo + (rank + 1) * s], atol=1e-6)
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduce_scatter_all_gather_world2_gloo():
+    """dp.reduce_scatter_span + dp.all_gather_span (the opt-in exchange of Stage1Trainer(dp_mode="sharded")) over every bucket of the
+    plan: each rank ends up with the all-reduce's sum in its shard and in the replicated tail, and the gather makes the span whole."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_shard_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
+
+
 def test_checkpoint_layout_and_search_order(tmp_path):
     """File layout / index / search order of vggt_qwen3_amd.checkpoint (reference: qa_inference.py:51-105), on a small
     stand-in module (no GPU): sharded dir wins over flat files, legacy dir name accepted, first flat file otherwise."""

@@ -59,6 +59,25 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restr
   }
 }
 
+// ---------------------------------------------------------------- GELU (erf form) backward: dz = dh * (Phi(z) + z * phi(z))
+// z = the bf16 pre-activation the forward GEMM rounded before applying GELU (projector_perceiver.py:35-37 under autograd).
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ z, bf16_t* __restrict__ dz,
+                                                       long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(dh + i * 8);
+    const bf16x8 zz = *reinterpret_cast<const bf16x8*>(z + i * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float zf = bf2f((bf16_t)zz[j]), df = bf2f((bf16_t)d[j]);
+      const float cdf = 0.5f * (1.f + erff(zf * 0.70710678118654752440f));
+      const float pdf = 0.39894228040143267794f * __expf(-0.5f * zf * zf);
+      o[j] = (short)f2bf(df * (cdf + zf * pdf));
+    }
+    *reinterpret_cast<bf16x8*>(dz + i * 8) = o;
+  }
+}
+
 // ---------------------------------------------------------------- transpose (64x64 tiles through LDS)
 // 16-byte global loads and stores on both sides when the leading dimensions allow (vec != 0), scalar at the edges.
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R,
@@ -468,6 +487,15 @@ extern "C" int vq3_silu_mul_bwd(const void* dact, const void* gu, void* dgu, int
   hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(flat_grid(rows * (inter / 8), 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dact, (const bf16_t*)gu, (bf16_t*)dgu, (long)rows, inter);
   VQ3_CHECK_LAUNCH("silu_mul_bwd");
+  return 0;
+}
+
+extern "C" int vq3_gelu_bwd(const void* dh, const void* z, void* dz, int64_t n, void* stream) {
+  VQ3_CHECK_ARG(dh && z && dz && n > 0 && n % 8 == 0, "gelu_bwd: n must be a positive multiple of 8");
+  VQ3_CHECK_ARG((((uintptr_t)dh | (uintptr_t)z | (uintptr_t)dz) % 16) == 0, "gelu_bwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(flat_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, (const bf16_t*)z,
+                     (bf16_t*)dz, (long)(n / 8));
+  VQ3_CHECK_LAUNCH("gelu_bwd");
   return 0;
 }
 

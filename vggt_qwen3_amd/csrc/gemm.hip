@@ -274,6 +274,7 @@ int launch_candidate(GemmParams p, int cand, int transA, int transB, int nbatch,
   if (cand >= 100) return launch_gemm_v3(p, transA, transB, cand - 100, nbatch, s);
   if (cand == 30) return launch_split_rows(p, nbatch, s);
   if (cand >= 20 && cand <= 22) return launch_gemm_v6(p, cand - 20, nbatch, s);
+  if (cand == 23) return launch_gemm_v8(p, nbatch, s);          // (-1: outside its contract - the tuner skips it)
   return launch_gemm_v2(p, cand, nbatch, s);
 }
 
@@ -372,6 +373,8 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   p.act = d->act; p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.alpha = d->alpha;
   p.kper = d->K; p.nsplit = 1;
   p.epi = 0;
+  p.stamps = nullptr;
+  p.nbw = 1;
   if (ve) {
     VQ3_CHECK_ARG(ve->Q && ve->K && ve->V, "gemm_vit_qkv: null output pointer");
     VQ3_CHECK_ARG(!d->transA && !d->transB && d->K % BK == 0 && !d->out_f32 && !d->accumulate && !d->R && !d->colscale && d->act == 0 &&
@@ -458,7 +461,18 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     if ((long)((d->M + 255) / 256) * ((d->N + 127) / 128) * nbatch >= 64) cands.push_back(21);
     if ((long)((d->M + 127) / 128) * ((d->N + 255) / 256) * nbatch >= 64) cands.push_back(22);
     if (split_rows_main(p, nbatch)) cands.push_back(30);
+    // the overlapped-epilogue kernel pays where a tile has few K steps for its epilogue: short K, enough tiles for every CU
+    if (d->K <= 2048 && (long)((d->M + 127) / 128) * ((d->N + 255) / 256) >= 2 * num_cus()) cands.push_back(23);
     cfg = tuned_choice(p, 0, 0, nbatch, s, cands, cfg);
+  }
+  if (cfg == 23) {
+    const int rc = launch_gemm_v8(p, nbatch, s);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      VQ3_CHECK_LAUNCH("gemm_bf16_nt(v8)");
+      return 0;
+    }
+    cfg = choose_config(d->M, d->N, d->K, nbatch) == 23 ? 13 : 13;      // outside v8's contract: a kernel that takes everything
   }
   if (cfg == 30) {
     const int rc = launch_split_rows(p, nbatch, s);
@@ -525,7 +539,7 @@ extern "C" int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* d, const void* gu, void*
 extern "C" int vq3_gemm_tile_order(int32_t M, int32_t N, int32_t bm, int32_t bn, int32_t wg_per_cu, int32_t* xm_out, int32_t* band_out,
                                    int32_t* order) {
   VQ3_CHECK_ARG(M > 0 && N > 0 && bm > 0 && bn > 0 && wg_per_cu >= 1, "gemm_tile_order: bad arguments");
-  GemmParams p;
+  GemmParams p{};
   p.M = M; p.N = N;
   p.mtiles = (M + bm - 1) / bm;
   p.ntiles = (N + bn - 1) / bn;

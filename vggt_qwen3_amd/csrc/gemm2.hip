@@ -316,6 +316,10 @@ int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream) {
     // round lasts as long as its slowest tile either way), so the tuner does not list them; kept for vq3_gemm_force_config
     case 15: return launch_cfg<224, 128, 2, 4, 3, 2>(p, nbatch, stream);
     case 16: return launch_cfg<192, 128, 2, 4, 3, 2>(p, nbatch, stream);
+    // 192 x 128, FOUR waves (96 x 64 each: 0.42 KB of LDS per MFMA), 2 stages = 80 KiB: TWO workgroups per CU, each one wave per SIMD.
+    // At K = 1024 a tile's epilogue (staging C through LDS + the row stores: 8-9 us of a 24 us tile on the 8-wave kernels, during which
+    // the MFMA pipe idles - tools/gemm_stamps.py) runs under the co-resident workgroup's main loop; M = 49 392 = 257.25 x 192.
+    case 17: return launch_cfg<192, 128, 2, 2, 2>(p, nbatch, stream);
     default: return launch_cfg<128, 128, 4, 2, 5, 2>(p, nbatch, stream);
   }
 }

@@ -29,11 +29,25 @@ constexpr int BK6 = 64;
 constexpr int HALF = 128 * 128;          // bytes per half-tile (128 rows x 64 k)
 
 #define V6_FENCE() asm volatile("" ::: "memory")
+// diagnostic stamps (p.stamps != nullptr only under tools/gemm_stamps.py): wall clock (100 MHz) of thread 0 at the marks of one tile
+#define V6_STAMP(IDX)                                                                           \
+  do {                                                                                          \
+    if (p.stamps && tid == 0) {                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+      p.stamps[(long)tile * 8 + (IDX)] = __builtin_amdgcn_s_memrealtime();                      \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+    }                                                                                           \
+  } while (0)
 
 // AH / BH = number of 128-row half-tiles of A / B per K tile: (2,2) = 256x256 (4 phases per K tile), (2,1) = 256x128 and
 // (1,2) = 128x256 (2 phases per K tile, same 16 MFMAs per phase and wave).
-template <int AH, int BH, bool OUT_F32>
+// EK = epilogue kind, one instantiation each: 0 = plain C epilogue (alpha / bias / activation / LayerScale / residual / accumulate / output
+// statistics), 3 = the same behind a folded LayerNorm (p.ln_in), 1 = fused q|k|v epilogue (LayerNorm fold optional), 2 = SwiGLU backward.
+// Compiled into ONE kernel they cost the 256 x 256 instantiation (256 VGPRs) 80 spilled registers in every launch's epilogue: the plain
+// fc1 launch (49 392 x 4096 x 1024) took 524 us with them and 443 us without (tools/gemm_stamps.py: "stage C" 13.1 -> 6.6 us per tile).
+template <int AH, int BH, bool OUT_F32, int EK = 0>
 __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
+  constexpr bool HAS_LN = (EK == 1 || EK == 3);
   constexpr int BM = 128 * AH, BN = 128 * BH;
   constexpr int NSLOT = AH + BH;
   constexpr int BUF = NSLOT * HALF;
@@ -151,7 +165,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   int tile = blockIdx.x;           // (< ntile: the grid never exceeds the tile count)
   do {                             // one pass for the 256 x 256 kernel (PERSIST is a compile-time false there: no loop is generated)
   tile_coords_id(p, tile, BM, BN, m0, n0);
-  if (LN_EARLY && p.ln_in && tid < BM) ln_row(p, m0 + tid, ln_mu, ln_rs);
+  V6_STAMP(0);
+  if (p.stamps && tid == 0)
+    p.stamps[(long)tile * 8 + 7] = ((unsigned long long)blockIdx.x << 32) | __builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, 4 bits */);
+  if (HAS_LN && LN_EARLY && p.ln_in && tid < BM) ln_row(p, m0 + tid, ln_mu, ln_rs);
 #pragma unroll
   for (int i = 0; i < AH * 4; ++i)
 #pragma unroll
@@ -188,6 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
     V6_FENCE();
     __builtin_amdgcn_sched_barrier(0);
   }
+  V6_STAMP(1);      // first operands have landed: main loop starts
 
   auto ktile = [&](int t, char* cur, char* nxt) {
     const bool s1 = t + 1 < nt, s2 = t + 2 < nt;
@@ -284,34 +302,42 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   }
 
   // ---- epilogue
+  V6_STAMP(2);      // main loop done
   const int next_tile = tile + (int)gridDim.x;
   const bool more = PERSIST && next_tile < ntile;
-  if (!OUT_F32 && staged_ok(p, coff, roff)) {
+  if constexpr (!OUT_F32) {      // (the host launches the bf16 instantiations only when host_staged_ok holds)
     // through LDS (the operand buffers are dead: every wave passed the last phase's barrier), out as whole rows
-    if (p.ln_in) {      // folded LayerNorm: rstd (acc - mu c) per lane-owned row, before the usual epilogue
-      // Register-frugal on purpose (this kernel sits at 256 VGPRs): the statistics are fetched here, one thread per tile row, not at
-      // the kernel's start, and a row's (mu, rstd) pair is applied as it is read back - only the four colsum quads stay live.
+    // folded LayerNorm: rstd (acc - mu c) per lane-owned row, before the usual epilogue. The 256 x 256 kernel keeps the rows' (mu, rstd)
+    // pairs in 2 KiB of LDS ABOVE the C image (its 128 KiB operand buffers are all the image needs) and applies them quad by quad inside
+    // the staging loop: as a pass of its own over the 128 accumulator registers it spilled 80 of them in every launch. The two-phase
+    // variants (64 accumulator registers, LDS full at 160 KiB) pass the pairs through the C image's space first.
+    constexpr bool LN_FUSED = HAS_LN && (AH + BH == 4);
+    const bool ln_on = HAS_LN && p.ln_in;
+    const float2* lnp = reinterpret_cast<const float2*>(smem + 2 * BUF);      // (LN_FUSED only)
+    f32x4 cc[BH * 2];
+    if (ln_on) {
       __syncthreads();                                       // operand buffers are dead for every wave
       if (tid < BM) {
         float mu_t = ln_mu, rs_t = ln_rs;
         if (!LN_EARLY) ln_row(p, m0 + tid, mu_t, rs_t);
-        reinterpret_cast<float2*>(smem_c)[tid] = float2{mu_t, rs_t};
+        reinterpret_cast<float2*>(LN_FUSED ? smem + 2 * BUF : smem_c)[tid] = float2{mu_t, rs_t};
       }
-      f32x4 cc[BH * 2];
 #pragma unroll
       for (int j = 0; j < BH; ++j)
 #pragma unroll
         for (int nt2 = 0; nt2 < 2; ++nt2) cc[j * 2 + nt2] = ln_colsum(p, n0 + j * 128 + wc * 32 + nt2 * 16 + 4 * fq);
       __syncthreads();
+      if (!LN_FUSED) {
 #pragma unroll
-      for (int i = 0; i < AH; ++i)
+        for (int i = 0; i < AH; ++i)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const float2 v = reinterpret_cast<const float2*>(smem_c)[i * 128 + wr * 64 + mt * 16 + fr];
+          for (int mt = 0; mt < 4; ++mt) {
+            const float2 v = reinterpret_cast<const float2*>(smem_c)[i * 128 + wr * 64 + mt * 16 + fr];
 #pragma unroll
-          for (int q = 0; q < BH * 2; ++q) acc[i * 4 + mt][q] = ln_apply(acc[i * 4 + mt][q], v.x, v.y, cc[q]);
-        }
-      __syncthreads();                                       // before the C image overwrites the pairs
+            for (int q = 0; q < BH * 2; ++q) acc[i * 4 + mt][q] = ln_apply(acc[i * 4 + mt][q], v.x, v.y, cc[q]);
+          }
+        __syncthreads();                                       // before the C image overwrites the pairs
+      }
       __builtin_amdgcn_sched_barrier(0);                     // (keeps the bias / LayerScale loads below from being hoisted into this block)
     }
     f32x4 bias_r[BH][2], cs_r[BH][2];
@@ -335,19 +361,35 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       if (nt > 1) stage_tile(1, smem + BUF);
       __builtin_amdgcn_sched_barrier(0);
     }
+    auto stage_all = [&](auto act_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int i = 0; i < AH; ++i)
+      for (int i = 0; i < AH; ++i)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt) {
+          float2 lv = float2{0.f, 1.f};
+          if (LN_FUSED && ln_on) lv = lnp[i * 128 + wr * 64 + mt * 16 + fr];
 #pragma unroll
-        for (int j = 0; j < BH; ++j)
+          for (int j = 0; j < BH; ++j)
 #pragma unroll
-          for (int nt2 = 0; nt2 < 2; ++nt2)
-            stage_quad<BN>(p, smem_c, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq,
-                           acc[i * 4 + mt][j * 2 + nt2], bias_r[j][nt2], cs_r[j][nt2]);
+            for (int nt2 = 0; nt2 < 2; ++nt2) {
+              f32x4 a = acc[i * 4 + mt][j * 2 + nt2];
+              if (LN_FUSED && ln_on) a = ln_apply(a, lv.x, lv.y, cc[j * 2 + nt2]);
+              stage_quad<BN, ACT>(p, smem_c, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq, a, bias_r[j][nt2], cs_r[j][nt2]);
+            }
+          if (LN_FUSED) __builtin_amdgcn_sched_barrier(0);      // one 16-row group at a time (register pressure)
+        }
+    };
+    // the activation is dispatched ONCE (the fused q|k|v and SwiGLU-backward epilogues never carry one)
+    if (EK != 1 && EK != 2 && p.act == 1) stage_all(std::integral_constant<int, 1>{});
+    else if (EK != 1 && EK != 2 && p.act == 2) stage_all(std::integral_constant<int, 2>{});
+    else stage_all(std::integral_constant<int, 0>{});
+    V6_STAMP(6);    // this wave's quads are in the C image
     if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's K tiles 0 and 1 has landed
     __syncthreads();
-    staged_store<BM, BN>(p, smem_c, coff, roff, m0, n0, tid, 512);
+    V6_STAMP(3);    // C image staged (and the next tile's first operands landed)
+    staged_store<BM, BN, (EK == 3 ? 0 : EK)>(p, smem_c, coff, roff, m0, n0, tid, 512);
+    V6_STAMP(4);    // row stores issued
   } else {
     if (more) {
       int nm0, nn0;
@@ -374,6 +416,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
     if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   prefetched = more;
+  if (p.stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (diagnostic only: thread 0's own stores have been acknowledged)
+    p.stamps[(long)tile * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+  }
   if (more) __syncthreads();      // everybody's DMA pieces are visible; the C image's readers are done before K tile 2 lands on it
   tile = next_tile;
   } while (PERSIST && tile < ntile);
@@ -382,18 +428,23 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
 template <int AH, int BH>
 int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
   // (two-phase variants: two K-tile buffers of the NEXT tile + the C image of the current one, or three K-tile buffers: 160 KiB)
-  constexpr int SMEM = (AH + BH == 4) ? 2 * 4 * HALF : 2 * 3 * HALF + 128 * AH * 128 * BH * 2;
+  constexpr int SMEM = (AH + BH == 4) ? 2 * 4 * HALF + 2048 : 2 * 3 * HALF + 128 * AH * 128 * BH * 2;   // (+ 2 KiB: LayerNorm pairs above the C image)
   static_assert(SMEM <= 160 * 1024 && (AH + BH == 4 || SMEM >= 3 * (AH + BH) * HALF), "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       vq3_set_error("gemm v6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
       return 2;
     }
     attr_done = true;
   }
+  // bf16 output that cannot take the LDS-staged epilogue (rows not 16-byte aligned): the loader-ring kernel keeps the per-quad path
+  if (!p.out_f32 && !host_staged_ok(p)) return launch_gemm_v2(p, AH == 2 ? 11 : 13, nbatch, stream);
   p.mtiles = (p.M + 128 * AH - 1) / (128 * AH);
   p.ntiles = (p.N + 128 * BH - 1) / (128 * BH);
   choose_tile_order(p, 128 * AH, 128 * BH, 1);
@@ -404,14 +455,21 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
     (void)hipGetLastError();
     ncu = n / 8 * 8;                 // persistent workgroups stride over the tile order by a multiple of 8: they stay on their XCD's slice
   }
+  if (const char* sp = getenv("VQ3_GEMM_STAMP_PTR")) p.stamps = (unsigned long long*)strtoull(sp, nullptr, 0);   // diagnostics only
   int nwg = p.mtiles * p.ntiles;
   if (AH + BH < 4 && nwg > ncu && getenv("VQ3_V6_PERSIST") == nullptr) nwg = ncu;      // (VQ3_V6_PERSIST=0: one tile per workgroup, for A/B runs)
   else if (AH + BH < 4 && nwg > ncu && atoi(getenv("VQ3_V6_PERSIST")) != 0) nwg = ncu;
   dim3 grid(nwg, 1, nbatch);
   if (p.out_f32)
-    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, true>), grid, dim3(512), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, true, 0>), grid, dim3(512), SMEM, stream, p);
+  else if (p.epi == 1)
+    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false, 1>), grid, dim3(512), SMEM, stream, p);
+  else if (p.epi == 2)
+    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false, 2>), grid, dim3(512), SMEM, stream, p);
+  else if (p.ln_in)
+    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false, 3>), grid, dim3(512), SMEM, stream, p);
   else
-    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false>), grid, dim3(512), SMEM, stream, p);
+    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false, 0>), grid, dim3(512), SMEM, stream, p);
   return 0;
 }
 

@@ -51,6 +51,8 @@ struct GemmParams {
   // ... and produced for the NEXT LayerNorm by the GEMM that writes its input: per row and 128 output columns the (sum, sum of squares)
   // of the stored bf16 values, st_out [M, N / 128, 2] (N % 128 == 0, every slot written by exactly one thread: no atomics, no zeroing)
   float* st_out;
+  // diagnostics (tools/gemm_stamps.py; null in production): per tile 8 x u64 of s_memrealtime / s_memtime stamps, written by thread 0
+  unsigned long long* stamps;
 };
 
 // row statistics of the folded LayerNorm (contraction length K is the normalised width)
@@ -324,9 +326,13 @@ __device__ __forceinline__ int cstage_off(int row, int chunk) {
 
 // phase 1, per lane-owned quad (tile-local row ml, column nl..nl+3): same arithmetic and rounding points as store_quad_pre up
 // to (and including) LayerScale; bias_v / cs_v are the lane's column vectors (prefetched), ignored when p.bias / p.colscale is null
-template <int BN>
+// ACT >= 0: the activation is a compile-time constant (the caller dispatches on p.act ONCE, outside its quad loops: with the run-time
+// form every one of a thread's 32 quads carries all three activation bodies, and the 256 x 256 kernel's epilogue was 22 000 instructions
+// for an 8 000-instruction instruction cache line budget); -1: run-time p.act
+template <int BN, int ACT = -1>
 __device__ __forceinline__ void stage_quad(const GemmParams& p, char* smem, int ml, int nl, const f32x4& a, const f32x4& bias_v,
                                            const f32x4& cs_v) {
+  const int act = ACT >= 0 ? ACT : p.act;
   float v[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
@@ -336,12 +342,12 @@ __device__ __forceinline__ void stage_quad(const GemmParams& p, char* smem, int 
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-  if (p.act == 1) {
+  if (act == 1) {
     const f32x2_t g0 = gelu_erf2(f32x2_t{v[0], v[1]}), g1 = gelu_erf2(f32x2_t{v[2], v[3]});
     v[0] = rbf(g0[0]); v[1] = rbf(g0[1]); v[2] = rbf(g1[0]); v[3] = rbf(g1[1]);
-  } else if (p.act) {
+  } else if (act) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = rbf(apply_act(v[r], p.act));
+    for (int r = 0; r < 4; ++r) v[r] = rbf(apply_act(v[r], act));
   }
   if (p.colscale) {
 #pragma unroll
@@ -359,15 +365,16 @@ __device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* s
 // phase 2 (after a workgroup barrier): `nthreads` threads (tid 0 .. nthreads-1) move the BM x BN image out as whole rows,
 // adding the residual (rounded, as PyTorch's bf16 add) and / or the old C (accumulate) on the way. Needs p.vec_ok, ldc % 8 == 0
 // and a 16-byte aligned C (checked by staged_ok on the host side of the kernel).
-template <int BM, int BN>
+// EPIK >= 0: only that epilogue kind is compiled in (the caller guarantees p.epi == EPIK); -1: run-time dispatch
+template <int BM, int BN, int EPIK = -1>
 __device__ __forceinline__ void staged_store(const GemmParams& p, const char* smem, long coff, long roff, int m0, int n0, int tid,
                                              int nthreads) {
   constexpr int CPR = BN / 8;                  // 16-byte chunks per row
-  if (p.epi == 1) {
+  if ((EPIK < 0 || EPIK == 1) && p.epi == 1) {
     vit_qkv_store<BM, BN>(p, smem, m0, n0, tid, nthreads);
     return;
   }
-  if (p.epi == 2) {
+  if ((EPIK < 0 || EPIK == 2) && p.epi == 2) {
     // SwiGLU backward on the way out (modeling_qwen3.py:81-83 under autograd): the tile is d(act) = d(silu(g) * u); with the saved
     // g | u rows read the same coalesced way it leaves as dg = d * u * silu'(g) and du = d * silu(g) - arithmetic of silu_mul_bwd_kernel
     constexpr int CPR2 = BN / 8;
@@ -585,6 +592,13 @@ __device__ __forceinline__ bool staged_ok(const GemmParams& p, long coff, long r
          (!p.R || ((p.ldr % 8 == 0) && (roff % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.R) & 15) == 0)));
 }
 
+// host twin of staged_ok for every batch index (the v6 kernels compile ONLY the staged bf16 epilogue: gemm6.hip routes the rest elsewhere)
+inline bool host_staged_ok(const GemmParams& p) {
+  return !p.out_f32 && p.nsplit == 1 && p.vec_ok && (p.ldc % 8 == 0) && (p.sC1 % 8 == 0) && (p.sC2 % 8 == 0) &&
+         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+         (!p.R || ((p.ldr % 8 == 0) && (p.sR1 % 8 == 0) && (p.sR2 % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.R) & 15) == 0)));
+}
+
 // host: pick the XCD blocking (xm) and the band width (nbw) of the walk for a tile grid. Model of the bytes one XCD pulls through
 // the fabric: its rectangle is mR x nR tiles, `conc` of them in flight together as a (conc / nbw) x nbw block; a row panel of A
 // (BM x K) is fetched once per band it appears in, a panel of B (BN x K) once per block row of a band (nothing is assumed to survive
@@ -629,6 +643,9 @@ inline void choose_tile_order(GemmParams& p, int BM, int BN, int wg_per_cu) {
 int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream);
 // v6 (256x256 tile, 8-phase schedule, NT, K % 64 == 0), defined in gemm6.hip.
 int launch_gemm_v6(GemmParams& p, int shape, int nbatch, hipStream_t stream);   // shape: 0 = 256x256, 1 = 256x128, 2 = 128x256
+// v8 (128x256 tile, compute / service wave teams, row-wise epilogue under the next tile's main loop), defined in gemm8.hip.
+// Returns -1 (nothing launched) when the problem is outside its contract: the caller picks another kernel.
+int launch_gemm_v8(GemmParams& p, int nbatch, hipStream_t stream);
 // v3 (any operand layout, K % 8 == 0), defined in gemm3.hip. nstage: 2 or 3.
 int launch_gemm_v3(GemmParams& p, int transA, int transB, int nstage, int nbatch, hipStream_t stream);
 

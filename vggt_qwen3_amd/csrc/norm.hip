@@ -333,6 +333,136 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
   }
 }
 
+// ---------------------------------------------------------------- LayerNorm backward (Perceiver "train_projector" mode)
+// y = xhat * w + b, xhat = (x - mean) * rstd over a row of `cols` f32 values (torch.nn.LayerNorm under autograd). One wave per row,
+// the row in registers (NCH chunks of 4 values per lane); statistics recomputed from x (two-pass, as the forward kernel does):
+//   g = dy * w;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dw_part[blk] = sum_rows dy * xhat;  db_part[blk] = sum_rows dy
+// A workgroup (4 waves) walks LNB_ROWS rows and leaves ONE partial row of dw / db (plain stores, every slot written): reduce them
+// with vq3_colsum_f32.
+constexpr int LNB_ROWS = 16;
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ w, float* __restrict__ dx,
+                                                            float* __restrict__ dw_part, float* __restrict__ db_part, long rows,
+                                                            int cols, float eps) {
+  extern __shared__ float lnb_red[];               // [2][cols]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float aw[NCH][4], ab[NCH][4];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { aw[c][j] = 0.f; ab[c][j] = 0.f; }
+  const float inv = 1.f / (float)cols;
+  for (int rr = wid; rr < LNB_ROWS; rr += 4) {
+    const long row = (long)blockIdx.x * LNB_ROWS + rr;
+    if (row >= rows) break;
+    float xv[NCH][4], gv[NCH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < cols) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * (long)cols + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xv[c][j] = v[j]; s += v[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[c][j] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) * inv;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < cols) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xv[c][j] -= mean; sq = fmaf(xv[c][j], xv[c][j], sq); }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < cols) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * (long)cols + col);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xv[c][j] *= rstd;                         // xhat
+          gv[c][j] = d[j] * wv[j];
+          sg += gv[c][j];
+          sgx = fmaf(gv[c][j], xv[c][j], sgx);
+          aw[c][j] = fmaf(d[j], xv[c][j], aw[c][j]);
+          ab[c][j] += d[j];
+        }
+      }
+    }
+    const float mg = wave_sum(sg) * inv, mgx = wave_sum(sgx) * inv;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < cols) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[c][j] - mg - xv[c][j] * mgx);
+        *reinterpret_cast<f32x4*>(dx + row * (long)cols + col) = o;
+      }
+    }
+  }
+  // combine the four waves' partial column sums (the waves add into one [2][cols] LDS image in turn), one partial row per workgroup
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (wid == k) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = (c * 64 + lane) * 4;
+        if (col < cols) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            lnb_red[col + j] = (k ? lnb_red[col + j] : 0.f) + aw[c][j];
+            lnb_red[cols + col + j] = (k ? lnb_red[cols + col + j] : 0.f) + ab[c][j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int col = threadIdx.x; col < cols; col += 256) {
+    dw_part[(long)blockIdx.x * cols + col] = lnb_red[col];
+    db_part[(long)blockIdx.x * cols + col] = lnb_red[cols + col];
+  }
+}
+
+// out_f32[c] (+)= sum_r part[r][c]  (the f32 twin of colsum_kernel: the Perceiver's parameters and gradients are fp32)
+__global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* __restrict__ part, int nrows, int cols, float* __restrict__ out,
+                                                          int accumulate) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    int r = rg;
+    for (; r + 48 < nrows; r += 64) {
+      a0 += part[(long)r * cols + c];
+      a1 += part[(long)(r + 16) * cols + c];
+      a2 += part[(long)(r + 32) * cols + c];
+      a3 += part[(long)(r + 48) * cols + c];
+    }
+    for (; r < nrows; r += 16) a0 += part[(long)r * cols + c];
+  }
+  red[rg][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[i][lane];
+    if (accumulate) v += out[c];
+    out[c] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int vq3_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int32_t cols,
@@ -469,6 +599,29 @@ extern "C" int vq3_colsum_multi(const vq3_colsum_job* jobs, int32_t njobs, void*
   if (nsplit > 1 && (maxcols > CS_MAX_COLS || !colsum_scratch((hipStream_t)stream, &j.scratch, &j.tickets))) nsplit = 1;
   hipLaunchKernelGGL(colsum_multi_kernel, dim3((maxcols + 63) / 64, njobs, nsplit), dim3(1024), 0, (hipStream_t)stream, j);
   VQ3_CHECK_LAUNCH("colsum_multi");
+  return 0;
+}
+
+extern "C" int vq3_layernorm_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw_part, float* db_part,
+                                 int64_t rows, int32_t cols, float eps, void* stream) {
+  VQ3_CHECK_ARG(dy && x && w && dx && dw_part && db_part, "layernorm_bwd: null pointer (dw_part / db_part: ceil(rows / 16) * cols floats each)");
+  VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 4096, "layernorm_bwd: cols=%d must be a multiple of 4, <= 4096", cols);
+  VQ3_CHECK_ARG((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) % 16) == 0, "layernorm_bwd: pointers must be 16-byte aligned");
+  const long nblk = (rows + LNB_ROWS - 1) / LNB_ROWS;
+  const size_t smem = (size_t)2 * cols * sizeof(float);
+#define VQ3_LNB(N)                                                                                                          \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<N>), dim3((unsigned)nblk), dim3(256), smem, (hipStream_t)stream, dy, x, w, dx, dw_part, \
+                     db_part, (long)rows, cols, eps)
+  if (cols <= 1024) VQ3_LNB(4); else if (cols <= 2048) VQ3_LNB(8); else VQ3_LNB(16);
+#undef VQ3_LNB
+  VQ3_CHECK_LAUNCH("layernorm_bwd");
+  return 0;
+}
+
+extern "C" int vq3_colsum_f32(const float* part, int32_t nrows, int32_t cols, float* out_f32, int32_t accumulate, void* stream) {
+  VQ3_CHECK_ARG(part && out_f32 && nrows > 0 && cols > 0, "colsum_f32: bad args");
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, nrows, cols, out_f32, accumulate);
+  VQ3_CHECK_LAUNCH("colsum_f32");
   return 0;
 }
 

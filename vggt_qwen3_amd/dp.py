@@ -65,6 +65,52 @@ def allreduce_span(flat: torch.Tensor, lo: int, hi: int, group=None, async_op: b
     return allreduce_tensor(flat[lo:hi], group=group)
 
 
+# ---- opt-in: reduce-scatter + all-gather (Stage1Trainer(dp_mode="sharded")) ---------------------------------------------------
+# The same bytes as the all-reduce cross xGMI (a ring all-reduce IS a reduce-scatter followed by an all-gather), but the two halves
+# are separate collectives with the optimiser between them: every rank clips and runs AdamW on 1/world of each bucket only (the
+# 19 ms HBM-bound AdamW pass of the replicated design becomes 19 / world ms) and all-gathers the updated bf16 WEIGHTS instead of the
+# summed gradients. What matters at grad_accum 1, where the exchange is paid every micro-batch (SURVEY.md 8(d) C3).
+SHARD_ALIGN = 64        # elements: shard boundaries stay 128-byte aligned (the fused AdamW kernel's vector width and more)
+
+
+def shard_layout(lo: int, hi: int, world: int):
+    """[lo, hi) = world equal shards of `s` elements (s a multiple of SHARD_ALIGN) + a replicated tail [lo + world * s, hi)."""
+    s = ((hi - lo) // world) // SHARD_ALIGN * SHARD_ALIGN
+    return s, lo + world * s
+
+
+def reduce_scatter_span(flat: torch.Tensor, lo: int, hi: int, rank: int, world: int, group=None) -> None:
+    """In place: afterwards rank r holds the SUM over ranks in its shard [lo + r s, lo + (r + 1) s) and in the tail; the other
+    shards of [lo, hi) hold partial garbage (this rank's own contribution) and must not be read."""
+    s, tail = shard_layout(lo, hi, world)
+    staged = flat.is_cuda and dist.get_backend(group) == "gloo"          # gloo rehearsals: through the host (see allreduce_tensor)
+    if s:
+        src = flat[lo:tail]
+        if staged:
+            h = src.detach().to("cpu", copy=True)
+            out = torch.empty(s, dtype=h.dtype)
+            dist.reduce_scatter_tensor(out, h, op=dist.ReduceOp.SUM, group=group)
+            flat[lo + rank * s: lo + (rank + 1) * s].copy_(out)
+        else:
+            dist.reduce_scatter_tensor(flat[lo + rank * s: lo + (rank + 1) * s], src, op=dist.ReduceOp.SUM, group=group)
+    if tail < hi:
+        allreduce_tensor(flat[tail:hi], group=group)
+
+
+def all_gather_span(flat: torch.Tensor, lo: int, hi: int, rank: int, world: int, group=None) -> None:
+    """In place: every rank's shard of [lo, hi) is sent to all (the tail is replicated already)."""
+    s, tail = shard_layout(lo, hi, world)
+    if not s:
+        return
+    mine = flat[lo + rank * s: lo + (rank + 1) * s]
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        h = torch.empty(world * s, dtype=flat.dtype)
+        dist.all_gather_into_tensor(h, mine.detach().to("cpu", copy=True), group=group)
+        flat[lo:tail].copy_(h)
+    else:
+        dist.all_gather_into_tensor(flat[lo:tail], mine, group=group)
+
+
 def allreduce_in_backward_order(flat: torch.Tensor, buckets: Dict[int, Tuple[int, int]], embed_span: Tuple[int, int],
                                 group=None) -> None:
     """Reference schedule (used by the tests and as the no-overlap fallback): groups from the last layer to the

@@ -49,7 +49,8 @@ class Stage1Trainer:
     def __init__(self, model: VGGTQwen3VLM, *, lr=5e-6, proj_lr=1e-4, weight_decay=0.1, warmup_ratio=0.03,
                  max_steps=30000, grad_accum=32, betas=(0.9, 0.999), eps=1e-8, bucket_layers: int = 4,
                  process_group=None, max_grad_norm: Optional[float] = 1.0, accelerate_scheduler_rule: bool = True,
-                 wgrad_defer: Optional[int] = None, vision_group: Optional[int] = None, text_group: Optional[int] = None):
+                 wgrad_defer: Optional[int] = None, vision_group: Optional[int] = None, text_group: Optional[int] = None,
+                 dp_mode: Optional[str] = None):
         self.model = model
         self.tm = model.text_model
         self.lr, self.proj_lr, self.wd = lr, proj_lr, weight_decay
@@ -60,6 +61,14 @@ class Stage1Trainer:
         self.pg = process_group
         self.dist_on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.dist_on else 1
+        self.rank = dist.get_rank(process_group) if self.dist_on else 0
+        # "allreduce" (default): SUM all-reduce of every bucket, replicated AdamW. "sharded" (opt-in, dp.py): reduce-scatter of every
+        # bucket from inside the backward, clipping + AdamW on this rank's 1/world of each bucket, all-gather of the updated weights
+        self.dp_mode = dp_mode or os.environ.get("VQ3_DP_MODE", "allreduce")
+        if self.dp_mode not in ("allreduce", "sharded"):
+            raise ValueError(f"dp_mode must be 'allreduce' or 'sharded', got {self.dp_mode!r}")
+        if not self.dist_on or self.world == 1:
+            self.dp_mode = "allreduce"
         self.max_grad_norm = max_grad_norm
         # scheduler ticks per optimiser step: `world` under Accelerate's rule (the reference), 1 for a plain loop
         self.sched_ticks = self.world if accelerate_scheduler_rule else 1
@@ -153,7 +162,10 @@ class Stage1Trainer:
             if prof is not None:        # HIP events on the stream the collective runs on (bench.py: allreduce_ms_per_opt_step)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            dp.allreduce_span(self.tm.flat_g, lo, hi, group=self.pg)
+            if self.dp_mode == "sharded":
+                dp.reduce_scatter_span(self.tm.flat_g, lo, hi, self.rank, self.world, group=self.pg)
+            else:
+                dp.allreduce_span(self.tm.flat_g, lo, hi, group=self.pg)
             if prof is not None:
                 e1.record()
                 prof.append((e0, e1, (hi - lo) * self.tm.flat_g.element_size()))
@@ -180,12 +192,12 @@ class Stage1Trainer:
                 raise RuntimeError("micro_step: the batches passed as `upcoming` must come back, in order, as the same objects "
                                    "(flush_pending() accounts for the rest of the merged pass if the loop was interrupted)")
             self._merged_pending.pop(0)
-            self.micro += 1
             if not self._merged_pending and self._opt_due:
                 # the window's optimiser step runs with the call that returns the window's LAST loss: `micro`, `opt_step`, lrs() and
                 # the weights stay in phase for every call in between (a step_N save inside the group sees pre-step weights)
                 self._opt_due = False
                 self._optimizer_step()
+            self.micro += 1
             return loss
         k = self.micro % self.grad_accum
         members = [batch]
@@ -220,14 +232,15 @@ class Stage1Trainer:
             self.geom_grad[: self._gn] += torch.cat([g["0.weight"].reshape(-1), g["0.bias"].reshape(-1),
                                                      g["2.weight"].reshape(-1), g["2.bias"].reshape(-1)])
             self.geom_grad[self._gn:] += float(gsize)
-        self.micro += 1
         if gsize > 1:
+            self.micro += 1
             losses = st["loss"]
             self._merged_pending = [(members[j], losses[j]) for j in range(1, gsize)]
             self._opt_due = boundary        # deferred to the micro_step() call that hands out the group's last loss
             return losses[0]
         if boundary:
             self._optimizer_step()
+        self.micro += 1
         return st["loss"]
 
     def flush_pending(self) -> List[torch.Tensor]:
@@ -289,16 +302,40 @@ class Stage1Trainer:
         gscale = 1.0 / self.world
         geom_step = self.geom_on and float(self.geom_grad[self._gn].item()) > 0   # one host read per optimiser step
         clip = None
+        sharded = self.dp_mode == "sharded"
+        # the parts of flat_g / flat_w this rank owns: everything (replicated), or its shard of every bucket + the replicated tails
+        if sharded:
+            spans, tails = [], []
+            for lo, hi in list(self.buckets.values()) + [self.embed_span]:
+                sh, tail = dp.shard_layout(lo, hi, self.world)
+                if sh:
+                    spans.append((lo + self.rank * sh, lo + (self.rank + 1) * sh))
+                if tail < hi:
+                    tails.append((tail, hi))
+        else:
+            spans, tails = [(0, tm.flat_g.numel())], []
         if self.max_grad_norm is not None and self.max_grad_norm > 0:
             # global L2 norm over every trainable gradient (text model + geom_head), as DeepSpeed / clip_grad_norm_ take it
             self.norm_sq.zero_()
-            ops.sumsq(tm.flat_g, self.norm_part, self.norm_sq)
-            if geom_step:
+            for a, b in spans:
+                ops.sumsq(tm.flat_g[a:b], self.norm_part, self.norm_sq)
+            if sharded:
+                if self.rank == 0:                                  # replicated pieces are counted once
+                    for a, b in tails:
+                        ops.sumsq(tm.flat_g[a:b], self.norm_part, self.norm_sq)
+                    if geom_step:
+                        ops.sumsq(self.geom_grad[: self._gn], self.norm_part, self.norm_sq)
+                dp.allreduce_tensor(self.norm_sq, group=self.pg)    # every rank gets the same total
+            elif geom_step:
                 ops.sumsq(self.geom_grad[: self._gn], self.norm_part, self.norm_sq)
             clip = (self.norm_sq, float(self.max_grad_norm))
             self.last_grad_norm = self.norm_sq.sqrt() * gscale
-        ops.adamw_step(self.master, self.m, self.v, tm.flat_g, tm.flat_w, self.lr * mult, self.betas[0], self.betas[1],
-                       self.eps, self.wd, self.opt_step, gscale, clip=clip)
+        for a, b in spans + tails:
+            ops.adamw_step(self.master[a:b], self.m[a:b], self.v[a:b], tm.flat_g[a:b], tm.flat_w[a:b], self.lr * mult, self.betas[0],
+                           self.betas[1], self.eps, self.wd, self.opt_step, gscale, clip=clip)
+        if sharded:                                                 # the updated bf16 weights of every shard reach every rank
+            for lo, hi in list(self.buckets.values()) + [self.embed_span]:
+                dp.all_gather_span(tm.flat_w, lo, hi, self.rank, self.world, group=self.pg)
         tm.refresh_derived()     # e4m3 / W^T copies of the weights (no-ops unless enabled)
         if geom_step:
             ops.adamw_step(self.geom_master, self.geom_m, self.geom_v, ops.cast(self.geom_grad[: self._gn].contiguous(), BF16),
@@ -359,9 +396,21 @@ class Stage1Trainer:
             self._save(Path(output_dir), rank, checkpoint)
         return records
 
+    def gather_sharded_state(self) -> None:
+        """dp_mode "sharded": fp32 master weights and Adam moments are current only inside this rank's shards; all-gather them so
+        that rank 0 can write a complete trainer state (a no-op in the replicated mode)."""
+        if self.dp_mode != "sharded":
+            return
+        torch.cuda.current_stream().synchronize()
+        for lo, hi in list(self.buckets.values()) + [self.embed_span]:
+            for t in (self.master, self.m, self.v):
+                dp.all_gather_span(t, lo, hi, self.rank, self.world, group=self.pg)
+
     def _save(self, path, rank: int, checkpoint) -> None:
         if self.dist_on:
             dist.barrier(group=self.pg)
+            if self.micro % self.grad_accum == 0:
+                self.gather_sharded_state()
         if rank == 0:                       # replicas are identical: one writer (the reference makes every rank call save_state
             checkpoint.save_model(self.model, path)        # only because ZeRO-3 shards need gathering)
             if self.micro % self.grad_accum == 0:
