@@ -375,6 +375,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   p.epi = 0;
   p.stamps = nullptr;
   p.nbw = 1;
+  p.stagger = 0;
   if (ve) {
     VQ3_CHECK_ARG(ve->Q && ve->K && ve->V, "gemm_vit_qkv: null output pointer");
     VQ3_CHECK_ARG(!d->transA && !d->transB && d->K % BK == 0 && !d->out_f32 && !d->accumulate && !d->R && !d->colscale && d->act == 0 &&
@@ -461,8 +462,8 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     if ((long)((d->M + 255) / 256) * ((d->N + 127) / 128) * nbatch >= 64) cands.push_back(21);
     if ((long)((d->M + 127) / 128) * ((d->N + 255) / 256) * nbatch >= 64) cands.push_back(22);
     if (split_rows_main(p, nbatch)) cands.push_back(30);
-    // the overlapped-epilogue kernel pays where a tile has few K steps for its epilogue: short K, enough tiles for every CU
-    if (d->K <= 2048 && (long)((d->M + 127) / 128) * ((d->N + 255) / 256) >= 2 * num_cus()) cands.push_back(23);
+    // (cfg 23, the overlapped-epilogue kernel of gemm8.hip, is not a candidate: correct, but 20-30 % behind cfg 20 / 30 on every
+    // shape measured - DESIGN.md section 9; vq3_gemm_force_config(23) selects it)
     cfg = tuned_choice(p, 0, 0, nbatch, s, cands, cfg);
   }
   if (cfg == 23) {
@@ -472,7 +473,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
       VQ3_CHECK_LAUNCH("gemm_bf16_nt(v8)");
       return 0;
     }
-    cfg = choose_config(d->M, d->N, d->K, nbatch) == 23 ? 13 : 13;      // outside v8's contract: a kernel that takes everything
+    cfg = 13;      // outside v8's contract: a kernel that takes everything
   }
   if (cfg == 30) {
     const int rc = launch_split_rows(p, nbatch, s);

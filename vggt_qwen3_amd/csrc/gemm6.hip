@@ -163,6 +163,14 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   };
   bool prefetched = false;         // this tile's first K tiles were requested during the previous tile's epilogue (and have landed)
   int tile = blockIdx.x;           // (< ntile: the grid never exceeds the tile count)
+  // Start-up stagger: every tile of a launch costs the same, so the CUs run in lockstep and reach their epilogues - the C-tile stores, the
+  // residual reads - in the same microseconds: bursts of 32-64 MB against an otherwise idle memory system, with the MFMA pipes waiting
+  // (tools/gemm_stamps.py: "issue stores" 13.7 us per tile with a residual). Workgroups of the first round wait (workgroup % 8) * stagger
+  // ticks (workgroup % 8 = the XCD under round-robin placement; only speed depends on it): the offsets then persist from round to round.
+  if (p.stagger > 0 && blockIdx.x < 256 && blockIdx.z == 0) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((blockIdx.x & 7) * p.stagger);
+    while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(8);
+  }
   do {                             // one pass for the 256 x 256 kernel (PERSIST is a compile-time false there: no loop is generated)
   tile_coords_id(p, tile, BM, BN, m0, n0);
   V6_STAMP(0);
@@ -456,6 +464,9 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
     ncu = n / 8 * 8;                 // persistent workgroups stride over the tile order by a multiple of 8: they stay on their XCD's slice
   }
   if (const char* sp = getenv("VQ3_GEMM_STAMP_PTR")) p.stamps = (unsigned long long*)strtoull(sp, nullptr, 0);   // diagnostics only
+  static int stagger_env = -1;
+  if (stagger_env < 0) { const char* e = getenv("VQ3_V6_STAGGER"); stagger_env = e ? atoi(e) : 0; }
+  p.stagger = stagger_env;
   int nwg = p.mtiles * p.ntiles;
   if (AH + BH < 4 && nwg > ncu && getenv("VQ3_V6_PERSIST") == nullptr) nwg = ncu;      // (VQ3_V6_PERSIST=0: one tile per workgroup, for A/B runs)
   else if (AH + BH < 4 && nwg > ncu && atoi(getenv("VQ3_V6_PERSIST")) != 0) nwg = ncu;

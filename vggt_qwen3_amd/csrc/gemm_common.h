@@ -53,6 +53,8 @@ struct GemmParams {
   float* st_out;
   // diagnostics (tools/gemm_stamps.py; null in production): per tile 8 x u64 of s_memrealtime / s_memtime stamps, written by thread 0
   unsigned long long* stamps;
+  // start-up stagger (gemm6.hip): workgroups of the launch's first round wait (blockIdx.x % 8) * stagger ticks of the 100 MHz clock
+  int stagger;
 };
 
 // row statistics of the folded LayerNorm (contraction length K is the normalised width)
