@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--geom", action="store_true", help="geometry tokens on (config C4)")
     ap.add_argument("--fp8", action="store_true",
                     help="config C5: Qwen3 forward projections in e4m3 (block-scaled MFMA), backward bf16; NOT the default")
+    ap.add_argument("--train-projector", action="store_true",
+                    help="the 'corrected' mode (VisionLanguageConfig.train_projector): the Perceiver gets a gradient and an AdamW "
+                         "group; NOT the default - the reference runs it under no_grad (vggt_qwen3_vlm.py:128,162)")
     ap.add_argument("--trim-pad", action="store_true",
                     help="drop the all-padding tail of the batch (exact; NOT the default: fewer FLOPs are executed)")
     ap.add_argument("--vision-prefetch", action="store_true",
@@ -228,7 +231,8 @@ def main():
     pcfg = PerceiverConfig(**yaml.safe_load((ROOT / "configs" / "perceiver_small.yaml").read_text()))
     vcfg = VisionLanguageConfig(text_model_name="synthetic", vision_ckpt_dir="none", num_vis_tokens=128,
                                 geom_tokens=8 if args.geom else 0, projector_cfg=pcfg, text_config=qcfg,
-                                device=str(dev), seed=0, trim_padding=args.trim_pad, fp8_text_forward=args.fp8)
+                                device=str(dev), seed=0, trim_padding=args.trim_pad, fp8_text_forward=args.fp8,
+                                train_projector=args.train_projector)
     model = VGGTQwen3VLM(vcfg)
     model.train()
     accum = args.grad_accum if args.grad_accum > 0 else max(1, min(32, args.steps))
@@ -521,7 +525,8 @@ def main():
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": L, "views": V,
                        "grad_accum": accum, "optimizer_steps_timed": len(cycles), "micro_batches_per_pass": int(trainer.text_group),
                        "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
-                       "trim_padding": bool(args.trim_pad), "fp8_text_forward": bool(args.fp8), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
+                       "trim_padding": bool(args.trim_pad), "fp8_text_forward": bool(args.fp8),
+                       "train_projector": bool(args.train_projector), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),
             # utilisation counts EXECUTED FLOPs: the lm_head + CE run on the labelled rows only (same loss and gradients);
             # the reference's figure (logits for all L positions) is kept beside it, never used for a utilisation number

@@ -137,11 +137,12 @@ int vq3_layernorm_fwd(const void* x, const void* res, int32_t x_f32, const float
 
 /* Backward of torch.nn.LayerNorm over f32 rows (the Perceiver's post-norm LayerNorms, src/models/projector_perceiver.py:39-40,48-50,
  * when the projector is trained - VisionLanguageConfig.train_projector; the reference's @torch.no_grad() never reaches it):
- * x f32 [rows, cols] = the tensor that was normalised (residual already added), dy f32 = d(loss)/d(output), w f32 [cols].
+ * x (+ res, when non-NULL: the forward's optional residual) f32 [rows, cols] = the tensor that was normalised, dy f32 =
+ * d(loss)/d(output), w f32 [cols].
  * dx f32 [rows, cols]; dw_part, db_part f32 [ceil(rows / 16), cols]: one partial row per workgroup of sum(dy * xhat) / sum(dy)
  * (plain stores, every slot written) - reduce them with vq3_colsum_f32. Statistics are recomputed from x. cols <= 4096, % 4 == 0. */
-int vq3_layernorm_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw_part, float* db_part, int64_t rows,
-                      int32_t cols, float eps, void* stream);
+int vq3_layernorm_bwd(const float* dy, const float* x, const float* res, const float* w, float* dx, float* dw_part, float* db_part,
+                      int64_t rows, int32_t cols, float eps, void* stream);
 /* out_f32[c] (+)= sum_{r < nrows} part[r*cols + c] (f32 twin of vq3_colsum_f32_to_bf16). */
 int vq3_colsum_f32(const float* part, int32_t nrows, int32_t cols, float* out_f32, int32_t accumulate, void* stream);
 
@@ -151,6 +152,9 @@ int vq3_colsum_f32(const float* part, int32_t nrows, int32_t cols, float* out_f3
 /* Backward of the exact (erf) GELU of projector_perceiver.py:36 on the bf16 pre-activation z the forward GEMM produced:
  * dz = dh * (Phi(z) + z * phi(z)); dh, z, dz bf16 [n], n % 8 == 0. */
 int vq3_gelu_bwd(const void* dh, const void* z, void* dz, int64_t n, void* stream);
+/* h = bf16(gelu_erf(z)) on a materialised bf16 pre-activation z [n] (n % 8 == 0): the activation the GEMM epilogue applies when it
+ * is fused (act = 1), as a pass of its own for the trained-projector path, which keeps z for vq3_gelu_bwd. */
+int vq3_gelu_fwd(const void* z, void* h, int64_t n, void* stream);
 /* Qwen3MLP (modeling_qwen3.py:81-83): act[m, i] = silu(gu[m, i]) * gu[m, I + i]; gu bf16 [rows, 2I]. */
 int vq3_silu_mul_fwd(const void* gu, void* act, int64_t rows, int32_t inter, void* stream);
 /* dgu[m, i] = dact * up * silu'(gate); dgu[m, I+i] = dact * silu(gate). */

@@ -165,6 +165,8 @@ def save_trainer_state(trainer, out_dir) -> Path:
           "layout": {k: [int(o), list(s)] for k, (o, s) in trainer.tm.table.items()},
           "master": trainer.master.cpu(), "m": trainer.m.cpu(), "v": trainer.v.cpu(),
           "geom_master": trainer.geom_master.cpu(), "geom_m": trainer.geom_m.cpu(), "geom_v": trainer.geom_v.cpu()}
+    if getattr(trainer, "proj_on", False):       # trained projector ("corrected" mode): its fp32 parameters live in the model file
+        st["proj_m"], st["proj_v"] = trainer.proj_m.cpu(), trainer.proj_v.cpu()
     torch.save(st, out / TRAINER_STATE)
     return out / TRAINER_STATE
 
@@ -179,6 +181,8 @@ def load_trainer_state(trainer, ckpt_dir) -> None:
     trainer.micro, trainer.opt_step = st["micro"], st["opt_step"]
     for name in ("master", "m", "v", "geom_master", "geom_m", "geom_v"):
         getattr(trainer, name).copy_(st[name])
+    if getattr(trainer, "proj_on", False) and "proj_m" in st:
+        trainer.proj_m.copy_(st["proj_m"]); trainer.proj_v.copy_(st["proj_v"])
     from . import ops
     trainer.tm.flat_w.copy_(ops.cast(trainer.master, torch.bfloat16))
     trainer.tm.refresh_derived()      # e4m3 / W^T copies follow the restored weights (they were built at construction)

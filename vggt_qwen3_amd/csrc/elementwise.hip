@@ -59,6 +59,21 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restr
   }
 }
 
+// ---------------------------------------------------------------- GELU (erf form) forward on a materialised pre-activation
+// h = bf16(gelu(z)): what the GEMM epilogue (act = 1) applies to its rounded output - the trained-projector path keeps z for the backward
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ z, bf16_t* __restrict__ h, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const bf16x8 zz = *reinterpret_cast<const bf16x8*>(z + i * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2_t g = gelu_erf2(f32x2_t{bf2f((bf16_t)zz[2 * j]), bf2f((bf16_t)zz[2 * j + 1])});
+      o[2 * j] = (short)f2bf(g[0]); o[2 * j + 1] = (short)f2bf(g[1]);
+    }
+    *reinterpret_cast<bf16x8*>(h + i * 8) = o;
+  }
+}
+
 // ---------------------------------------------------------------- GELU (erf form) backward: dz = dh * (Phi(z) + z * phi(z))
 // z = the bf16 pre-activation the forward GEMM rounded before applying GELU (projector_perceiver.py:35-37 under autograd).
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ z, bf16_t* __restrict__ dz,
@@ -487,6 +502,14 @@ extern "C" int vq3_silu_mul_bwd(const void* dact, const void* gu, void* dgu, int
   hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(flat_grid(rows * (inter / 8), 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dact, (const bf16_t*)gu, (bf16_t*)dgu, (long)rows, inter);
   VQ3_CHECK_LAUNCH("silu_mul_bwd");
+  return 0;
+}
+
+extern "C" int vq3_gelu_fwd(const void* z, void* h, int64_t n, void* stream) {
+  VQ3_CHECK_ARG(z && h && n > 0 && n % 8 == 0, "gelu_fwd: n must be a positive multiple of 8");
+  VQ3_CHECK_ARG((((uintptr_t)z | (uintptr_t)h) % 16) == 0, "gelu_fwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(flat_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)h, (long)(n / 8));
+  VQ3_CHECK_LAUNCH("gelu_fwd");
   return 0;
 }
 

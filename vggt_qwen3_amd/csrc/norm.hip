@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
 constexpr int LNB_ROWS = 16;
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ w, float* __restrict__ dx,
+                                                            const float* __restrict__ res, const float* __restrict__ w, float* __restrict__ dx,
                                                             float* __restrict__ dw_part, float* __restrict__ db_part, long rows,
                                                             int cols, float eps) {
   extern __shared__ float lnb_red[];               // [2][cols]
@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int c = 0; c < NCH; ++c) {
       const int col = (c * 64 + lane) * 4;
       if (col < cols) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * (long)cols + col);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + row * (long)cols + col);
+        if (res) v += *reinterpret_cast<const f32x4*>(res + row * (long)cols + col);     // the forward normalised x + res
 #pragma unroll
         for (int j = 0; j < 4; ++j) { xv[c][j] = v[j]; s += v[j]; }
       } else {
@@ -602,15 +603,15 @@ extern "C" int vq3_colsum_multi(const vq3_colsum_job* jobs, int32_t njobs, void*
   return 0;
 }
 
-extern "C" int vq3_layernorm_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw_part, float* db_part,
-                                 int64_t rows, int32_t cols, float eps, void* stream) {
+extern "C" int vq3_layernorm_bwd(const float* dy, const float* x, const float* res, const float* w, float* dx, float* dw_part,
+                                 float* db_part, int64_t rows, int32_t cols, float eps, void* stream) {
   VQ3_CHECK_ARG(dy && x && w && dx && dw_part && db_part, "layernorm_bwd: null pointer (dw_part / db_part: ceil(rows / 16) * cols floats each)");
   VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 4096, "layernorm_bwd: cols=%d must be a multiple of 4, <= 4096", cols);
-  VQ3_CHECK_ARG((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) % 16) == 0, "layernorm_bwd: pointers must be 16-byte aligned");
+  VQ3_CHECK_ARG((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)res | (uintptr_t)w | (uintptr_t)dx) % 16) == 0, "layernorm_bwd: pointers must be 16-byte aligned");
   const long nblk = (rows + LNB_ROWS - 1) / LNB_ROWS;
   const size_t smem = (size_t)2 * cols * sizeof(float);
 #define VQ3_LNB(N)                                                                                                          \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<N>), dim3((unsigned)nblk), dim3(256), smem, (hipStream_t)stream, dy, x, w, dx, dw_part, \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<N>), dim3((unsigned)nblk), dim3(256), smem, (hipStream_t)stream, dy, x, res, w, dx, dw_part, \
                      db_part, (long)rows, cols, eps)
   if (cols <= 1024) VQ3_LNB(4); else if (cols <= 2048) VQ3_LNB(8); else VQ3_LNB(16);
 #undef VQ3_LNB

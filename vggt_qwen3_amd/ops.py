@@ -228,6 +228,53 @@ def transpose_raw(src, dst, R, C, Rpad, lds, ldd, n=(1, 1, 1), s=(0, 0, 0), d=(0
           "vq3_transpose_bf16")
 
 
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, eps: float, res: Optional[torch.Tensor] = None,
+                  dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+    """torch.nn.LayerNorm backward over f32 rows: x (+ res) = the tensor that was normalised, dy = d(output).
+    -> (dx f32 [rows, cols], dw f32 [cols], db f32 [cols]); dw_out / db_out (f32 [cols]): ACCUMULATE the parameter gradients there."""
+    _req(dy, F32, "layernorm_bwd dy"); _req(x, F32, "layernorm_bwd x"); _req(w, F32, "layernorm_bwd w")
+    assert dy.is_contiguous() and x.is_contiguous() and dy.shape == x.shape and x.dim() == 2
+    if res is not None:
+        _req(res, F32, "layernorm_bwd res"); assert res.is_contiguous() and res.shape == x.shape
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    nblk = (rows + 15) // 16
+    part = torch.empty((2, nblk, cols), device=x.device, dtype=F32)
+    lib = _lib.load()
+    check(lib.vq3_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _p(res), w.data_ptr(), dx.data_ptr(), part[0].data_ptr(),
+                                part[1].data_ptr(), rows, cols, eps, _stream()), "vq3_layernorm_bwd")
+    dw = colsum_f32(part[0], out=dw_out, accumulate=dw_out is not None)
+    db = colsum_f32(part[1], out=db_out, accumulate=db_out is not None)
+    return dx, dw, db
+
+
+def colsum_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out[c] (+)= sum_r x[r, c] for an f32 matrix (bias gradients of f32 activations' gradients)."""
+    _req(x, F32, "colsum_f32 x"); assert x.is_contiguous() and x.dim() == 2
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(cols, device=x.device, dtype=F32)
+        accumulate = False
+    _req(out, F32, "colsum_f32 out")
+    check(_lib.load().vq3_colsum_f32(x.data_ptr(), rows, cols, out.data_ptr(), 1 if accumulate else 0, _stream()), "vq3_colsum_f32")
+    return out
+
+
+def gelu_fwd(z: torch.Tensor) -> torch.Tensor:
+    _req(z, BF16, "gelu_fwd z"); assert z.is_contiguous() and z.numel() % 8 == 0
+    h = torch.empty_like(z)
+    check(_lib.load().vq3_gelu_fwd(z.data_ptr(), h.data_ptr(), z.numel(), _stream()), "vq3_gelu_fwd")
+    return h
+
+
+def gelu_bwd(dh: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    _req(dh, BF16, "gelu_bwd dh"); _req(z, BF16, "gelu_bwd z")
+    assert dh.is_contiguous() and z.is_contiguous() and dh.shape == z.shape and z.numel() % 8 == 0
+    dz = torch.empty_like(z)
+    check(_lib.load().vq3_gelu_bwd(dh.data_ptr(), z.data_ptr(), dz.data_ptr(), z.numel(), _stream()), "vq3_gelu_bwd")
+    return dz
+
+
 def transpose2d(x: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
     """[R, C] bf16 -> [C, round_up(R, pad_to)] with zero padding."""
     assert x.dim() == 2 and x.stride(1) == 1

@@ -124,6 +124,26 @@ class Stage1Trainer:
         self.buckets, self.embed_span = dp.plan_buckets(self.tm.table, self.tm.config.num_hidden_layers, bucket_layers)
         dp.check_cover(self.buckets, self.embed_span, n)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.dist_on else None
+        # "corrected" mode (VisionLanguageConfig.train_projector): the Perceiver's fp32 parameters, gradients and Adam moments as flat
+        # buffers (the parameters and their .grad become views), one gradient all-reduce bucket of their own, the proj_lr group
+        self.proj_on = bool(getattr(model, "train_projector", False))
+        if self.proj_on:
+            pp = [p_ for _, p_ in model.projector.named_parameters()]
+            pn = sum(p_.numel() for p_ in pp)
+            self.proj_w32 = torch.empty(pn, device=dev, dtype=F32)
+            self.proj_g32 = torch.zeros(pn, device=dev, dtype=F32)
+            self.proj_m = torch.zeros(pn, device=dev, dtype=F32)
+            self.proj_v = torch.zeros(pn, device=dev, dtype=F32)
+            self.proj_w16 = torch.empty(pn, device=dev, dtype=BF16)      # (AdamW writes the bf16 image; the compute copies are refreshed from fp32)
+            off = 0
+            with torch.no_grad():
+                for p_ in pp:
+                    k = p_.numel()
+                    self.proj_w32[off:off + k].copy_(p_.detach().reshape(-1))
+                    p_.data = self.proj_w32[off:off + k].view_as(p_)
+                    p_.grad = self.proj_g32[off:off + k].view_as(p_)
+                    off += k
+            model.projector._cc = None
         self._works: List = []
         self.comm_profile: Optional[List] = None    # set to [] to collect (start event, end event, bytes) per gradient all-reduce
         self._fired: List[int] = []     # buckets all-reduced from inside the backward of the current boundary micro-batch
@@ -224,6 +244,8 @@ class Stage1Trainer:
         self._fired = []
         if not accumulate:
             self.geom_grad.zero_()
+            if self.proj_on:
+                self.proj_g32.zero_()
         # A micro-batch without any labelled token (the answer truncated away) has no gradient: _backward_text then zeroes
         # flat_g on the first micro-batch of a window and still fires every layer_done hook, so the ranks' collectives match.
         d_geom = model._backward_text(st, 1.0 / self.grad_accum, accumulate, layer_done=hook, flush=boundary)
@@ -297,6 +319,12 @@ class Stage1Trainer:
                 with torch.cuda.stream(self.comm_stream):
                     dp.allreduce_tensor(self.geom_grad, group=self.pg)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        proj_g16 = None
+        if self.proj_on:
+            # the projector's gradients leave as bf16 like the text model's: one bucket of their own (replicated in either dp_mode)
+            proj_g16 = ops.cast(self.proj_g32, BF16)
+            if self.dist_on:
+                dp.allreduce_tensor(proj_g16, group=self.pg)
         self.opt_step += 1
         mult = self.lr_mult(self.opt_step)
         gscale = 1.0 / self.world
@@ -319,15 +347,15 @@ class Stage1Trainer:
             self.norm_sq.zero_()
             for a, b in spans:
                 ops.sumsq(tm.flat_g[a:b], self.norm_part, self.norm_sq)
+            if not sharded or self.rank == 0:                       # replicated pieces are counted once when the sum is all-reduced
+                for a, b in tails:
+                    ops.sumsq(tm.flat_g[a:b], self.norm_part, self.norm_sq)
+                if geom_step:
+                    ops.sumsq(self.geom_grad[: self._gn], self.norm_part, self.norm_sq)
+                if proj_g16 is not None:
+                    ops.sumsq(proj_g16, self.norm_part, self.norm_sq)
             if sharded:
-                if self.rank == 0:                                  # replicated pieces are counted once
-                    for a, b in tails:
-                        ops.sumsq(tm.flat_g[a:b], self.norm_part, self.norm_sq)
-                    if geom_step:
-                        ops.sumsq(self.geom_grad[: self._gn], self.norm_part, self.norm_sq)
                 dp.allreduce_tensor(self.norm_sq, group=self.pg)    # every rank gets the same total
-            elif geom_step:
-                ops.sumsq(self.geom_grad[: self._gn], self.norm_part, self.norm_sq)
             clip = (self.norm_sq, float(self.max_grad_norm))
             self.last_grad_norm = self.norm_sq.sqrt() * gscale
         for a, b in spans + tails:
@@ -336,6 +364,10 @@ class Stage1Trainer:
         if sharded:                                                 # the updated bf16 weights of every shard reach every rank
             for lo, hi in list(self.buckets.values()) + [self.embed_span]:
                 dp.all_gather_span(tm.flat_w, lo, hi, self.rank, self.world, group=self.pg)
+        if proj_g16 is not None:
+            ops.adamw_step(self.proj_w32, self.proj_m, self.proj_v, proj_g16, self.proj_w16, self.proj_lr * mult, self.betas[0],
+                           self.betas[1], self.eps, self.wd, self.opt_step, gscale, clip=clip)
+            self.model.projector._cc = None               # bf16 compute copies are rebuilt from the updated fp32 parameters
         tm.refresh_derived()     # e4m3 / W^T copies of the weights (no-ops unless enabled)
         if geom_step:
             ops.adamw_step(self.geom_master, self.geom_m, self.geom_v, ops.cast(self.geom_grad[: self._gn].contiguous(), BF16),

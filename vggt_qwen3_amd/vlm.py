@@ -45,6 +45,10 @@ class VisionLanguageConfig:
     seed: int = 0
     trim_padding: bool = False
     fp8_text_forward: bool = False               # BASELINE config C5: e4m3 forward GEMMs in the text model
+    # False (default) = the reference as it runs: encode_images under no_grad, the Perceiver never receives a gradient although
+    # train_sft.py:138-145 gives it a learning-rate group. True = the "corrected" mode of SURVEY.md 3.1: the projector's forward saves
+    # for backward, d(loss)/d(visual tokens) flows into its hand-written backward, the trainer updates it with proj_lr.
+    train_projector: bool = False
 
 
 def build_srcmap(input_ids: torch.Tensor, image_id: int, S: int) -> torch.Tensor:
@@ -161,6 +165,7 @@ class VGGTQwen3VLM(nn.Module):
         # False = compute all L positions like the reference; True = drop the all-padding tail of the batch (same
         # loss and gradients, fewer rows). Off by default so the dense figure stays comparable with the reference's.
         self.trim_padding = bool(config.trim_padding)
+        self.train_projector = bool(config.train_projector)
         if config.fp8_text_forward:
             self.text_model.enable_fp8_forward(True)
         self._vis_stream = None
@@ -239,9 +244,9 @@ class VGGTQwen3VLM(nn.Module):
         return None
 
     @torch.no_grad()
-    def encode_images(self, images: torch.Tensor, _orig: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """images [B, V, C, H, W] -> [B, num_vis_tokens, hidden] (vggt_qwen3_vlm.py:128-162)."""
-        B, V = images.shape[:2]
+    def _vision_tokens(self, images: torch.Tensor, _orig: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The frozen tower's last output, first num_vis_tokens tokens of view 0 (vggt_qwen3_vlm.py:144-156): [B, Nv, 2048]."""
+        B = images.shape[0]
         agg = self._take_grouped(images if _orig is None else _orig) if self._vis_group else None
         if agg is None:
             toks, _ = self.vision_model.aggregator(images)
@@ -250,7 +255,12 @@ class VGGTQwen3VLM(nn.Module):
             agg = agg[:, : self.num_vis_tokens, :]
         elif agg.dim() == 4:
             agg = agg.reshape(B, -1, agg.shape[-1])[:, : self.num_vis_tokens, :]
-        return self.projector(agg.contiguous())
+        return agg.contiguous()
+
+    @torch.no_grad()
+    def encode_images(self, images: torch.Tensor, _orig: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """images [B, V, C, H, W] -> [B, num_vis_tokens, hidden] (vggt_qwen3_vlm.py:128-162)."""
+        return self.projector(self._vision_tokens(images, _orig))
 
     def prefetch_images(self, images: torch.Tensor) -> None:
         """Run encode_images for a FUTURE batch on a second HIP stream: the vision tower is frozen and under no_grad
@@ -320,9 +330,15 @@ class VGGTQwen3VLM(nn.Module):
         B, L = input_ids.shape
         images0 = images
         images = images.to(self.device_)
-        vis = self._take_prefetched(images)
-        if vis is None:
-            vis = self.encode_images(images, _orig=images0)                                   # [B, Nv, H] fp32
+        pctx = None
+        if self.train_projector and need_grad:
+            # "corrected" mode: the tower stays frozen (no_grad), the projector's forward keeps what its backward needs
+            with torch.no_grad():
+                vis, pctx = self.projector.forward_train(self._vision_tokens(images, _orig=images0))
+        else:
+            vis = self._take_prefetched(images)
+            if vis is None:
+                vis = self.encode_images(images, _orig=images0)                               # [B, Nv, H] fp32
         gfeat = self._geom_inputs(geom_token)
         geom_ctx, gy = None, None
         if gfeat is not None:
@@ -352,7 +368,7 @@ class VGGTQwen3VLM(nn.Module):
         h_last, saved = tm.forward_hidden(emb, attention_mask, save=need_grad, plan_key=(attention_mask0,))
         loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad, L=saved["L"], plan_key=(labels0,), groups=loss_groups)
         return dict(loss=loss, saved=saved, head=head_ctx, srcmap=srcmap, input_ids=input_ids, B=B, L=L, S=S,
-                    geom_ctx=geom_ctx, geom_y=gy, emb=emb, h_last=h_last)
+                    geom_ctx=geom_ctx, geom_y=gy, emb=emb, h_last=h_last, pctx=pctx)
 
     def _backward_text(self, st: dict, gscale: float, accumulate: bool, layer_done=None, flush: bool = True):
         """Backward of everything that has gradients in the reference: Qwen3 (all parameters, tied embedding) and,
@@ -381,10 +397,18 @@ class VGGTQwen3VLM(nn.Module):
         ids = st["input_ids"].reshape(-1)
         sorted_ids, order = torch.sort(ids, stable=True)
         dfeat = None
-        if st["geom_ctx"] is not None:
+        if st["geom_ctx"] is not None or st.get("pctx") is not None:
             dfeat = torch.zeros((B, S, H), device=d_emb.device, dtype=F32)
         ops.embed_splice_bwd(sorted_ids, order, st["srcmap"], d_emb, tm._g["embed"], dfeat, B, L, H, S)
         if dfeat is None:
+            return None
+        if st.get("pctx") is not None:
+            # the visual rows' gradient goes on into the Perceiver (fp32 gradients accumulate in its parameters' .grad)
+            ng = self.geom_tokens if st["geom_ctx"] is not None else 0
+            with torch.no_grad():
+                self.projector.backward(st["pctx"], dfeat[:, ng:].contiguous())
+            st["pctx"] = None
+        if st["geom_ctx"] is None:
             return None
         return dfeat[:, : self.geom_tokens].sum(dim=1)  # the 8 geom tokens are one expanded vector
 
