@@ -6,6 +6,8 @@
 // so every softmax statistic of a query row lives on the lane that owns that query column.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "common.h"
 #include "vq3_hip.h"
 
@@ -258,28 +260,38 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     }
   }
 
-  // staging: 512 16-byte chunks per tile and operand, NS = 512 / NT per thread: row = tid >> 3 (+ NT / 8 per step), chunk = tid & 7
+  // staging: 512 16-byte chunks per tile and operand, NS = 512 / NT per thread: row = tid >> 3 (+ NT / 8 per step), chunk = tid & 7.
+  // Raw buffer loads: the per-lane offset is fixed for the whole key loop and the tile advances through the SCALAR offset, so a tile
+  // costs no address arithmetic on the VALU (the 64-bit pointer form spent ~30 vector instructions per tile on it - beside 64
+  // v_exp_f32 and 32 MFMAs); rows past N read as zero through the descriptor's range check (their scores are masked below).
   constexpr int NS = 512 / NT, RSTEP = NT / 8;
   const int srow0 = tid >> 3, sch = tid & 7;
   const int nt = (N + FA_KV - 1) / FA_KV;
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kb), 0, N * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Vb), 0, N * 128, 0x00020000);
   u32x4 kreg[NS], vreg[NS];
+  int goff[NS], kst[NS], vst[NS];          // per-lane byte offsets: in the (sample, head)'s K / V, in the LDS K image, in the LDS V image
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int row = srow0 + RSTEP * i;
+    goff[i] = row * 128 + sch * 16;
+    kst[i] = fa_swz(row, sch);
+    vst[i] = FA_KV * 128 + fa_vswz(row, sch);
+  }
   auto load_tile = [&](int t) {
+    const int soff = t * (FA_KV * 128);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      int kr = t * FA_KV + srow0 + RSTEP * i;
-      kr = kr < N ? kr : N - 1;
-      kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (long)kr * 64 + sch * 8);
-      vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (long)kr * 64 + sch * 8);
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, goff[i], soff, 0));
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, goff[i], soff, 0));
     }
   };
   auto store_tile = [&](int buf) {
-    char* Ks = smem + buf * (2 * FA_KV * 128);
-    char* Vs = Ks + FA_KV * 128;
+    char* sb = smem + buf * (2 * FA_KV * 128);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      const int row = srow0 + RSTEP * i;
-      *reinterpret_cast<u32x4*>(Ks + fa_swz(row, sch)) = kreg[i];
-      *reinterpret_cast<u32x4*>(Vs + fa_vswz(row, sch)) = vreg[i];
+      *reinterpret_cast<u32x4*>(sb + kst[i]) = kreg[i];
+      *reinterpret_cast<u32x4*>(sb + vst[i]) = vreg[i];
     }
   };
   int koff0[4], koff1[4];
@@ -305,10 +317,13 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   // a wave whose 32 * QB query rows all lie past N (the ragged last block: N = 1029 leaves 5 rows for wave 0 and none for waves
   // 1-3) only helps to stage K / V: its SIMD's MFMA and VALU slots go to the other workgroup on the CU
   const bool active = q0 < q_end;
-  for (int t = 0; t < nt; ++t) {
+  // the key loop runs two tiles per iteration so that the LDS stage is a compile-time constant: every fragment read and staging
+  // store then carries its stage offset as an immediate
+  auto tile_body = [&](const int t, auto stage_tag) {
+    constexpr int STG = decltype(stage_tag)::value;
     const bool more = t + 1 < nt;
-    const char* sb = smem + (t & 1) * (2 * FA_KV * 128);
-    const unsigned sbase = lds_base + (unsigned)((t & 1) * (2 * FA_KV * 128));
+    const char* sb = smem + STG * (2 * FA_KV * 128);
+    const unsigned sbase = lds_base + (unsigned)(STG * (2 * FA_KV * 128));
     if (more) load_tile(t + 1);
     if (active) {
     // ---- S^T = K . Q'^T - m
@@ -483,8 +498,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       }
     }
     }   // active
-    if (more) store_tile((t + 1) & 1);
+    if (more) store_tile(STG ^ 1);
     __syncthreads();
+  };
+  for (int t = 0; t < nt; t += 2) {
+    tile_body(t, std::integral_constant<int, 0>{});
+    if (t + 1 < nt) tile_body(t + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue: lane owns query q0 + 32*qb + r, d = 32*db + (i&3) + 8*(i>>2) + 4h
