@@ -207,6 +207,9 @@ __global__ __launch_bounds__(256) void vit_qkprep4_kernel(const bf16_t* __restri
 // V rows of 128 B with chunk bit 2 XOR (row >> 1) & 1, so the 4 key rows x 64 B a 32-lane half reads cover all 64 banks.
 constexpr int FA_KV = 64;
 constexpr float FA_THR = 6.0f;
+#ifndef FA_LSUM_MFMA
+#define FA_LSUM_MFMA 1
+#endif
 
 __device__ __forceinline__ int fa_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int fa_vswz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
@@ -249,6 +252,15 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   // One query block per wave only: with two the 16 extra registers per block would push the kernel past 256 VGPRs.
   constexpr bool NEGM = (QB == 1);
   f32x16 negm[NEGM ? QB : 1];
+  // Row sums of P on the MATRIX pipe: one more MFMA per 16-key chunk with an all-ones A operand leaves sum_k P[k][q] in every register
+  // of the query's lane (both half-waves: the MFMA sums over all 16 keys of the chunk) - the sums of the bf16-rounded P, i.e. exactly the
+  // weights the numerator uses. PMC (profiles/r3_flash_pmc.txt): the VALU is the busier pipe of this kernel (61 % against 43 %) and the
+  // two overlap little; this moves 68 of ~300 vector instructions per tile (the adds + the cross-half exchange) to 8 MFMAs.
+  constexpr bool LSUM = FA_LSUM_MFMA && QB == 2;      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
+  f32x16 lacc[LSUM ? QB : 1];
+  bf16x8 ones8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones8[j] = (short)0x3F80;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
@@ -257,6 +269,10 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     if (NEGM) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) negm[qb][i] = 0.f;
+    }
+    if (LSUM) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lacc[qb][i] = 0.f;
     }
   }
 
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         // (__float_as_int, not __builtin_bit_cast: hipcc 7.2 folds a bit_cast of a vector ELEMENT to element 0)
         int mi = max(__float_as_int(s0[qb][0]), __float_as_int(s1[qb][0]));
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mi = max(mi, max(__float_as_int(s0[qb][i]), __float_as_int(s1[qb][i])));
+        for (int i = 1; i < 16; ++i) mi = max(max(mi, __float_as_int(s0[qb][i])), __float_as_int(s1[qb][i]));      // one v_max3_i32 each
         const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);   // [0] = lower half's value, [1] = upper half's
         mi = max((int)sw[0], (int)sw[1]);
         rel[qb] = mi > 0 ? __int_as_float(mi) : 0.f;
@@ -411,6 +427,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         for (int i = 0; i < 16; ++i) {
           o0[qb][i] *= alpha; o1[qb][i] *= alpha;
           s0[qb][i] -= adv; s1[qb][i] -= adv;
+          if (LSUM) lacc[qb][i] *= alpha;
         }
         if (NEGM) {
 #pragma unroll
@@ -430,8 +447,8 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   do {                                                                                                                  \
     _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                                 \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                   \
-        if ((U) < 2) { s0[qb][8 * ((U) & 1) + j] = __builtin_amdgcn_exp2f(s0[qb][8 * ((U) & 1) + j]); ps[qb] += s0[qb][8 * ((U) & 1) + j]; } \
-        else { s1[qb][8 * ((U) & 1) + j] = __builtin_amdgcn_exp2f(s1[qb][8 * ((U) & 1) + j]); ps[qb] += s1[qb][8 * ((U) & 1) + j]; }         \
+        if ((U) < 2) { s0[qb][8 * ((U) & 1) + j] = __builtin_amdgcn_exp2f(s0[qb][8 * ((U) & 1) + j]); if (!LSUM) ps[qb] += s0[qb][8 * ((U) & 1) + j]; } \
+        else { s1[qb][8 * ((U) & 1) + j] = __builtin_amdgcn_exp2f(s1[qb][8 * ((U) & 1) + j]); if (!LSUM) ps[qb] += s1[qb][8 * ((U) & 1) + j]; }         \
       }                                                                                                                 \
     }                                                                                                                   \
   } while (0)
@@ -445,6 +462,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         pf[j] = (short)f2bf((U) < 2 ? s0[qb][8 * ((U) & 1) + j] : s1[qb][8 * ((U) & 1) + j]);                            \
       o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), pf, o0[qb], 0, 0, 0);            \
       o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1[qb], 0, 0, 0);            \
+      if (LSUM) lacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf, lacc[qb], 0, 0, 0);                       \
     }                                                                                                                   \
   } while (0)
     // one MFMA, then a few of the next chunk's VALU instructions, ... (scheduler hint for the region up to the next wait)
@@ -473,10 +491,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     FA_MIX();
     FA_VWAIT(1, 0);
     FA_PV(3, 1);
+    if (!LSUM) {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps[qb]), __float_as_uint(ps[qb]), false, false);
-      l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      for (int qb = 0; qb < QB; ++qb) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps[qb]), __float_as_uint(ps[qb]), false, false);
+        l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
     }
     // ---- deferred rescale: only when some lane's scores outgrew the stale max by more than THR
     bool grow = false;
@@ -490,7 +510,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         m_run[qb] += adv;
         l_run[qb] *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; }
         if (NEGM) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) negm[qb][i] = -m_run[qb];
@@ -511,7 +531,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q0 + 32 * qb + r;
     if (q < q_end) {
-      const float inv = 1.f / l_run[qb];
+      const float inv = 1.f / (LSUM ? lacc[qb][0] : l_run[qb]);
       const long g = nb / NH;
       const int hd = (int)(nb % NH);
       bf16_t* orow = O + (g * N + q) * ldo + hd * 64;
