@@ -210,6 +210,12 @@ constexpr float FA_THR = 6.0f;
 #ifndef FA_LSUM_MFMA
 #define FA_LSUM_MFMA 1
 #endif
+#ifndef FA_QK_OVERLAP
+#define FA_QK_OVERLAP 1
+#endif
+#ifndef FA_QK_HINT
+#define FA_QK_HINT 0
+#endif
 
 __device__ __forceinline__ int fa_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int fa_vswz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
@@ -218,7 +224,9 @@ __device__ __forceinline__ int fa_vswz(int row, int chunk) { return row * 128 + 
 // length is a multiple of 256 plus a few (1029 = 5 special tokens + 1024 patches): as a fifth four-wave block those 5 rows held a
 // workgroup slot (222 VGPRs x 4 waves, 32 KiB LDS) for a whole key loop in every (sample, head) pair; as a one-wave workgroup on a
 // second stream they run beside the 4 exact blocks. Query rows q_begin <= q < q_end are processed, keys 0 .. N - 1.
-template <int QB, int NT>
+// VAR (two query blocks per wave only): 0 = row sums of P on the matrix pipe; 1 = keys 32-63 multiplied while keys 0-31 are scanned and
+// exponentiated (row sums on the VALU: both together do not fit 256 registers)
+template <int QB, int NT, int VAR = 0>
 __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                  int N, int NH, long ldo, float scale_log2e, int q_begin, int q_end) {
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   // of the query's lane (both half-waves: the MFMA sums over all 16 keys of the chunk) - the sums of the bf16-rounded P, i.e. exactly the
   // weights the numerator uses. PMC (profiles/r3_flash_pmc.txt): the VALU is the busier pipe of this kernel (61 % against 43 %) and the
   // two overlap little; this moves 68 of ~300 vector instructions per tile (the adds + the cross-half exchange) to 8 MFMAs.
-  constexpr bool LSUM = FA_LSUM_MFMA && QB == 2;      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
+  constexpr bool LSUM = FA_LSUM_MFMA && QB == 2 && VAR == 0;      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
   f32x16 lacc[LSUM ? QB : 1];
   bf16x8 ones8;
 #pragma unroll
@@ -521,9 +529,163 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     if (more) store_tile(STG ^ 1);
     __syncthreads();
   };
+  // Steady-state tile (not the first, no key tail; two query blocks per wave): the scores of keys 32-63 are multiplied WHILE keys
+  // 0-31 are scanned for growth and exponentiated - the deferred maximum makes that legal: the exponentials use the stale scale, the
+  // growth test only decides about a rescale afterwards. The overflow guard (a score more than 2^100 above the stale maximum) is
+  // evaluated on both halves before any P reaches a P.V product; in that rare case the first half's scores are multiplied again
+  // (its registers hold exponentials by then) and the tile takes the textbook order.
+  auto tile_fast = [&](const int t, auto stage_tag) {
+    constexpr int STG = decltype(stage_tag)::value;
+    const bool more = t + 1 < nt;
+    const char* sb = smem + STG * (2 * FA_KV * 128);
+    const unsigned sbase = lds_base + (unsigned)(STG * (2 * FA_KV * 128));
+    if (more) load_tile(t + 1);
+    if (active) {
+      f32x16 s0[QB], s1[QB];
+      u32x2 va[2][2], vb[2][2];
+      auto qk0 = [&]() {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s0[qb][i] = -m_run[qb];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sb + koff0[sidx]);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) s0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][sidx], s0[qb], 0, 0, 0);
+        }
+      };
+      qk0();
+      // ---- keys 32-63 on the matrix pipe; keys 0-31: growth scan + exponentials on the VALU between those MFMAs
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s1[qb][i] = -m_run[qb];
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        const bf16x8 kg = *reinterpret_cast<const bf16x8*>(sb + koff1[sidx]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) s1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kg, qf[qb][sidx], s1[qb], 0, 0, 0);
+      }
+      int mi[QB];
+      float ps[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        ps[qb] = 0.f;
+        mi[qb] = max(__float_as_int(s0[qb][0]), __float_as_int(s0[qb][1]));
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) mi[qb] = max(max(mi[qb], __float_as_int(s0[qb][i])), __float_as_int(s0[qb][i + 1]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[qb][i] = __builtin_amdgcn_exp2f(s0[qb][i]); if (!LSUM) ps[qb] += s0[qb][i]; }
+      }
+#if FA_QK_HINT
+#pragma unroll
+      for (int gidx = 0; gidx < 4 * QB; ++gidx) {           // one MFMA, then six of the 24 VALU instructions per MFMA, ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+      }
+#endif
+      // ---- keys 32-63: growth scan; both halves decide
+      const int kbase = t * FA_KV;
+      const bool special = (t == 0) || (kbase + FA_KV > N);          // wave-uniform: first tile (sets the scale) / key tail
+      float rel[QB];
+      bool slow = special;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) mi[qb] = max(max(mi[qb], __float_as_int(s1[qb][i])), __float_as_int(s1[qb][i + 1]));
+        const auto sw = __builtin_amdgcn_permlane32_swap(mi[qb], mi[qb], false, false);
+        const int mm = max((int)sw[0], (int)sw[1]);
+        rel[qb] = mm > 0 ? __int_as_float(mm) : 0.f;
+        slow = slow || !(rel[qb] <= 100.f);                                        // also catches NaN
+      }
+      if (__any(slow)) {
+        // textbook order (first tile, key tail, overflow guard): the first half's scores again (its registers hold exponentials),
+        // mask, exact maximum, advance, rescale, subtract, exponentiate
+        qk0();
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          if (kbase + FA_KV > N) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int key0 = kbase + (i & 3) + 8 * (i >> 2) + 4 * h;
+              if (key0 >= N) s0[qb][i] = -INFINITY;
+              if (key0 + 32 >= N) s1[qb][i] = -INFINITY;
+            }
+          }
+          if (special) {
+            float mx = fmaxf(s0[qb][0], s1[qb][0]);                                // exact float maximum (may be negative)
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[qb][i], s1[qb][i]));
+            rel[qb] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (t > 0 && !(rel[qb] > FA_THR)) rel[qb] = rel[qb] > 0.f ? rel[qb] : 0.f;     // (tail tile: growth below the threshold is deferred as usual)
+          }
+          const float adv = (t == 0 || rel[qb] > FA_THR) ? rel[qb] : 0.f;
+          const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-adv);         // tile 0: O = l = 0, and 0 * 2^+big would be NaN
+          m_run[qb] += adv;
+          l_run[qb] *= alpha;
+          ps[qb] = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            o0[qb][i] *= alpha; o1[qb][i] *= alpha;
+            if (LSUM) lacc[qb][i] *= alpha;
+            s0[qb][i] = __builtin_amdgcn_exp2f(s0[qb][i] - adv);
+            if (!LSUM) ps[qb] += s0[qb][i];
+            s1[qb][i] -= adv;
+          }
+          rel[qb] = (t > 0 && !(adv > 0.f)) ? rel[qb] : 0.f;
+        }
+      }
+      FA_VISSUE(0, 0);
+      FA_VISSUE(1, 1);
+      FA_VWAIT(0, 4);
+      FA_PV(0, 0);
+      FA_EXP(2);
+      FA_MIX();
+      FA_VISSUE(2, 0);
+      FA_VWAIT(1, 4);
+      FA_PV(1, 1);
+      FA_EXP(3);
+      FA_MIX();
+      FA_VISSUE(3, 1);
+      FA_VWAIT(0, 4);
+      FA_PV(2, 0);
+      FA_VWAIT(1, 0);
+      FA_PV(3, 1);
+      if (!LSUM) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps[qb]), __float_as_uint(ps[qb]), false, false);
+          l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+      }
+      bool grow = false;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) grow = grow || (rel[qb] > FA_THR);
+      if (__any(grow)) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const float adv = rel[qb] > FA_THR ? rel[qb] : 0.f;
+          const float alpha = __builtin_amdgcn_exp2f(-adv);
+          m_run[qb] += adv;
+          l_run[qb] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; }
+        }
+      }
+    }
+    if (more) store_tile(STG ^ 1);
+    __syncthreads();
+  };
+  constexpr bool FAST = (QB == 2) && FA_QK_OVERLAP && VAR == 1;
   for (int t = 0; t < nt; t += 2) {
-    tile_body(t, std::integral_constant<int, 0>{});
-    if (t + 1 < nt) tile_body(t + 1, std::integral_constant<int, 1>{});
+    if constexpr (FAST) {
+      tile_fast(t, std::integral_constant<int, 0>{});
+      if (t + 1 < nt) tile_fast(t + 1, std::integral_constant<int, 1>{});
+    } else {
+      tile_body(t, std::integral_constant<int, 0>{});
+      if (t + 1 < nt) tile_body(t + 1, std::integral_constant<int, 1>{});
+    }
   }
 
   // ---- epilogue: lane owns query q0 + 32*qb + r, d = 32*db + (i&3) + 8*(i>>2) + 4h
@@ -634,7 +796,15 @@ extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, v
     }
   }
   dim3 grid((q_main + 128 * qb - 1) / (128 * qb), G * NH);
-  if (qb == 2)
+  // variant: measured (tools/bench_flash.py, 6 x 16 heads): 8232 keys 920 (0) / 951 (1) TF/s, 1029 keys 563 / 560 - the overlap pays once the
+  // key loop is long; VQ3_FLASH_VAR pins one
+  static int fvar_env = -2;
+  if (fvar_env == -2) { const char* e = getenv("VQ3_FLASH_VAR"); fvar_env = e ? atoi(e) : -1; }
+  const int fvar = fvar_env >= 0 ? fvar_env : (N >= 2048 ? 1 : 0);
+  if (qb == 2 && fvar == 1)
+    hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main);
+  else if (qb == 2)
     hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
                        (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main);
   else
