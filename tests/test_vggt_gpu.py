@@ -26,16 +26,23 @@ def test_flash_attention_vs_sdpa(G, NH, N):
     assert e < 1e-2, f"flash attention rel err {e}"
 
 
-def test_flash_attention_spiked_max():
-    """Forces the running-max rescale: one key per tile dominates for some queries (guide rule 26)."""
+@pytest.mark.parametrize("N", [300, 2200])
+def test_flash_attention_spiked_max(N):
+    """Forces the running-max rescale: one key per tile dominates for some queries (guide rule 26). N = 300 runs the kernel variant with the
+    row sums on the matrix pipe; N = 2200 (>= 2048) the one that multiplies keys 32-63 while keys 0-31 are exponentiated: there the spikes
+    sit in both halves of their tiles, one of them (x 10: 2^115 above the stale maximum) is large enough for the overflow guard - the first half's scores are multiplied
+    again - and one lies in the key tail's tile."""
     from vggt_qwen3_amd import ops
     g = torch.Generator().manual_seed(3)
-    G, NH, N = 1, 1, 300
+    G, NH = 1, 1
     Q = torch.randn(G, NH, N, 64, generator=g)
     K = torch.randn(G, NH, N, 64, generator=g)
     V = torch.randn(G, NH, N, 64, generator=g)
-    for j, q in ((70, 5), (150, 5), (290, 40), (10, 100)):
-        K[0, 0, j] = Q[0, 0, q] * 3.0
+    spikes = [(70, 5, 3.0), (150, 5, 3.0), (290, 40, 3.0), (10, 100, 3.0)]
+    if N > 2048:
+        spikes += [(64 * 9 + 17, 7, 3.0), (64 * 9 + 49, 7, 4.0), (64 * 20 + 40, 300, 10.0), (64 * 21 + 3, 300, 3.0), (N - 3, 1500, 5.0)]
+    for j, q, f in spikes:
+        K[0, 0, j] = Q[0, 0, q] * f
     Q, K, V = Q.to(BF16).cuda(), K.to(BF16).cuda(), V.to(BF16).cuda()
     out = ops.flash_attn(Q, K, V).view(G, N, NH, 64).transpose(1, 2)
     ref = torch.nn.functional.scaled_dot_product_attention(Q.float(), K.float(), V.float())
