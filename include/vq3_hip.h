@@ -250,6 +250,10 @@ int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* qn_b, const 
  * reads it transposed out of LDS) -> O bf16 token-major O[(g*N + n)*ldo + h*64 + d]. */
 int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N,
                        int32_t head_dim, int64_t ldo, float scale, void* stream);
+/* The same for the first q_rows queries of every group only (keys / values: all N): O[(g*q_rows + n)*ldo + h*64 + d], n < q_rows.
+ * The reference keeps only the first num_vis_tokens rows of the last global block's output (src/models/vggt_qwen3_vlm.py:148-156). */
+int vq3_flash_attn_fwd_rows(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N,
+                            int32_t q_rows, int32_t head_dim, int64_t ldo, float scale, void* stream);
 
 /* Inverted dropout in place (the four nn.Dropout sites of a PerceiverLayer, src/models/projector_perceiver.py:33,37,42,46-49,
  * which stay ACTIVE under `model.train()` although encode_images runs under no_grad): element i is zeroed with probability p,

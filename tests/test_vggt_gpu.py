@@ -26,6 +26,22 @@ def test_flash_attention_vs_sdpa(G, NH, N):
     assert e < 1e-2, f"flash attention rel err {e}"
 
 
+@pytest.mark.parametrize("G,NH,N,nq", [(2, 2, 138, 40), (3, 16, 1029, 128), (1, 4, 2058, 128), (2, 4, 1029, 600), (1, 2, 300, 300)])
+def test_flash_attention_leading_query_rows(G, NH, N, nq):
+    """vq3_flash_attn_fwd_rows: the first nq queries of every group against all N keys -> [G * nq, NH * 64]."""
+    from vggt_qwen3_amd import ops
+    g = torch.Generator().manual_seed(N + nq)
+    Q = torch.randn(G, NH, N, 64, generator=g).to(BF16).cuda()
+    K = torch.randn(G, NH, N, 64, generator=g).to(BF16).cuda()
+    V = torch.randn(G, NH, N, 64, generator=g).to(BF16).cuda()
+    out = ops.flash_attn(Q, K, V, q_rows=nq)
+    assert out.shape == (G * nq, NH * 64)
+    ref = torch.nn.functional.scaled_dot_product_attention(Q[:, :, :nq].float(), K.float(), V.float())
+    assert relerr(out.view(G, nq, NH, 64).transpose(1, 2), ref) < 1e-2
+    with pytest.raises(RuntimeError):
+        ops.flash_attn(Q, K, V, q_rows=N + 1)
+
+
 @pytest.mark.parametrize("N", [300, 2200])
 def test_flash_attention_spiked_max(N):
     """Forces the running-max rescale: one key per tile dominates for some queries (guide rule 26). N = 300 runs the kernel variant with the
@@ -240,3 +256,23 @@ def test_aggregator_is_batch_invariant():
     assert yab.shape[0] == 3
     assert relerr(yab[:2], ya) < 1e-3 and relerr(yab[2:], yb) < 1e-3
     assert (yab[:2].float() - ya.float()).abs().max() <= 2 ** -6 * ya.float().abs().max()
+
+
+@pytest.mark.parametrize("n", [7, 40, 200])
+def test_aggregator_forward_head_equals_the_slice_the_reference_takes(n, monkeypatch):
+    """Aggregator.forward_head(images, n) = forward(images)[0][-1].reshape(B, S*P, 2C)[:, :n] (vggt_qwen3_vlm.py:144-156); the last global
+    block runs attention / proj / MLP on the kept rows only. n = 40 crosses from view 0 into view 1 (P = 35), 200 > S*P = 105 keeps all."""
+    from vggt_qwen3_amd.vggt import VGGT
+    for fold in ("1", "0"):
+        monkeypatch.setenv("VQ3_VGGT_LN_FOLD", fold)
+        model = VGGT(img_size=70, patch_size=14, embed_dim=128, depth=2, dino_depth=2, device="cuda", seed=3)
+        agg = model.aggregator
+        g = torch.Generator().manual_seed(19)
+        x = torch.rand(2, 3, 3, 70, 84, generator=g).cuda()
+        full = agg(x)[0][-1]
+        B, S, P, C2 = full.shape
+        want = full.reshape(B, S * P, C2)[:, :n]
+        got = agg.forward_head(x, n)
+        assert got.shape == want.shape
+        assert relerr(got, want) < 1e-3
+        assert (got.float() - want.float()).abs().max() <= 2 ** -6 * want.float().abs().max()

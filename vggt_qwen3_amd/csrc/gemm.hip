@@ -263,6 +263,8 @@ int launch_split_rows(GemmParams p, int nbatch, hipStream_t s) {
   if (p.epi == 1) { b.C = p.C; b.vit.m_off = m_main; }      // Q / K / V are addressed by token index, C is a placeholder
   if (p.ln_in) b.ln_in = p.ln_in + (long)m_main * p.ln_parts * 2;
   if (p.st_out) b.st_out = p.st_out + (long)m_main * (p.N >> 7) * 2;
+  // (tried: the row tail on a side stream forked from / joined to `s` by events so that it overlaps the main launch instead of following it -
+  // no gain, fc1 +3 %: the dispatcher does not interleave the two grids; gpurun_out r3_diag9 epi_30 vs epi_30_serial)
   int rc = launch_gemm_v6(a, 0, nbatch, s);
   if (rc) return rc;
   const long t128 = (long)((b.M + 127) / 128) * ((b.N + 127) / 128);
@@ -291,10 +293,14 @@ int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int tr
   }
   if (!g_flush && hipMalloc(&g_flush, FLUSH_BYTES) != hipSuccess) { (void)hipGetLastError(); g_flush = nullptr; return -1; }
   // trial output: dense scratch, no read-modify-write operands (an in-place residual or accumulate target must not be touched)
-  if (p.epi == 0) p.C = g_scratch_c;      // (epi == 1 writes Q / K / V: idempotent, no read-modify-write)
-  p.ldc = p.N; p.R = nullptr; p.ldr = 0; p.accumulate = 0;
-  p.sC1 = (long)p.M * p.N * p.nb2; p.sC2 = (long)p.M * p.N; p.sR1 = p.sR2 = 0;
-  p.vec_ok = (p.N % 4 == 0) ? 1 : 0;
+  if (p.epi == 0) p.C = g_scratch_c;      // (epi == 1 writes Q / K / V, epi == 3 gate|up and act: idempotent, no read-modify-write)
+  if (p.epi != 3) {
+    p.ldc = p.N;
+    p.sC1 = (long)p.M * p.N * p.nb2; p.sC2 = (long)p.M * p.N;
+    p.vec_ok = (p.N % 4 == 0) ? 1 : 0;
+  }
+  p.R = nullptr; p.ldr = 0; p.accumulate = 0;
+  p.sR1 = p.sR2 = 0;
   (void)hipDeviceSynchronize();   // measure alone: work queued on other streams (the wgrad stream) would skew the ranking
   (void)hipGetLastError();
   hipEvent_t e0, e1;
@@ -342,7 +348,7 @@ int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStr
 }  // namespace
 
 static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve, void* stream, const void* sw_gu = nullptr,
-                         void* sw_dgu = nullptr, const vq3_gemm_ln_fold* ln = nullptr) {
+                         void* sw_dgu = nullptr, const vq3_gemm_ln_fold* ln = nullptr, void* sw_fwd_gu = nullptr) {
   VQ3_CHECK_ARG(d != nullptr, "gemm: null descriptor");
   VQ3_CHECK_ARG(d->A && d->B && (d->C || ve || sw_dgu), "gemm: null operand pointer");
   VQ3_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -355,7 +361,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   VQ3_CHECK_ARG(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0), "gemm: A/B must be 16-byte aligned");
   VQ3_CHECK_ARG(d->sA1 % 8 == 0 && d->sA2 % 8 == 0 && d->sB1 % 8 == 0 && d->sB2 % 8 == 0,
                 "gemm: batch strides of A/B must be multiples of 8 elements");
-  VQ3_CHECK_ARG(ve || sw_dgu || d->ldc >= d->N, "gemm: ldc=%d < N=%d", d->ldc, d->N);
+  VQ3_CHECK_ARG(ve || sw_dgu || sw_fwd_gu || d->ldc >= d->N, "gemm: ldc=%d < N=%d", d->ldc, d->N);
   VQ3_CHECK_ARG(d->nb1 >= 1 && d->nb2 >= 1 && d->b2divB >= 1, "gemm: bad batch dims");
   VQ3_CHECK_ARG((long)d->nb1 * d->nb2 <= 65535, "gemm: too many batches");
   VQ3_CHECK_ARG(d->act >= 0 && d->act <= 2, "gemm: bad activation %d", d->act);
@@ -408,6 +414,17 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     p.C = sw_dgu; p.ldc = d->N;         // placeholders (alignment checks only)
     p.sC1 = p.sC2 = 0;
   }
+  if (sw_fwd_gu) {
+    VQ3_CHECK_ARG(!ve && !sw_dgu && !ln, "gemm_swiglu_fwd: no other fused epilogue");
+    VQ3_CHECK_ARG(!d->transA && !d->transB && d->K % BK == 0 && !d->out_f32 && !d->accumulate && !d->R && !d->colscale && !d->bias &&
+                      d->act == 0 && d->ksplit <= 1 && d->nb1 == 1 && d->nb2 == 1 && d->alpha == 1.f,
+                  "gemm_swiglu_fwd: plain NT bf16 GEMM (no epilogue, no batch), K %% 64 == 0");
+    VQ3_CHECK_ARG(d->N % 256 == 0 && d->ldc >= d->N / 2 && d->ldc % 8 == 0, "gemm_swiglu_fwd: N = 2 I with I %% 128 == 0, act rows of >= I elements (ld %% 8)");
+    VQ3_CHECK_ARG(((uintptr_t)sw_fwd_gu | (uintptr_t)d->C) % 16 == 0, "gemm_swiglu_fwd: gate|up / act must be 16-byte aligned");
+    p.epi = 3;
+    p.sw_dgu = (bf16_t*)sw_fwd_gu;
+    p.sC1 = p.sC2 = 0;
+  }
   const int esz = d->out_f32 ? 4 : 2;
   bool vec = (p.ldc % 4 == 0) && (p.sC1 % 4 == 0) && (p.sC2 % 4 == 0) && ((uintptr_t)p.C % (4 * esz) == 0);
   if (d->R) vec = vec && (d->ldr % 4 == 0) && (d->sR1 % 4 == 0) && (d->sR2 % 4 == 0) && ((uintptr_t)d->R % (4 * esz) == 0);
@@ -451,6 +468,15 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     const int rc = launch_gemm_v3(p, d->transA, d->transB, nstage, nbatch, s);
     if (rc) return rc;
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3)");
+    return 0;
+  }
+  if (p.epi == 3) {
+    // the 8-phase kernels only (the epilogue needs gate and up of a feature in ONE tile: gemm6.hip stages the two weight row ranges)
+    int cfg = (g_forced_cfg >= 20 && g_forced_cfg <= 22) ? g_forced_cfg : 20;
+    if (g_forced_cfg == -3 && (long)d->M * d->N * d->K >= (1L << 24)) cfg = tuned_choice(p, 0, 0, nbatch, s, {20, 21, 22}, 20);
+    const int rc = launch_gemm_v6(p, cfg - 20, nbatch, s);
+    if (rc) return rc;
+    VQ3_CHECK_LAUNCH("gemm_swiglu_fwd(v6)");
     return 0;
   }
   int cfg = choose_config(d->M, d->N, d->K, nbatch);
@@ -535,6 +561,11 @@ extern "C" int vq3_gemm_vit_qkv_ln(const vq3_gemm_desc* d, const vq3_vit_qkv_epi
 extern "C" int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* d, const void* gu, void* dgu, void* stream) {
   VQ3_CHECK_ARG(dgu != nullptr, "gemm_swiglu_bwd: null output pointer");
   return gemm_dispatch(d, nullptr, stream, gu, dgu);
+}
+
+extern "C" int vq3_gemm_swiglu_fwd(const vq3_gemm_desc* d, void* gu, void* stream) {
+  VQ3_CHECK_ARG(gu != nullptr && d != nullptr && d->C != nullptr, "gemm_swiglu_fwd: null output pointer");
+  return gemm_dispatch(d, nullptr, stream, nullptr, nullptr, nullptr, gu);
 }
 
 extern "C" int vq3_gemm_tile_order(int32_t M, int32_t N, int32_t bm, int32_t bn, int32_t wg_per_cu, int32_t* xm_out, int32_t* band_out,

@@ -42,7 +42,8 @@ constexpr int HALF = 128 * 128;          // bytes per half-tile (128 rows x 64 k
 // AH / BH = number of 128-row half-tiles of A / B per K tile: (2,2) = 256x256 (4 phases per K tile), (2,1) = 256x128 and
 // (1,2) = 128x256 (2 phases per K tile, same 16 MFMAs per phase and wave).
 // EK = epilogue kind, one instantiation each: 0 = plain C epilogue (alpha / bias / activation / LayerScale / residual / accumulate / output
-// statistics), 3 = the same behind a folded LayerNorm (p.ln_in), 1 = fused q|k|v epilogue (LayerNorm fold optional), 2 = SwiGLU backward.
+// statistics), 3 = the same behind a folded LayerNorm (p.ln_in), 1 = fused q|k|v epilogue (LayerNorm fold optional), 2 = SwiGLU backward,
+// 4 = SwiGLU forward (B = gate|up weight [2 I, K]: a tile multiplies BN/2 gate rows and the SAME BN/2 up rows, see set_offsets).
 // Compiled into ONE kernel they cost the 256 x 256 instantiation (256 VGPRs) 80 spilled registers in every launch's epilogue: the plain
 // fc1 launch (49 392 x 4096 x 1024) took 524 us with them and 443 us without (tools/gemm_stamps.py: "stage C" 13.1 -> 6.6 us per tile).
 template <int AH, int BH, bool OUT_F32, int EK = 0>
@@ -89,7 +90,12 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       }
 #pragma unroll
       for (int h = 0; h < BH; ++h) {
-        int rb = tn0 + h * 128 + r; rb = rb < p.N ? rb : p.N - 1;
+        int rb = tn0 + h * 128 + r;
+        if constexpr (EK == 4) {       // tile columns [0, BN/2) = gate features tn0/2 .., [BN/2, BN) = the same up features (weight rows I + ..)
+          const int li = h * 128 + r;
+          rb = li < BN / 2 ? (tn0 >> 1) + li : (p.N >> 1) + (tn0 >> 1) + li - BN / 2;
+        }
+        rb = rb < p.N ? rb : p.N - 1;
         offB[h][j] = (unsigned)(((long)rb * p.ldb + kch * 8) * 2);
       }
     }
@@ -358,6 +364,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
         if (p.bias) bias_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.colscale) cs_r[j][nt2] = *reinterpret_cast<const f32x4*>(p.colscale + n);
       }
+    EpiPre pre;
+    pre.on = false;
+    if constexpr (EK == 0) staged_prefetch<BM, BN>(p, coff, roff, m0, n0, tid, 512, pre);
     if (more) {
       // the next tile's first two K tiles: requested AFTER this epilogue's own operands (vmcnt counts in order: a wait for a younger
       // load would also wait for these), into the two buffers below the C image
@@ -389,14 +398,14 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
         }
     };
     // the activation is dispatched ONCE (the fused q|k|v and SwiGLU-backward epilogues never carry one)
-    if (EK != 1 && EK != 2 && p.act == 1) stage_all(std::integral_constant<int, 1>{});
-    else if (EK != 1 && EK != 2 && p.act == 2) stage_all(std::integral_constant<int, 2>{});
+    if (EK != 1 && EK != 2 && EK != 4 && p.act == 1) stage_all(std::integral_constant<int, 1>{});
+    else if (EK != 1 && EK != 2 && EK != 4 && p.act == 2) stage_all(std::integral_constant<int, 2>{});
     else stage_all(std::integral_constant<int, 0>{});
     V6_STAMP(6);    // this wave's quads are in the C image
     if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's K tiles 0 and 1 has landed
     __syncthreads();
     V6_STAMP(3);    // C image staged (and the next tile's first operands landed)
-    staged_store<BM, BN, (EK == 3 ? 0 : EK)>(p, smem_c, coff, roff, m0, n0, tid, 512);
+    staged_store<BM, BN, (EK == 3 ? 0 : EK)>(p, smem_c, coff, roff, m0, n0, tid, 512, &pre);     // (EK == 4: gate|up and act leave together)
     V6_STAMP(4);    // row stores issued
   } else {
     if (more) {
@@ -445,6 +454,7 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       vq3_set_error("gemm v6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
       return 2;
@@ -452,6 +462,10 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
     attr_done = true;
   }
   // bf16 output that cannot take the LDS-staged epilogue (rows not 16-byte aligned): the loader-ring kernel keeps the per-quad path
+  if (p.epi == 3 && (p.out_f32 || !host_staged_ok(p) || (p.N >> 1) % (64 * BH) != 0)) {
+    vq3_set_error("gemm v6: the SwiGLU-forward epilogue needs the staged bf16 path and I %% %d == 0", 64 * BH);
+    return 1;
+  }
   if (!p.out_f32 && !host_staged_ok(p)) return launch_gemm_v2(p, AH == 2 ? 11 : 13, nbatch, stream);
   p.mtiles = (p.M + 128 * AH - 1) / (128 * AH);
   p.ntiles = (p.N + 128 * BH - 1) / (128 * BH);
@@ -477,6 +491,8 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false, 1>), grid, dim3(512), SMEM, stream, p);
   else if (p.epi == 2)
     hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false, 2>), grid, dim3(512), SMEM, stream, p);
+  else if (p.epi == 3)
+    hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false, 4>), grid, dim3(512), SMEM, stream, p);
   else if (p.ln_in)
     hipLaunchKernelGGL((gemm_v6_kernel<AH, BH, false, 3>), grid, dim3(512), SMEM, stream, p);
   else

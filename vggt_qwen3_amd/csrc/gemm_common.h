@@ -38,10 +38,11 @@ struct GemmParams {
   int accumulate;  // C += result
   int vec_ok;      // C (and R) rows are 16B (f32) / 8B (bf16) aligned for 4-wide stores
   float alpha;
-  int epi;         // 0 = C / R epilogue; 1 = VitQkvEpi; 2 = SwiGLU backward (staged path only)
+  int epi;         // 0 = C / R epilogue; 1 = VitQkvEpi; 2 = SwiGLU backward; 3 = SwiGLU forward (staged path only; 3: gemm6.hip only)
   VitQkvEpi vit;
   const bf16_t* sw_gu;   // epi == 2: saved gate|up pre-activations [M, 2N]
   bf16_t* sw_dgu;        //           d(gate|up) [M, 2N]; the GEMM result d(act) [M, N] is never written
+                         // epi == 3: N = 2 I columns gate | up; sw_dgu = gate|up out [M, 2 I], C / ldc = act out [M, I] = silu(gate) * up
   // LayerNorm folded into the GEMM that consumes it (staged epilogue only): A holds the raw rows x, B = gamma o W, bias = b + W.beta,
   // ln_c[n] = sum_k B[n,k]; the row statistics arrive as ln_parts (sum, sum of squares) pairs per row. y = rstd (acc - mu c) + bias.
   const float* ln_in;    // [M, ln_parts, 2] or null
@@ -368,10 +369,70 @@ __device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* s
 // adding the residual (rounded, as PyTorch's bf16 add) and / or the old C (accumulate) on the way. Needs p.vec_ok, ldc % 8 == 0
 // and a 16-byte aligned C (checked by staged_ok on the host side of the kernel).
 // EPIK >= 0: only that epilogue kind is compiled in (the caller guarantees p.epi == EPIK); -1: run-time dispatch
+// The residual / old-C operands of a thread's FIRST batch of rows (the rows staged_store hands it first), requested before the C tile is
+// staged: their round trip - every CU of a round asks within the same microseconds - runs under the staging instead of after it
+// (tools/gemm_stamps.py, proj 49 392 x 1024 x 1024 + residual: "issue stores" 13.8 us per tile against 3.2 us without a residual).
+struct EpiPre {
+  u32x4 v[EPI_U];      // the residual rows, or the old C rows of an accumulating launch (a launch with both is not prefetched)
+  bool on;
+};
+template <int BM, int BN>
+__device__ __forceinline__ void staged_load_rows(const GemmParams& p, const bf16_t* src, long ld, int m0, int n, int row0, int rpp,
+                                                 u32x4 (&v)[EPI_U]) {
+#pragma unroll
+  for (int u = 0; u < EPI_U; ++u) {
+    const int row = row0 + u * rpp, m = m0 + row;
+    const long mc = (row < BM && m < p.M) ? m : p.M - 1;
+    v[u] = *reinterpret_cast<const u32x4*>(src + mc * ld + n);
+  }
+}
+template <int BM, int BN>
+__device__ __forceinline__ void staged_prefetch(const GemmParams& p, long coff, long roff, int m0, int n0, int tid, int nthreads, EpiPre& pre) {
+  constexpr int CPR = BN / 8;
+  const int n = n0 + (tid % CPR) * 8;
+  pre.on = p.epi == 0 && ((p.R != nullptr) != (p.accumulate != 0)) && n + 7 < p.N;
+  if (!pre.on) return;
+  if (p.R) staged_load_rows<BM, BN>(p, reinterpret_cast<const bf16_t*>(p.R) + roff, p.ldr, m0, n, tid / CPR, nthreads / CPR, pre.v);
+  else staged_load_rows<BM, BN>(p, reinterpret_cast<const bf16_t*>(p.C) + coff, p.ldc, m0, n, tid / CPR, nthreads / CPR, pre.v);
+}
+
 template <int BM, int BN, int EPIK = -1>
 __device__ __forceinline__ void staged_store(const GemmParams& p, const char* smem, long coff, long roff, int m0, int n0, int tid,
-                                             int nthreads) {
+                                             int nthreads, const EpiPre* pre = nullptr) {
   constexpr int CPR = BN / 8;                  // 16-byte chunks per row
+  if constexpr (EPIK == 4) {
+    // SwiGLU forward (modeling_qwen3.py:81-83): the tile's columns are [BN/2 gate | the same BN/2 up columns] (the kernel stages the
+    // two weight row ranges side by side), so a thread holds gate and up of 8 features of one row: both leave to gate|up [M, 2 I] as
+    // the backward reads them, act = bf16(bf16(silu(g)) * u) to C - arithmetic and rounding points of silu_mul_fwd_kernel.
+    constexpr int HC = BN / 16;                // chunks per half row
+    const int inter = p.N >> 1;
+    const int rpp = nthreads / HC, c = tid % HC, n = (n0 >> 1) + c * 8;
+    if (n >= inter) return;                    // I % 8 == 0 (host)
+    bf16_t* act = reinterpret_cast<bf16_t*>(p.C) + coff;
+    for (int row = tid / HC; row < BM; row += rpp) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
+      const u32x4 uv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c + HC));
+      u32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float r[2];
+#pragma unroll
+        for (int hgh = 0; hgh < 2; ++hgh) {
+          const float gf = bf2f((bf16_t)((gv[k] >> (16 * hgh)) & 0xffff));
+          const float uf = bf2f((bf16_t)((uv[k] >> (16 * hgh)) & 0xffff));
+          r[hgh] = rbf(silu_f(gf)) * uf;
+        }
+        o[k] = pack2bf(r[0], r[1]);
+      }
+      bf16_t* gp = p.sw_dgu + (long)m * p.N + n;
+      *reinterpret_cast<u32x4*>(gp) = gv;
+      *reinterpret_cast<u32x4*>(gp + inter) = uv;
+      *reinterpret_cast<u32x4*>(act + (long)m * p.ldc + n) = o;
+    }
+    return;
+  }
   if ((EPIK < 0 || EPIK == 1) && p.epi == 1) {
     vit_qkv_store<BM, BN>(p, smem, m0, n0, tid, nthreads);
     return;
@@ -430,23 +491,31 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
   if (n >= p.N) return;
   const bool fulln = n + 7 < p.N;
   if (fulln) {
+    // residual / old-C rows of EPI_U passes are requested before any of them is used, and the NEXT batch's before this batch's stores
+    // (which the compiler must assume alias them): the round trips overlap the arithmetic and the stores of the batch before
+    u32x4 rv[EPI_U], cv[EPI_U];
+    const bool pre_r = pre && pre->on && R, pre_c = pre && pre->on && !R;
+    if (pre_r) {
+#pragma unroll
+      for (int u = 0; u < EPI_U; ++u) rv[u] = pre->v[u];
+    } else if (R) {
+      staged_load_rows<BM, BN>(p, R, p.ldr, m0, n, tid / CPR, rpp, rv);
+    }
+    if (pre_c) {
+#pragma unroll
+      for (int u = 0; u < EPI_U; ++u) cv[u] = pre->v[u];
+    } else if (p.accumulate) {
+      staged_load_rows<BM, BN>(p, C, p.ldc, m0, n, tid / CPR, rpp, cv);
+    }
     for (int row0 = tid / CPR; row0 < BM; row0 += rpp * EPI_U) {
-      // residual / old-C rows of EPI_U passes are requested before any of them is used (and before this batch's stores, which
-      // the compiler must assume alias them): one L2 / HBM round trip per batch instead of one per row
-      u32x4 rv[EPI_U], cv[EPI_U];
-      bool ok[EPI_U];
+      u32x4 rn[EPI_U], cn[EPI_U];
+      const bool nxt = row0 + rpp * EPI_U < BM;
+      if (nxt && R) staged_load_rows<BM, BN>(p, R, p.ldr, m0, n, row0 + rpp * EPI_U, rpp, rn);
+      if (nxt && p.accumulate) staged_load_rows<BM, BN>(p, C, p.ldc, m0, n, row0 + rpp * EPI_U, rpp, cn);
 #pragma unroll
       for (int u = 0; u < EPI_U; ++u) {
         const int row = row0 + u * rpp, m = m0 + row;
-        ok[u] = row < BM && m < p.M;
-        const long mc = ok[u] ? m : p.M - 1;
-        if (R) rv[u] = *reinterpret_cast<const u32x4*>(R + mc * p.ldr + n);
-        if (p.accumulate) cv[u] = *reinterpret_cast<const u32x4*>(C + mc * p.ldc + n);
-      }
-#pragma unroll
-      for (int u = 0; u < EPI_U; ++u) {
-        if (!ok[u]) continue;
-        const int row = row0 + u * rpp, m = m0 + row;
+        if (!(row < BM && m < p.M)) continue;
         const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
         float v[8];
 #pragma unroll
@@ -479,6 +548,10 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
           if ((c & 15) == 0)
             *reinterpret_cast<float2*>(p.st_out + ((long)m * (p.N >> 7) + (n >> 7)) * 2) = float2{sm, sq};
         }
+      }
+      if (nxt) {
+#pragma unroll
+        for (int u = 0; u < EPI_U; ++u) { rv[u] = rn[u]; cv[u] = cn[u]; }
       }
     }
     return;

@@ -229,7 +229,7 @@ __device__ __forceinline__ int fa_vswz(int row, int chunk) { return row * 128 + 
 template <int QB, int NT, int VAR = 0>
 __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-                                                                 int N, int NH, long ldo, float scale_log2e, int q_begin, int q_end) {
+                                                                 int N, int NH, long ldo, float scale_log2e, int q_begin, int q_end, int o_rows) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * FA_KV * 128];   // 2 stages x (K tile | V tile)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       const float inv = 1.f / (LSUM ? lacc[qb][0] : l_run[qb]);
       const long g = nb / NH;
       const int hd = (int)(nb % NH);
-      bf16_t* orow = O + (g * N + q) * ldo + hd * 64;
+      bf16_t* orow = O + (g * o_rows + q) * ldo + hd * 64;     // o_rows = N, or the leading rows kept per group
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {
         const int d = 8 * i4 + 4 * h;
@@ -750,9 +750,10 @@ extern "C" int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* q
   return 0;
 }
 
-extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH,
-                                  int32_t N, int32_t head_dim, int64_t ldo, float scale, void* stream) {
+static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N, int32_t q_rows,
+                               int32_t head_dim, int64_t ldo, float scale, void* stream) {
   VQ3_CHECK_ARG(Q && K && V && O, "flash_attn_fwd: null pointer");
+  VQ3_CHECK_ARG(q_rows > 0 && q_rows <= N, "flash_attn_fwd: q_rows must be in 1..N, got %d", q_rows);
   VQ3_CHECK_ARG(head_dim == 64, "flash_attn_fwd: head_dim must be 64, got %d", head_dim);
   VQ3_CHECK_ARG(G > 0 && NH > 0 && N > 0, "flash_attn_fwd: bad shape");
   VQ3_CHECK_ARG((long)G * NH <= 65535, "flash_attn_fwd: too many (group, head) pairs");
@@ -761,15 +762,16 @@ extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, v
   static int qb_forced = -1;
   if (qb_forced < 0) { const char* e = getenv("VQ3_FLASH_QB"); qb_forced = e ? atoi(e) : 0; }
   // two query blocks per wave (every K / V fragment read feeds two MFMA chains) once there are enough rows to fill them
-  int qb = qb_forced ? qb_forced : (N >= 512 ? 2 : 1);
+  int qb = qb_forced ? qb_forced : (q_rows >= 512 ? 2 : 1);
   if (!qb_forced && qb == 2) {
     // 512 workgroup slots (2 per CU at 2 query blocks per wave): a grid of 1 .. 2 rounds whose last round is mostly empty - one
     // 8 232-token sample: 33 x 16 = 528 workgroups - runs better as 3-per-CU workgroups of half the rows (602 -> 670 TF/s)
-    const double r = (double)((N + 255) / 256) * G * NH / 512.0;
+    const double r = (double)((q_rows + 255) / 256) * G * NH / 512.0;
     if (r > 1.0 && r < 2.0 && (double)(long)(r + 0.999999) - r > 0.4) qb = 1;
   }
   const float sl2 = scale * 1.44269504088896340736f;
-  int q_main = N;
+  int q_main = q_rows;
+  bool forked = false;
   // ragged tail of <= 32 rows past a multiple of 256 (and >= 512 (sample, head) pairs, so that the saved slots matter): the four-wave
   // launch takes the exact blocks, a one-wave launch on a side stream (forked from / joined to `stream` by events) the tail
   const int tail = N % 256;
@@ -778,7 +780,7 @@ extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, v
   static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   if (tail_split < 0) { const char* e = getenv("VQ3_FLASH_TAIL"); tail_split = e ? atoi(e) : 1; }
   // (measured: 48 x 16 pairs 409 -> 364 us; 6 x 16 pairs 51 -> 61 us - the one-wave launch is as long as the main one there)
-  if (tail_split && qb == 2 && tail > 0 && tail <= 32 && N > 256 && (long)G * NH >= (tail_split > 1 ? tail_split : 512)) {
+  if (tail_split && q_rows == N && qb == 2 && tail > 0 && tail <= 32 && N > 256 && (long)G * NH >= (tail_split > 1 ? tail_split : 512)) {
     if (!side) {
       if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -788,10 +790,11 @@ extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, v
     }
     if (side) {
       q_main = N - tail;
+      forked = true;
       (void)hipEventRecord(ev_fork, (hipStream_t)stream);
       (void)hipStreamWaitEvent(side, ev_fork, 0);
       hipLaunchKernelGGL((flash_attn_hd64_kernel<1, 64>), dim3(1, G * NH), dim3(64), 0, side, (const bf16_t*)Q, (const bf16_t*)K,
-                         (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N);
+                         (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N, N);
       (void)hipEventRecord(ev_join, side);
     }
   }
@@ -803,14 +806,26 @@ extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, v
   const int fvar = fvar_env >= 0 ? fvar_env : (N >= 2048 ? 1 : 0);
   if (qb == 2 && fvar == 1)
     hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows);
   else if (qb == 2)
     hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows);
   else
     hipLaunchKernelGGL((flash_attn_hd64_kernel<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main);
-  if (q_main != N) (void)hipStreamWaitEvent((hipStream_t)stream, ev_join, 0);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows);
+  if (forked) (void)hipStreamWaitEvent((hipStream_t)stream, ev_join, 0);
   VQ3_CHECK_LAUNCH("flash_attn_fwd");
   return 0;
+}
+
+extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH,
+                                  int32_t N, int32_t head_dim, int64_t ldo, float scale, void* stream) {
+  return flash_attn_fwd_impl(Q, K, V, O, G, NH, N, N, head_dim, ldo, scale, stream);
+}
+
+// The same attention for the first q_rows queries of every group only (all N keys): O[(g*q_rows + n)*ldo + h*64 + d], n < q_rows. The
+// last global block of the aggregator feeds only the first num_vis_tokens rows of each sample to the projector (vggt_qwen3_vlm.py:148-156).
+extern "C" int vq3_flash_attn_fwd_rows(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N,
+                                       int32_t q_rows, int32_t head_dim, int64_t ldo, float scale, void* stream) {
+  return flash_attn_fwd_impl(Q, K, V, O, G, NH, N, q_rows, head_dim, ldo, scale, stream);
 }

@@ -558,15 +558,22 @@ def linear_vit_qkv(x: torch.Tensor, w: torch.Tensor, bias, N: int, NH: int, *, q
     return Q, Kt, V
 
 
-def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """softmax(Q K^T / 8) V for Q,K,V bf16 [G, NH, N, 64] -> token-major [G*N, NH*64]."""
+def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None, q_rows: Optional[int] = None) -> torch.Tensor:
+    """softmax(Q K^T / 8) V for Q,K,V bf16 [G, NH, N, 64] -> token-major [G*N, NH*64]; with q_rows only the first q_rows queries of
+    every group are computed (all N keys) -> [G*q_rows, NH*64]."""
     _req(Q, BF16, "flash Q"); _req(K, BF16, "flash K"); _req(V, BF16, "flash V")
     assert Q.is_contiguous() and K.is_contiguous() and V.is_contiguous() and K.shape == Q.shape and V.shape == Q.shape
     G, NH, N, D = Q.shape
+    nq = N if q_rows is None else int(q_rows)
     if out is None:
-        out = torch.empty((G * N, NH * D), device=Q.device, dtype=BF16)
-    check(_lib.load().vq3_flash_attn_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), G, NH, N, D,
-                                         out.stride(0), D ** -0.5, _stream()), "vq3_flash_attn_fwd")
+        out = torch.empty((G * nq, NH * D), device=Q.device, dtype=BF16)
+    assert out.shape[0] >= G * nq
+    if q_rows is None:
+        check(_lib.load().vq3_flash_attn_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), G, NH, N, D,
+                                             out.stride(0), D ** -0.5, _stream()), "vq3_flash_attn_fwd")
+    else:
+        check(_lib.load().vq3_flash_attn_fwd_rows(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), G, NH, N, nq, D,
+                                                  out.stride(0), D ** -0.5, _stream()), "vq3_flash_attn_fwd_rows")
     return out
 
 

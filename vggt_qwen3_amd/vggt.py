@@ -215,9 +215,16 @@ class Aggregator(nn.Module):
         return self._rope_cache[maxpos]
 
     # ------------------------------------------------------------------ one transformer block
-    def _block(self, x, w, N, *, rope, eps, P, Wp, st=None):
-        """One pre-norm block. Returns (x_out, statistics of x_out's rows for the next block's first LayerNorm, or None)."""
+    def _block(self, x, w, N, *, rope, eps, P, Wp, st=None, keep=None):
+        """One pre-norm block. Returns (x_out, statistics of x_out's rows for the next block's first LayerNorm, or None).
+        keep = n: only the first n rows of every N-token group leave the block ([G*n, C]) - q|k|v still covers all rows (every key and
+        value is attended), attention / proj / MLP run on the kept queries alone. Row-wise ops: the kept rows equal the full block's."""
         NH = self.num_heads
+        if keep is not None and keep < N:
+            G = x.shape[0] // N
+            head = lambda t: t.view(G, N, *t.shape[1:])[:, :keep].reshape(G * keep, *t.shape[1:]).contiguous()
+        else:
+            keep, head = None, (lambda t: t)
         if self._ln_fold:
             # no LayerNorm launch, no normalised copy of x: the q|k|v and fc1 GEMMs read the raw rows and apply (mu, rstd) in their
             # epilogues; the residual GEMMs that form x leave the (sum, sum of squares) pairs the next fold needs
@@ -230,8 +237,9 @@ class Aggregator(nn.Module):
                                              tokens_per_frame=P, patch_start=self.patch_start_idx, Wp=Wp, eps=1e-5, **kw)
             else:
                 Q, K, V = ops.linear_vit_qkv(x, w["qkv_wf"], w["qkv_d"], N, NH, **kw)
-            o = ops.flash_attn(Q, K, V)
-            st2 = torch.empty((T, C // 128, 2), device=x.device, dtype=torch.float32)
+            o = ops.flash_attn(Q, K, V, q_rows=keep)
+            x = head(x)
+            st2 = torch.empty((x.shape[0], C // 128, 2), device=x.device, dtype=torch.float32)
             x = ops.linear(o, w["proj_w"], bias=w["proj_b"], colscale=w["ls1"], residual=x, ln_fold=ops.ln_fold(stats_out=st2))
             h = ops.linear(x, w["fc1_wf"], bias=w["fc1_d"], act=ops.ACT_GELU,
                            ln_fold=ops.ln_fold(stats_in=st2, eps=eps, colsum=w["fc1_c"]))
@@ -245,8 +253,8 @@ class Aggregator(nn.Module):
                                          tokens_per_frame=P, patch_start=self.patch_start_idx, Wp=Wp, eps=1e-5)
         else:
             Q, K, V = ops.linear_vit_qkv(xn, w["qkv_w"], w["qkv_b"], N, NH)
-        o = ops.flash_attn(Q, K, V)
-        x = ops.linear(o, w["proj_w"], bias=w["proj_b"], colscale=w["ls1"], residual=x)
+        o = ops.flash_attn(Q, K, V, q_rows=keep)
+        x = ops.linear(o, w["proj_w"], bias=w["proj_b"], colscale=w["ls1"], residual=head(x))
         xn2, _ = ops.layernorm_fwd(x, w["n2"][0], w["n2"][1], eps)
         h = ops.linear(xn2, w["fc1_w"], bias=w["fc1_b"], act=ops.ACT_GELU)
         return ops.linear(h, w["fc2_w"], bias=w["fc2_b"], colscale=w["ls2"], residual=x), None
@@ -286,7 +294,7 @@ class Aggregator(nn.Module):
         return x.view(B * S, -1, self.embed_dim)
 
     @torch.no_grad()
-    def forward(self, images: torch.Tensor, return_all: bool = False):
+    def forward(self, images: torch.Tensor, return_all: bool = False, _head_rows: Optional[int] = None):
         """images [B, S, 3, H, W] in [0,1] -> ([... , tokens [B, S, P, 2C]], patch_start_idx).
         Only the last iterate is materialised unless return_all (the reference reads list[-1] only)."""
         cc = self._prepare()
@@ -309,10 +317,24 @@ class Aggregator(nn.Module):
         for i in range(self.depth):
             x, st = self._block(x, cc["frame"][i], P, rope=rope, eps=1e-5, P=P, Wp=Wp, st=st)
             fr = x
+            if _head_rows is not None and not return_all and i == self.depth - 1:
+                n = min(_head_rows, S * P)
+                x, _ = self._block(x, cc["global"][i], S * P, rope=rope, eps=1e-5, P=P, Wp=Wp, st=st, keep=n)
+                outs.append(torch.cat([fr.view(B, S * P, C)[:, :n], x.view(B, n, C)], dim=-1))          # [B, n, 2C]
+                break
             x, st = self._block(x, cc["global"][i], S * P, rope=rope, eps=1e-5, P=P, Wp=Wp, st=st)
             if return_all or i == self.depth - 1:
                 outs.append(torch.cat([fr.view(B, S, P, C), x.view(B, S, P, C)], dim=-1))
         return outs, self.patch_start_idx
+
+    @torch.no_grad()
+    def forward_head(self, images: torch.Tensor, n: int) -> torch.Tensor:
+        """forward(images)[0][-1].reshape(B, S*P, 2C)[:, :n] - all the reference reads of the tower (vggt_qwen3_vlm.py:144-156: the last
+        iterate, flattened over views, first num_vis_tokens rows) - without the rows nobody reads: the LAST global block computes its
+        attention output, proj and MLP for the first n tokens of every sample only (its q|k|v, and every earlier block, are needed in
+        full: all tokens are keys / values of the kept queries)."""
+        toks, _ = self.forward(images, _head_rows=int(n))
+        return toks[-1]
 
 
 class VGGT(nn.Module):

@@ -12,6 +12,7 @@ hand-written HIP backward of the whole text model (+ geom_head), so `accelerator
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Dict, Optional
@@ -169,6 +170,7 @@ class VGGTQwen3VLM(nn.Module):
         if config.fp8_text_forward:
             self.text_model.enable_fp8_forward(True)
         self._vis_stream = None
+        self._vision_head = os.environ.get("VQ3_VISION_HEAD", "1") != "0"
         self._prefetched = None
         self._vis_group = []          # [(images tensor, aggregator tokens)]: precompute_vision() results waiting for their micro-batch
         self._text_param_names = [n for n, _ in self.text_model.named_parameters()]
@@ -210,6 +212,16 @@ class VGGTQwen3VLM(nn.Module):
         return model
 
     # ------------------------------------------------------------------ encoders
+    def _aggregate(self, images: torch.Tensor) -> torch.Tensor:
+        """aggregated_tokens_list[-1] of the tower (vggt_qwen3_vlm.py:144-147). Our aggregator can stop at the rows the slicing below
+        keeps (Aggregator.forward_head: the last global block's proj / MLP for the first num_vis_tokens rows of a sample only - an exact
+        shortcut, VQ3_VISION_HEAD=0 computes every row); any other tower is called the reference's way."""
+        agg_mod = self.vision_model.aggregator
+        if self._vision_head and hasattr(agg_mod, "forward_head"):
+            return agg_mod.forward_head(images, self.num_vis_tokens)
+        toks, _ = agg_mod(images)
+        return toks[-1]
+
     @torch.no_grad()
     def precompute_vision(self, images_list) -> None:
         """The frozen aggregator (vggt_qwen3_vlm.py:44-45,128-144: no_grad, eval-mode arithmetic, no dropout) for SEVERAL upcoming
@@ -223,8 +235,7 @@ class VGGTQwen3VLM(nn.Module):
         shapes = {tuple(im.shape[1:]) for im in imgs}
         if len(shapes) != 1:                               # different view counts / sizes cannot share a pass
             return
-        toks, _ = self.vision_model.aggregator(torch.cat(imgs, dim=0) if len(imgs) > 1 else imgs[0])
-        agg = toks[-1]
+        agg = self._aggregate(torch.cat(imgs, dim=0) if len(imgs) > 1 else imgs[0])
         if agg.shape[0] != sum(im.shape[0] for im in imgs):    # (a tower that does not keep the batch axis first: no sharing)
             return
         b0 = 0
@@ -249,8 +260,7 @@ class VGGTQwen3VLM(nn.Module):
         B = images.shape[0]
         agg = self._take_grouped(images if _orig is None else _orig) if self._vis_group else None
         if agg is None:
-            toks, _ = self.vision_model.aggregator(images)
-            agg = toks[-1]
+            agg = self._aggregate(images)
         if agg.dim() == 3:
             agg = agg[:, : self.num_vis_tokens, :]
         elif agg.dim() == 4:
