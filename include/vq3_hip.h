@@ -105,6 +105,12 @@ int vq3_rowstats128(const void* x_bf16, float* stats, int64_t rows, int32_t cols
  * pre-activations gu bf16 [M, 2N] = gate | up into dgu bf16 [M, 2N] = d(gate) | d(up), d(gate) = d(act) * up * silu'(gate),
  * d(up) = d(act) * silu(gate) - same arithmetic and rounding as vq3_silu_mul_bwd on the materialised d(act). */
 int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* desc, const void* gu, void* dgu, void* stream);
+/* The gate|up projection with the SwiGLU forward in its epilogue (Qwen3MLP.forward, modeling_qwen3.py:81-83): desc is the plain NT GEMM
+ * x [M, K] . W_gate|up [2 I, K]^T (N = 2 I, I % 128 == 0, K % 64 == 0, no bias / residual / batch); every tile multiplies a block of gate
+ * rows of W and the same block of up rows, so the epilogue holds both halves of a feature: gu bf16 [M, 2 I] = gate | up is written as the
+ * backward reads it, and desc->C / ldc receive act bf16 [M, I] = bf16(bf16(silu(gate)) * up) - same arithmetic and rounding as
+ * vq3_silu_mul_fwd on the materialised gu. */
+int vq3_gemm_swiglu_fwd(const vq3_gemm_desc* desc, void* gu, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Normalisation
@@ -118,6 +124,9 @@ int vq3_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t 
  * written); reduce it with vq3_colsum_f32_to_bf16. dres may be NULL; dx may alias dres. */
 int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                     float* dw_part, int64_t rows, int32_t cols, float eps, void* stream);
+/* The same with rows_per_part rows (a multiple of 4, 4..256) per workgroup and partial row: dw_part f32 [ceil(rows/rows_per_part), cols]. */
+int vq3_rmsnorm_bwd_rows(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                         float* dw_part, int64_t rows, int32_t cols, int32_t rows_per_part, void* stream);
 /* out_bf16[c] (+)= sum_{r < nrows} part[r*cols + c]: column sum of a partial slab into a (bf16) gradient vector. */
 int vq3_colsum_f32_to_bf16(const float* part, int32_t nrows, int32_t cols, void* out_bf16, int32_t accumulate,
                            void* stream);

@@ -301,6 +301,36 @@ def test_gemm_swiglu_bwd_epilogue_equals_two_launches(ops, transB):
     assert _relerr(got[:, :I], g32.grad) < 1e-2 and _relerr(got[:, I:], u32.grad) < 1e-2
 
 
+@pytest.mark.parametrize("cfg", [-3, 20, 21, 22])
+@pytest.mark.parametrize("M,H,I", [(300, 256, 384), (1200, 2560, 9728), (77, 128, 128)])
+def test_gemm_swiglu_fwd_epilogue_equals_two_launches(ops, cfg, M, H, I):
+    """vq3_gemm_swiglu_fwd (gate|up projection with silu(gate) * up in its epilogue) against the two launches it replaces - vq3_gemm_bf16_nt
+    then vq3_silu_mul_fwd: gu and act bit-identical (same k order per element, same rounding points); act written into a row block of a
+    longer slab, as the trainer's deferred weight-gradient operands are; ragged M inside a tile."""
+    x = _rand((M, H), 1.0, seed=50)
+    W = _rand((2 * I, H), 0.05, seed=51)                      # [gate rows | up rows]
+    ops.gemm_force_config(cfg)
+    try:
+        gu_ref = ops.linear(x, W)
+        act_ref = ops.silu_mul_fwd(gu_ref)
+        slab = torch.full((M + 5, I), 7.0, device="cuda", dtype=BF16)
+        gu, act = ops.gemm_swiglu_fwd(x, W, act_out=slab[2:2 + M])
+    finally:
+        ops.gemm_force_config(-3)
+    assert act.data_ptr() == slab[2:].data_ptr()
+    if cfg == -3:                  # (the tuner may give the two paths different tile shapes: compare the fused pair with itself)
+        assert _relerr(gu, gu_ref) < 1e-3
+        assert torch.equal(act, ops.silu_mul_fwd(gu))
+    else:
+        assert torch.equal(gu, gu_ref)
+        assert torch.equal(act, act_ref)
+    assert (slab[:2] == 7.0).all() and (slab[2 + M:] == 7.0).all()            # nothing outside the row block
+    ref = torch.nn.functional.silu(gu_ref[:, :I].float()).to(BF16).float() * gu_ref[:, I:].float()
+    assert _relerr(act, ref) < 4e-3
+    with pytest.raises(RuntimeError):
+        ops.gemm_swiglu_fwd(x, _rand((2 * 200, H), 0.05, seed=52))             # I % 128 != 0
+
+
 def test_gemm_batched_strided(ops):
     """Attention-shaped use: batch (b, h) with K/V shared by groups of heads and a strided output."""
     Bz, Hq, Hkv, L, D = 2, 8, 2, 200, 128

@@ -1,0 +1,11 @@
+#!/bin/bash
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r3_diag11
+rm -rf $O; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "swiglu" > $O/pytest_a.log 2>&1 && echo pytest a ok
+tail -n 3 $O/pytest_a.log
+VQ3_GEMM_TABLE=1 timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-variants --no-trim-variant --no-cpu-baseline > $O/bench.log 2> $O/bench.err && echo bench ok
+VQ3_SWIGLU_FWD_FUSED=0 timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-variants --no-trim-variant --no-cpu-baseline > $O/bench_off.log 2> $O/bench_off.err && echo bench off ok
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/pytest_b.log 2>&1 && echo pytest b ok
+tail -n 3 $O/pytest_b.log

@@ -56,11 +56,13 @@ SIGNATURES = {
     "vq3_gemm_bf16_nt": [C.POINTER(GemmDesc), c_p],
     "vq3_gemm_vit_qkv": [C.POINTER(GemmDesc), C.POINTER(VitQkvEpilogue), c_p],
     "vq3_gemm_swiglu_bwd": [C.POINTER(GemmDesc), c_p, c_p, c_p],
+    "vq3_gemm_swiglu_fwd": [C.POINTER(GemmDesc), c_p, c_p],
     "vq3_gemm_bf16_nt_ln": [C.POINTER(GemmDesc), C.POINTER(GemmLnFold), c_p],
     "vq3_gemm_vit_qkv_ln": [C.POINTER(GemmDesc), C.POINTER(VitQkvEpilogue), C.POINTER(GemmLnFold), c_p],
     "vq3_rowstats128": [c_p, c_p, i64, i32, c_p],
     "vq3_rmsnorm_fwd": [c_p, c_p, c_p, c_p, i64, i32, i64, i64, f32, c_p],
     "vq3_rmsnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
+    "vq3_rmsnorm_bwd_rows": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, i32, c_p],
     "vq3_colsum_f32_to_bf16": [c_p, i32, i32, c_p, i32, c_p],
     "vq3_colsum_multi": [C.POINTER(ColsumJob), i32, c_p],
     "vq3_layernorm_fwd": [c_p, c_p, i32, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],

@@ -49,12 +49,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 // registers (one HBM read); the four waves' dw contributions meet in LDS and leave as ONE plain-store row of the
 // partial slab dw_part[blockIdx][cols] - no global atomics (300 blocks hammering one 10-KB row ran ~14x below the
 // atomic rate); vq3_colsum_f32_to_bf16 sums the slab straight into the bf16 gradient.
-constexpr int RB_ROWS = 4;
 template <int NCH>  // cols <= NCH * 512
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* dres, bf16_t* dx, float* __restrict__ dw,
-                                                          long rows, int cols) {
+                                                          long rows, int cols, int rb_rows) {
   extern __shared__ __attribute__((aligned(16))) float dw_s[];   // [4 waves][cols]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float dwacc[NCH][8];
@@ -66,8 +65,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     for (int j = 0; j < 8; ++j) dwacc[ch][j] = 0.f;
     if (c < cols) wv[ch] = *reinterpret_cast<const bf16x8*>(w + c);
   }
-  for (int rr = 0; rr < RB_ROWS / 4; ++rr) {
-    const long row = (long)blockIdx.x * RB_ROWS + rr * 4 + wid;
+  for (int rr = 0; rr < rb_rows / 4; ++rr) {          // rb_rows rows per workgroup (= per partial dw row), one row per wave and pass
+    const long row = (long)blockIdx.x * rb_rows + rr * 4 + wid;
     if (row >= rows) break;
     const float rs = rstd[row];
     const bf16_t* xr = x + row * (long)cols;
@@ -480,16 +479,16 @@ extern "C" int vq3_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
   return 0;
 }
 
-extern "C" int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
-                               void* dx, float* dw_f32, int64_t rows, int32_t cols, float eps, void* stream) {
-  (void)eps;
-  VQ3_CHECK_ARG(dy && x && w && rstd && dx && dw_f32, "rmsnorm_bwd: null pointer (dw_part must hold ceil(rows/4)*cols floats)");
+static int rmsnorm_bwd_impl(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                            float* dw_f32, int64_t rows, int32_t cols, int32_t rows_per_part, void* stream) {
+  VQ3_CHECK_ARG(dy && x && w && rstd && dx && dw_f32, "rmsnorm_bwd: null pointer (dw_part must hold ceil(rows/rows_per_part)*cols floats)");
   VQ3_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "rmsnorm_bwd: bad cols=%d (<= 4096)", cols);
-  const long nblk = (rows + RB_ROWS - 1) / RB_ROWS;
+  VQ3_CHECK_ARG(rows_per_part >= 4 && rows_per_part <= 256 && rows_per_part % 4 == 0, "rmsnorm_bwd: rows_per_part=%d must be a multiple of 4 in 4..256", rows_per_part);
+  const long nblk = (rows + rows_per_part - 1) / rows_per_part;
 #define VQ3_RB_LAUNCH(NCH)                                                                                           \
   hipLaunchKernelGGL(rmsnorm_bwd_kernel<NCH>, dim3((unsigned)nblk), dim3(256), 4 * cols * sizeof(float),              \
                      (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd,               \
-                     (const bf16_t*)dres, (bf16_t*)dx, dw_f32, (long)rows, cols)
+                     (const bf16_t*)dres, (bf16_t*)dx, dw_f32, (long)rows, cols, (int)rows_per_part)
   if (cols <= 512) VQ3_RB_LAUNCH(1);
   else if (cols <= 1024) VQ3_RB_LAUNCH(2);
   else if (cols <= 2560) VQ3_RB_LAUNCH(5);
@@ -497,6 +496,19 @@ extern "C" int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
 #undef VQ3_RB_LAUNCH
   VQ3_CHECK_LAUNCH("rmsnorm_bwd");
   return 0;
+}
+
+extern "C" int vq3_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                               float* dw_f32, int64_t rows, int32_t cols, float eps, void* stream) {
+  (void)eps;
+  return rmsnorm_bwd_impl(dy, x, w, rstd, dres, dx, dw_f32, rows, cols, 4, stream);
+}
+
+// The same with rows_per_part (a multiple of 4) rows per workgroup: dw_part is [ceil(rows / rows_per_part), cols]. At 9 600 rows (a
+// merged pass) 4 rows per partial make the slab a tenth of the kernel's traffic and its column sum a launch of half the kernel's length.
+extern "C" int vq3_rmsnorm_bwd_rows(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                                    float* dw_f32, int64_t rows, int32_t cols, int32_t rows_per_part, void* stream) {
+  return rmsnorm_bwd_impl(dy, x, w, rstd, dres, dx, dw_f32, rows, cols, rows_per_part, stream);
 }
 
 namespace {

@@ -2,6 +2,7 @@
 host, and enqueue the HIP kernel on torch's current stream. No math happens in Python or in torch here."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -172,11 +173,14 @@ def rmsnorm_bwd(dy, x, w, rstd, dres, dw_out: torch.Tensor, accumulate: bool, ep
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
     rows, cols = x.shape
     dx = _out2d(out, rows, cols, x, "rmsnorm_bwd")
-    nblk = (rows + 3) // 4
+    # rows per workgroup = per partial dw row: 4 while that still gives every CU several workgroups, 16 for the rows of a merged pass
+    # (9 600 rows: the slab shrinks from 24.6 MB to 6.1 MB per call, its column sum from 29 us to a quarter)
+    rpp = 16 if rows >= 8192 else 4
+    nblk = (rows + rpp - 1) // rpp
     part = torch.empty((nblk, cols), device=x.device, dtype=F32)
     lib = _lib.load()
-    check(lib.vq3_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres), dx.data_ptr(),
-                              part.data_ptr(), rows, cols, eps, _stream()), "vq3_rmsnorm_bwd")
+    check(lib.vq3_rmsnorm_bwd_rows(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(dres), dx.data_ptr(),
+                                   part.data_ptr(), rows, cols, rpp, _stream()), "vq3_rmsnorm_bwd_rows")
     if defer is not None:
         defer.append((part, nblk, cols, dw_out, accumulate))
         return dx
@@ -516,6 +520,37 @@ def gemm_swiglu_bwd(dY: torch.Tensor, W: torch.Tensor, gu: torch.Tensor, transB:
     else:
         check(_lib.load().vq3_gemm_swiglu_bwd(d, gu.data_ptr(), dgu.data_ptr(), _stream()), "vq3_gemm_swiglu_bwd")
     return dgu
+
+
+def swiglu_fwd_fusable(M: int, inter: int, K: int) -> bool:
+    """Shapes vq3_gemm_swiglu_fwd takes (the 8-phase NT kernels: K % 64 == 0; gate and up of a feature in one tile: I % 128 == 0)."""
+    return K % 64 == 0 and inter % 128 == 0 and M >= 1 and os.environ.get("VQ3_SWIGLU_FWD_FUSED", "1") != "0"
+
+
+def gemm_swiglu_fwd(x: torch.Tensor, w_gu: torch.Tensor, gu_out: Optional[torch.Tensor] = None, act_out: Optional[torch.Tensor] = None):
+    """(gu, act) with gu = x @ w_gu^T [M, 2 I] = gate | up and act = silu_mul_fwd(gu) [M, I], in ONE launch (vq3_gemm_swiglu_fwd):
+    x bf16 [M, K], w_gu bf16 [2 I, K] (gate rows, then up rows - the fused weight of modeling_qwen3.py:81-83)."""
+    _req(x, BF16, "swiglu_fwd x"); _req(w_gu, BF16, "swiglu_fwd w")
+    assert x.dim() == 2 and w_gu.dim() == 2 and x.stride(1) == 1 and w_gu.stride(1) == 1 and x.shape[1] == w_gu.shape[1]
+    M, K = x.shape
+    N = w_gu.shape[0]
+    gu = _out2d(gu_out, M, N, x, "gemm_swiglu_fwd gu")
+    act = _out2d(act_out, M, N // 2, x, "gemm_swiglu_fwd act")
+    assert gu.is_contiguous()
+    d = GemmDesc()
+    d.A = x.data_ptr(); d.B = w_gu.data_ptr(); d.C = act.data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = M, N, K, x.stride(0), w_gu.stride(0), act.stride(0), 0
+    d.nb1 = d.nb2 = d.b2divB = 1
+    d.alpha = 1.0
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().vq3_gemm_swiglu_fwd(d, gu.data_ptr(), _stream()), "vq3_gemm_swiglu_fwd")
+        e1.record()
+        GEMM_PROFILE.append((2.0 * M * N * K, 2.0 * M * K + 2.0 * N * K + 2.0 * M * N * 1.5, e0, e1, (M, N, K, 1)))
+    else:
+        check(_lib.load().vq3_gemm_swiglu_fwd(d, gu.data_ptr(), _stream()), "vq3_gemm_swiglu_fwd")
+    return gu, act
 
 
 def linear_vit_qkv(x: torch.Tensor, w: torch.Tensor, bias, N: int, NH: int, *, qn=None, kn=None, cos=None, sin=None,

@@ -423,8 +423,12 @@ class Qwen3ForCausalLM(nn.Module):
             ao = self._attention_fwd(i, xn1, B, L, keymask, ctx, ao_out=wv(i, "o.X"))
             h_mid = self._proj(ao, f"l{i}.o", residual=h)
             xn2, r2 = ops.rmsnorm_fwd(h_mid, self._w[f"l{i}.ln2"], c.rms_norm_eps, want_rstd=True, out=wv(i, "gu.X"))
-            gu = self._proj(xn2, f"l{i}.gu")
-            act = ops.silu_mul_fwd(gu, out=wv(i, "down.X"))
+            if getattr(self, "_fp8", None) is None and ops.swiglu_fwd_fusable(B * L, c.intermediate_size, H):
+                # gate|up projection with silu(gate) * up in its epilogue: act leaves with gu, no second pass over [rows, 2 I]
+                gu, act = ops.gemm_swiglu_fwd(xn2, self._w[f"l{i}.gu"], act_out=wv(i, "down.X"))
+            else:
+                gu = self._proj(xn2, f"l{i}.gu")
+                act = ops.silu_mul_fwd(gu, out=wv(i, "down.X"))
             h_out = self._proj(act, f"l{i}.down", residual=h_mid)
             if save:
                 ctx.update(h_in=h, r1=r1, xn1=xn1, h_mid=h_mid, r2=r2, xn2=xn2, gu=gu, act=act)
