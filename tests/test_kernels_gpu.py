@@ -695,3 +695,26 @@ def test_qwen_flash_attention_fwd_bwd(ops, B, Hkv, L, pad, G):
     lse_ref = torch.logsumexp(s.detach(), dim=-1) * 1.4426950408889634
     ok = rowvis.squeeze(-1).expand(B, Hq, L)
     assert (lse[ok] - lse_ref[ok]).abs().max() < 2e-2
+
+
+def test_gemm_tune_file_makes_the_choice_repeatable(tmp_path):
+    """VQ3_GEMM_TUNE_FILE: the measured kernel choices of one process are appended to the file; a second process reads them and measures
+    nothing (same kernels, same summation order from run to run and on every rank that is pointed at the file)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tune = tmp_path / "tune.txt"
+    code = ("import torch; from vggt_qwen3_amd import ops; x = torch.randn(512, 1024, device='cuda').to(torch.bfloat16); "
+            "w = torch.randn(768, 1024, device='cuda').to(torch.bfloat16); y = ops.linear(x, w); torch.cuda.synchronize(); "
+            "print('ok', float(y.float().abs().sum()) > 0)")
+    env = dict(os.environ, VQ3_GEMM_TUNE_FILE=str(tune), VQ3_GEMM_AUTOTUNE_LOG="1", PYTHONPATH=repo)
+    first = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=repo)
+    assert first.returncode == 0 and "ok True" in first.stdout, first.stderr[-2000:]
+    assert "[vq3 gemm autotune] M=512 N=768 K=1024" in first.stderr
+    lines = [l.split() for l in tune.read_text().splitlines() if l.strip()]
+    assert any(l[:4] == ["512", "768", "1024", "1"] and len(l) == 6 for l in lines)
+    second = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=repo)
+    assert second.returncode == 0 and "ok True" in second.stdout, second.stderr[-2000:]
+    assert "[vq3 gemm autotune]" not in second.stderr                      # nothing was measured: the table came from the file
+    assert tune.read_text().count("512 768 1024 1 ") == 1

@@ -17,6 +17,7 @@
 #include <tuple>
 #include <vector>
 
+#include <cstdio>
 #include "gemm_common.h"
 #include "vq3_hip.h"
 
@@ -331,17 +332,47 @@ int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int tr
   return best;
 }
 
+// VQ3_GEMM_TUNE_FILE=<path>: the table is read from that file before the first choice and every newly measured entry is appended to it
+// ("M N K batch flags cfg" per line) - a second run, or the other ranks of a job pointed at the same file, then make the SAME choices
+// (same kernels, same summation order) without measuring. Without it the choice is timing-based and may differ from run to run and
+// from rank to rank (replicas still agree bit for bit: they apply the same all-reduced gradient); VQ3_GEMM_AUTOTUNE=0 turns measuring off.
+bool g_tune_file_read = false;
+void tune_file_read() {
+  g_tune_file_read = true;
+  const char* path = getenv("VQ3_GEMM_TUNE_FILE");
+  if (!path || !*path) return;
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  int m, n, k, b, fl, cfg;
+  while (fscanf(f, "%d %d %d %d %d %d", &m, &n, &k, &b, &fl, &cfg) == 6) g_tuned[TuneKey(m, n, k, b, fl)] = cfg;
+  fclose(f);
+}
+void tune_file_append(const TuneKey& key, int cfg) {
+  const char* path = getenv("VQ3_GEMM_TUNE_FILE");
+  if (!path || !*path) return;
+  FILE* f = fopen(path, "a");
+  if (!f) return;
+  fprintf(f, "%d %d %d %d %d %d\n", std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key), std::get<4>(key), cfg);
+  fclose(f);
+}
+
 int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStream_t s, const std::vector<int>& cands, int fallback) {
+  // (the key carries what selects a code path inside the candidates: layout, epilogue kind, and whether the 4-wide / whole-row stores apply)
+  const bool rows16 = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                      (!p.R || ((p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.R) & 15) == 0)));
   const int flags = (transA ? 1 : 0) | (transB ? 2 : 0) | (p.out_f32 ? 4 : 0) | (p.accumulate ? 8 : 0) | (p.R ? 16 : 0) |
-                    (p.bias ? 32 : 0) | (p.act << 6) | (p.colscale ? 256 : 0) | (p.epi << 9) | (p.ln_in ? 4096 : 0) | (p.st_out ? 8192 : 0);
+                    (p.bias ? 32 : 0) | (p.act << 6) | (p.colscale ? 256 : 0) | (p.epi << 9) | (p.ln_in ? 4096 : 0) | (p.st_out ? 8192 : 0) |
+                    (p.vec_ok ? 0 : 16384) | (rows16 ? 0 : 32768);
   const TuneKey key(p.M, p.N, p.K, nbatch, flags);
   std::lock_guard<std::mutex> lock(g_tune_mutex);
+  if (!g_tune_file_read) tune_file_read();
   auto it = g_tuned.find(key);
   if (it != g_tuned.end()) return it->second;
   if (!autotune_on(s)) return fallback;                   // not remembered: a later, tunable call may still measure
   int best = tune(p, cands, transA, transB, nbatch, s);
   if (best < 0) best = fallback;
   g_tuned[key] = best;
+  tune_file_append(key, best);
   return best;
 }
 
