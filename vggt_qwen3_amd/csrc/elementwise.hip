@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
 #pragma unroll
     for (int u = 0; u < 16; ++u) use[u] = (k0 + u < end) && srcmap[t[u]] < 0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = cin ? *reinterpret_cast<const bf16x8*>(dout + t[u] * (long)H + c) : bf16x8{};
+    for (int u = 0; u < 16; ++u) v[u] = (cin && use[u]) ? *reinterpret_cast<const bf16x8*>(dout + t[u] * (long)H + c) : bf16x8{};
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       if (use[u]) {

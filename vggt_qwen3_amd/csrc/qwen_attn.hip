@@ -9,6 +9,7 @@
 namespace {
 
 constexpr int D = 128;
+constexpr int QK_IT = 6;     // heads per half-wave whose loads are in flight together (48 heads / 8 half-waves)
 
 // Lane layout: a HALF wave (32 lanes) owns one head; lane j holds elements 2j, 2j+1 and their rotate-half partners
 // 2j+64, 2j+65 (two 4-byte accesses), so a wave covers two heads per pass, RoPE needs no cross-lane traffic and the RMS
@@ -40,10 +41,26 @@ __global__ __launch_bounds__(256) void qkprep_fwd_kernel(const bf16_t* __restric
   float c1a, c1b, c2a, c2b, s1a, s1b, s2a, s2b;
   ld2(cs + l * D + e, c1a, c1b); ld2(cs + l * D + e + 64, c2a, c2b);
   ld2(sn + l * D + e, s1a, s1b); ld2(sn + l * D + e + 64, s2a, s2b);
-  for (int h = 2 * wid + half; h < HT; h += 8) {
-    float x1a, x1b, x2a, x2b;
-    ld2(row + h * D + e, x1a, x1b);
-    ld2(row + h * D + e + 64, x2a, x2b);
+  // the rows of QK_IT heads are requested before the first is used (Qwen3-4B: 48 heads = 6 per half-wave = one batch): the loop used
+  // to pay one memory round trip per head
+  float wq1a, wq1b, wq2a, wq2b, wk1a, wk1b, wk2a, wk2b;
+  ld2(q_w + e, wq1a, wq1b); ld2(q_w + e + 64, wq2a, wq2b);
+  ld2(k_w + e, wk1a, wk1b); ld2(k_w + e + 64, wk2a, wk2b);
+  for (int hb = 2 * wid + half; hb < HT; hb += 8 * QK_IT) {
+  uint32_t xr1[QK_IT], xr2[QK_IT];
+#pragma unroll
+  for (int i = 0; i < QK_IT; ++i) {
+    const int h = hb + 8 * i;
+    const int hc = h < HT ? h : HT - 1;
+    xr1[i] = *reinterpret_cast<const uint32_t*>(row + hc * D + e);
+    xr2[i] = *reinterpret_cast<const uint32_t*>(row + hc * D + e + 64);
+  }
+#pragma unroll
+  for (int i = 0; i < QK_IT; ++i) {
+    const int h = hb + 8 * i;
+    if (h >= HT) break;
+    const float x1a = bf2f((bf16_t)(xr1[i] & 0xffff)), x1b = bf2f((bf16_t)(xr1[i] >> 16));
+    const float x2a = bf2f((bf16_t)(xr2[i] & 0xffff)), x2b = bf2f((bf16_t)(xr2[i] >> 16));
     if (h >= Hq + Hkv) {  // value head: plain copy
       const int hv = h - Hq - Hkv;
       bf16_t* o = V + (((long)b * Hkv + hv) * L + l) * D;
@@ -52,9 +69,7 @@ __global__ __launch_bounds__(256) void qkprep_fwd_kernel(const bf16_t* __restric
       continue;
     }
     const bool isq = h < Hq;
-    const bf16_t* w = isq ? q_w : k_w;
-    float w1a, w1b, w2a, w2b;
-    ld2(w + e, w1a, w1b); ld2(w + e + 64, w2a, w2b);
+    const float w1a = isq ? wq1a : wk1a, w1b = isq ? wq1b : wk1b, w2a = isq ? wq2a : wk2a, w2b = isq ? wq2b : wk2b;
     const float rs = rsqrtf(half_sum(x1a * x1a + x1b * x1b + x2a * x2a + x2b * x2b) / (float)D + eps);
     const float n1a = rbf(w1a * rbf(x1a * rs)), n1b = rbf(w1b * rbf(x1b * rs));
     const float n2a = rbf(w2a * rbf(x2a * rs)), n2b = rbf(w2b * rbf(x2b * rs));
@@ -72,6 +87,7 @@ __global__ __launch_bounds__(256) void qkprep_fwd_kernel(const bf16_t* __restric
     }
     *reinterpret_cast<uint32_t*>(o + e) = pack2bf(o1a, o1b);
     *reinterpret_cast<uint32_t*>(o + e + 64) = pack2bf(o2a, o2b);
+  }
   }
 }
 
@@ -98,56 +114,78 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
   ld2(cs + l * D + e, c1[0], c1[1]); ld2(cs + l * D + e + 64, c2[0], c2[1]);
   ld2(sn + l * D + e, s1[0], s1[1]); ld2(sn + l * D + e + 64, s2[0], s2[1]);
   float aq1[2] = {0.f, 0.f}, aq2[2] = {0.f, 0.f}, ak1[2] = {0.f, 0.f}, ak2[2] = {0.f, 0.f};
-  for (int h = 2 * wid + half; h < HT; h += 8) {
-    if (h >= Hq + Hkv) {
-      const int hv = h - Hq - Hkv;
-      const bf16_t* g = dV + (((long)b * Hkv + hv) * L + l) * D;
-      if (kv_parts == 1) {
-        *reinterpret_cast<uint32_t*>(drow + h * D + e) = *reinterpret_cast<const uint32_t*>(g + e);
-        *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = *reinterpret_cast<const uint32_t*>(g + e + 64);
-      } else {                                   // partial slabs of the split dK/dV pass: summed in f32, rounded once
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-        for (int sp = 0; sp < kv_parts; ++sp) {
+  float wq1[2], wq2[2], wk1[2], wk2[2];
+  ld2(q_w + e, wq1[0], wq1[1]); ld2(q_w + e + 64, wq2[0], wq2[1]);
+  ld2(k_w + e, wk1[0], wk1[1]); ld2(k_w + e + 64, wk2[0], wk2[1]);
+  const int np = kv_parts < 2 ? 1 : 2;             // slabs fetched with the batch (further ones, kv_parts 3..4: in the arithmetic loop)
+  // the gradient rows (first two partial slabs), the saved q|k|v rows and the row statistics of QK_IT heads are requested before the
+  // first is used: one memory round trip per batch instead of one per head (Qwen3-4B: 48 heads = 6 per half-wave = one batch)
+  for (int hb = 2 * wid + half; hb < HT; hb += 8 * QK_IT) {
+    uint32_t ga1[QK_IT], ga2[QK_IT], gb1[QK_IT], gb2[QK_IT], xr1[QK_IT], xr2[QK_IT];
+    float rsv[QK_IT];
+#pragma unroll
+    for (int i = 0; i < QK_IT; ++i) {
+      const int h = hb + 8 * i;
+      const int hc = h < HT ? h : HT - 1;
+      const bool isq = hc < Hq, isv = hc >= Hq + Hkv;
+      const bf16_t* g = isq ? dQ + (((long)b * Hq + hc) * L + l) * D
+                            : (isv ? dV + (((long)b * Hkv + (hc - Hq - Hkv)) * L + l) * D : dK + (((long)b * Hkv + (hc - Hq)) * L + l) * D);
+      ga1[i] = *reinterpret_cast<const uint32_t*>(g + e);
+      ga2[i] = *reinterpret_cast<const uint32_t*>(g + e + 64);
+      const bf16_t* g2 = (!isq && np == 2) ? g + part_stride : g;      // (q heads: re-read of the same line, never used)
+      gb1[i] = *reinterpret_cast<const uint32_t*>(g2 + e);
+      gb2[i] = *reinterpret_cast<const uint32_t*>(g2 + e + 64);
+      xr1[i] = *reinterpret_cast<const uint32_t*>(row + hc * D + e);
+      xr2[i] = *reinterpret_cast<const uint32_t*>(row + hc * D + e + 64);
+      rsv[i] = isv ? 1.f : (isq ? q_rstd[t * Hq + hc] : k_rstd[t * Hkv + (hc - Hq)]);
+    }
+#pragma unroll
+    for (int i = 0; i < QK_IT; ++i) {
+      const int h = hb + 8 * i;
+      if (h >= HT) break;
+      const bool isq = h < Hq;
+      float dy1[2] = {bf2f((bf16_t)(ga1[i] & 0xffff)), bf2f((bf16_t)(ga1[i] >> 16))};
+      float dy2[2] = {bf2f((bf16_t)(ga2[i] & 0xffff)), bf2f((bf16_t)(ga2[i] >> 16))};
+      if (!isq && np == 2) {                         // partial slabs of the split dK/dV pass: summed in f32 in slab order, rounded once
+        dy1[0] += bf2f((bf16_t)(gb1[i] & 0xffff)); dy1[1] += bf2f((bf16_t)(gb1[i] >> 16));
+        dy2[0] += bf2f((bf16_t)(gb2[i] & 0xffff)); dy2[1] += bf2f((bf16_t)(gb2[i] >> 16));
+        const bf16_t* g = h >= Hq + Hkv ? dV + (((long)b * Hkv + (h - Hq - Hkv)) * L + l) * D : dK + (((long)b * Hkv + (h - Hq)) * L + l) * D;
+        for (int sp = 2; sp < kv_parts; ++sp) {
           float t0, t1, u0, u1;
           ld2(g + sp * part_stride + e, t0, t1); ld2(g + sp * part_stride + e + 64, u0, u1);
-          a0 += t0; a1 += t1; b0 += u0; b1 += u1;
+          dy1[0] += t0; dy1[1] += t1; dy2[0] += u0; dy2[1] += u1;
         }
-        *reinterpret_cast<uint32_t*>(drow + h * D + e) = pack2bf(a0, a1);
-        *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = pack2bf(b0, b1);
       }
-      continue;
-    }
-    const bool isq = h < Hq;
-    const bf16_t* g = isq ? dQ + (((long)b * Hq + h) * L + l) * D : dK + (((long)b * Hkv + (h - Hq)) * L + l) * D;
-    const bf16_t* w = isq ? q_w : k_w;
-    const float rs = isq ? q_rstd[t * Hq + h] : k_rstd[t * Hkv + (h - Hq)];
-    float dy1[2], dy2[2], x1[2], x2[2], w1[2], w2[2];
-    ld2(g + e, dy1[0], dy1[1]); ld2(g + e + 64, dy2[0], dy2[1]);
-    if (!isq) {
-      for (int sp = 1; sp < kv_parts; ++sp) {    // the other partial slabs of dK
-        float t0, t1, u0, u1;
-        ld2(g + sp * part_stride + e, t0, t1); ld2(g + sp * part_stride + e + 64, u0, u1);
-        dy1[0] += t0; dy1[1] += t1; dy2[0] += u0; dy2[1] += u1;
+      if (h >= Hq + Hkv) {
+        if (kv_parts == 1) {
+          *reinterpret_cast<uint32_t*>(drow + h * D + e) = ga1[i];
+          *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = ga2[i];
+        } else {
+          *reinterpret_cast<uint32_t*>(drow + h * D + e) = pack2bf(dy1[0], dy1[1]);
+          *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = pack2bf(dy2[0], dy2[1]);
+        }
+        continue;
       }
-    }
-    ld2(row + h * D + e, x1[0], x1[1]); ld2(row + h * D + e + 64, x2[0], x2[1]);
-    ld2(w + e, w1[0], w1[1]); ld2(w + e + 64, w2[0], w2[1]);
-    float dn1[2], dn2[2], xh1[2], xh2[2], g1[2], g2[2], part = 0.f;
+      const float rs = rsv[i];
+      const float x1[2] = {bf2f((bf16_t)(xr1[i] & 0xffff)), bf2f((bf16_t)(xr1[i] >> 16))};
+      const float x2[2] = {bf2f((bf16_t)(xr2[i] & 0xffff)), bf2f((bf16_t)(xr2[i] >> 16))};
+      float dn1[2], dn2[2], xh1[2], xh2[2], g1[2], g2[2], part = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      // y1 = n1*c1 - n2*s1 ; y2 = n2*c2 + n1*s2
-      dn1[u] = dy1[u] * c1[u] + dy2[u] * s2[u];
-      dn2[u] = -dy1[u] * s1[u] + dy2[u] * c2[u];
-      xh1[u] = x1[u] * rs; xh2[u] = x2[u] * rs;
-      g1[u] = dn1[u] * w1[u]; g2[u] = dn2[u] * w2[u];
-      part += g1[u] * xh1[u] + g2[u] * xh2[u];
-    }
-    const float dot = half_sum(part) / (float)D;
-    *reinterpret_cast<uint32_t*>(drow + h * D + e) = pack2bf(rs * (g1[0] - xh1[0] * dot), rs * (g1[1] - xh1[1] * dot));
-    *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = pack2bf(rs * (g2[0] - xh2[0] * dot), rs * (g2[1] - xh2[1] * dot));
+      for (int u = 0; u < 2; ++u) {
+        // y1 = n1*c1 - n2*s1 ; y2 = n2*c2 + n1*s2
+        dn1[u] = dy1[u] * c1[u] + dy2[u] * s2[u];
+        dn2[u] = -dy1[u] * s1[u] + dy2[u] * c2[u];
+        xh1[u] = x1[u] * rs; xh2[u] = x2[u] * rs;
+        g1[u] = dn1[u] * (isq ? wq1[u] : wk1[u]); g2[u] = dn2[u] * (isq ? wq2[u] : wk2[u]);
+        part += g1[u] * xh1[u] + g2[u] * xh2[u];
+      }
+      const float dot = half_sum(part) / (float)D;
+      *reinterpret_cast<uint32_t*>(drow + h * D + e) = pack2bf(rs * (g1[0] - xh1[0] * dot), rs * (g1[1] - xh1[1] * dot));
+      *reinterpret_cast<uint32_t*>(drow + h * D + e + 64) = pack2bf(rs * (g2[0] - xh2[0] * dot), rs * (g2[1] - xh2[1] * dot));
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (isq) { aq1[u] += dn1[u] * xh1[u]; aq2[u] += dn2[u] * xh2[u]; } else { ak1[u] += dn1[u] * xh1[u]; ak2[u] += dn2[u] * xh2[u]; }
+      for (int u = 0; u < 2; ++u) {
+        if (isq) { aq1[u] += dn1[u] * xh1[u]; aq2[u] += dn2[u] * xh2[u]; } else { ak1[u] += dn1[u] * xh1[u]; ak2[u] += dn2[u] * xh2[u]; }
+      }
     }
   }
 #pragma unroll

@@ -377,8 +377,16 @@ class VGGTQwen3VLM(nn.Module):
         emb = ops.embed_splice_fwd(input_ids.contiguous(), tm._w["embed"], feats16, srcmap, B, L, H, S)
         h_last, saved = tm.forward_hidden(emb, attention_mask, save=need_grad, plan_key=(attention_mask0,))
         loss, head_ctx = tm.loss_head(h_last, labels, save=need_grad, L=saved["L"], plan_key=(labels0,), groups=loss_groups)
+        live = None
+        if need_grad:
+            # positions whose embedding row CAN receive a gradient: attended as a key, or carrying a loss term (position t predicts
+            # labels[t + 1], loss_utils.py:49-71). Every other row of d(embeds) is exactly zero (masked keys get exact-zero dK / dV,
+            # all other ops are row-wise), and with the reference's collator that is ~85 % of a batch: the padding id's run.
+            nxt = torch.full_like(labels, -100)
+            nxt[:, :-1] = labels[:, 1:]
+            live = (attention_mask != 0) | (nxt != -100)
         return dict(loss=loss, saved=saved, head=head_ctx, srcmap=srcmap, input_ids=input_ids, B=B, L=L, S=S,
-                    geom_ctx=geom_ctx, geom_y=gy, emb=emb, h_last=h_last, pctx=pctx)
+                    geom_ctx=geom_ctx, geom_y=gy, emb=emb, h_last=h_last, pctx=pctx, live=live)
 
     def _backward_text(self, st: dict, gscale: float, accumulate: bool, layer_done=None, flush: bool = True):
         """Backward of everything that has gradients in the reference: Qwen3 (all parameters, tied embedding) and,
@@ -405,11 +413,26 @@ class VGGTQwen3VLM(nn.Module):
         if Lp != L:
             d_emb = d_emb.view(B, Lp, H)[:, :L].contiguous()
         ids = st["input_ids"].reshape(-1)
-        sorted_ids, order = torch.sort(ids, stable=True)
         dfeat = None
         if st["geom_ctx"] is not None or st.get("pctx") is not None:
             dfeat = torch.zeros((B, S, H), device=d_emb.device, dtype=F32)
-        ops.embed_splice_bwd(sorted_ids, order, st["srcmap"], d_emb, tm._g["embed"], dfeat, B, L, H, S)
+        live = st.get("live")
+        if live is None or os.environ.get("VQ3_EMBED_BWD_LIVE", "1") == "0":
+            sorted_ids, order = torch.sort(ids, stable=True)
+            ops.embed_splice_bwd(sorted_ids, order, st["srcmap"], d_emb, tm._g["embed"], dfeat, B, L, H, S)
+        else:
+            # Rows that cannot carry a gradient leave the id runs (index plumbing, no arithmetic): each gets a sort key of its own
+            # behind every real id - a run of one, marked "skip" in the table pass's source map - so the run of the padding id, which
+            # one workgroup per 512 columns used to sum serially over ~8 000 all-zero rows (1.2 ms per pass), is gone. Same sums, same
+            # order inside every remaining run. The feature gradient (second call) still sees the real source map.
+            live = live.reshape(-1)
+            pos = torch.arange(ids.numel(), device=ids.device, dtype=ids.dtype)
+            keys = torch.where(live, ids, pos + (1 << 40))
+            sorted_keys, order = torch.sort(keys, stable=True)
+            srcmap_tbl = torch.where(live, st["srcmap"].reshape(-1), torch.zeros_like(st["srcmap"].reshape(-1)))
+            ops.embed_splice_bwd(sorted_keys, order, srcmap_tbl, d_emb, tm._g["embed"], None, B, L, H, S)
+            if dfeat is not None:
+                ops.embed_splice_bwd(sorted_keys, order, st["srcmap"], d_emb, None, dfeat, B, L, H, S)
         if dfeat is None:
             return None
         if st.get("pctx") is not None:
