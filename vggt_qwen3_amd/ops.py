@@ -173,9 +173,10 @@ def rmsnorm_bwd(dy, x, w, rstd, dres, dw_out: torch.Tensor, accumulate: bool, ep
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
     rows, cols = x.shape
     dx = _out2d(out, rows, cols, x, "rmsnorm_bwd")
-    # rows per workgroup = per partial dw row: 4 while that still gives every CU several workgroups, 16 for the rows of a merged pass
-    # (9 600 rows: the slab shrinks from 24.6 MB to 6.1 MB per call, its column sum from 29 us to a quarter)
-    rpp = 16 if rows >= 8192 else 4
+    # rows per workgroup = per partial dw row (vq3_rmsnorm_bwd_rows). Measured at 9 600 x 2560 (a merged pass): 16 rows per workgroup
+    # shrink the slab from 24.6 MB to 6.1 MB and its column sum from 29 to 23 us, but the kernel itself goes from 51 to 64 us (a wave
+    # then walks 4 rows one memory round trip after the other) - a net loss, so 4 stays.
+    rpp = int(os.environ.get("VQ3_RMSNORM_BWD_ROWS", "4"))
     nblk = (rows + rpp - 1) // rpp
     part = torch.empty((nblk, cols), device=x.device, dtype=F32)
     lib = _lib.load()
