@@ -6,8 +6,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from vggt_qwen3_amd import ops
 
-B, L, Hq, Hkv, D = 6, 200, 32, 8, 128
-NC = 12
+B, L, Hq, Hkv, D = (int(sys.argv[1]) if len(sys.argv) > 1 else 6), 200, 32, 8, 128     # 48 = a merged pass of 8 micro-batches
+NC = 12 if B <= 8 else 3
 torch.manual_seed(0)
 sets = []
 for _ in range(NC):

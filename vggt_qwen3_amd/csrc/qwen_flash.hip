@@ -13,6 +13,7 @@
 // d-block db stands for feature d = 4 r + db, so one 8-byte load per key/query row feeds all four d-blocks.
 // Layouts: Q, dQ [B, Hq, L, 128]; K, V, dK, dV [B, Hkv, L, 128]; O, dO token-major rows (b*L + q) with row stride ld,
 // head h at column h*128; LSE (log2 domain, scaled) and Delta f32 [B, Hq, L].
+#include <cstdlib>
 #include "common.h"
 #include "vq3_hip.h"
 
@@ -434,6 +435,185 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* _
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV with LDS-staged Q / dO
+// Same mapping and arithmetic as qwen_flash_bwd_dkv_kernel; what changes is where a q-block's operands come from. There every step
+// began with ~56 global loads per lane (rows of Q and dO, their 8-byte "transposed" gathers, LSE, delta) whose round trip nothing could
+// hide: the kernel runs one wave per SIMD (accumulators for dK^T and dV^T alone are 128 registers), so a step cost ~4 us for 0.5 us of
+// MFMA work. Here each wave owns two LDS stages of {Q tile, dO tile, LSE | delta} (32 rows x 256 B each, 16-byte chunks XOR (row & 15))
+// filled by global_load_lds one q-block AHEAD (17 DMA instructions per stage, counted vmcnt - no barrier: a wave reads only what it
+// staged itself), and both operand forms are LDS reads: the rows as ds_read_b128, the gathers as ds_read_b64 of the same tile.
+constexpr int DKV_TILE = 32 * 256;                       // bytes of a 32-row x 128-feature bf16 tile
+constexpr int DKV_STAGE = 2 * DKV_TILE + 256;            // Q | dO | 32 LSE + 32 delta floats
+__device__ __forceinline__ void dma_tile(const bf16_t* base, long rowstride, int row0, int maxrow, char* dst, int lane) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = 4 * p + (lane >> 4);
+    const int lchunk = (lane & 15) ^ (row & 15);
+    int grow = row0 + row;
+    grow = grow < maxrow ? grow : maxrow;
+    const char* g = reinterpret_cast<const char*>(base + (long)grow * rowstride) + lchunk * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ bf16x8 lds_row16(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 256 + ((chunk ^ (row & 15)) << 4));
+}
+// the gather of gather_load / gather_split from an LDS tile: 4 consecutive features 4r .. 4r+3 of 8 rows per half
+__device__ __forceinline__ void lds_gather(const char* tile, int sp, int h, int r, bf16x8 (&a)[4]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = 16 * sp + 8 * (j >> 2) + 4 * h + (j & 3);
+    const u32x2 g = *reinterpret_cast<const u32x2*>(tile + row * 256 + (((r >> 1) ^ (row & 15)) << 4) + ((r & 1) << 3));
+    a[0][j] = (short)(g[0] & 0xffff);
+    a[1][j] = (short)(g[0] >> 16);
+    a[2][j] = (short)(g[1] & 0xffff);
+    a[3][j] = (short)(g[1] >> 16);
+  }
+}
+
+__global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_lds_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                    const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
+                                                                    const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
+                                                                    const float* __restrict__ Delta, bf16_t* __restrict__ dK,
+                                                                    bf16_t* __restrict__ dV, int L, int Hq, int Hkv, long lddo,
+                                                                    float scale, int S, long part_stride) {
+  extern __shared__ __attribute__((aligned(16))) char dkv_smem[];      // [4 waves][2 stages][DKV_STAGE], then red
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nkb = (L + 31) / 32;
+  const int sp = blockIdx.x % S;
+  const int bid = blockIdx.x / S;
+  const int nbh = (gridDim.x / S) / nkb;
+  const int kb = bid / nbh;                                     // kb = 0 walks the most q-blocks: heaviest first
+  dK += sp * part_stride;
+  dV += sp * part_stride;
+  const int hk = (bid % nbh) % Hkv, b = (bid % nbh) / Hkv;
+  const int G = Hq / Hkv, hq = hk * G + g;
+  const bool active = g < G;
+  const int key = kb * 32 + r, kc = key < L ? key : L - 1;
+  const bf16_t* Kr = K + (((long)b * Hkv + hk) * L + kc) * D + 8 * h;
+  const bf16_t* Vr = V + (((long)b * Hkv + hk) * L + kc) * D + 8 * h;
+  const bool key_ok = key < L && keymask[(long)b * L + kc] != 0;
+  if (__ballot(key_ok) == 0ull) {
+    if (key < L && g == 0) {
+      bf16_t* dKz = dK + (((long)b * Hkv + hk) * L + key) * D + 64 * h;
+      bf16_t* dVz = dV + (((long)b * Hkv + hk) * L + key) * D + 64 * h;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        *reinterpret_cast<u32x4*>(dKz + 8 * c) = z;
+        *reinterpret_cast<u32x4*>(dVz + 8 * c) = z;
+      }
+    }
+    return;
+  }
+  bf16x8 kf[8], vf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { kf[s] = ld8(Kr + 16 * s); vf[s] = ld8(Vr + 16 * s); }
+  f32x16 dk[4], dv[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+  const float sl2e = scale * LOG2E;
+  char* const mine = dkv_smem + __builtin_amdgcn_readfirstlane(g) * (2 * DKV_STAGE);      // wave-uniform: the DMA's LDS base goes through M0
+  if (active) {
+    const bf16_t* Qh = Q + ((long)b * Hq + hq) * L * D;
+    const bf16_t* dOh = dO + (long)b * L * lddo + (long)hq * D;
+    const float* lse_h = LSE + ((long)b * Hq + hq) * L;
+    const float* del_h = Delta + ((long)b * Hq + hq) * L;
+    auto issue = [&](int qb, char* st) {
+      dma_tile(Qh, D, qb * 32, L - 1, st, lane);
+      dma_tile(dOh, lddo, qb * 32, L - 1, st + DKV_TILE, lane);
+      int q = qb * 32 + (lane & 31);
+      q = q < L ? q : L - 1;
+      const float* src = (lane < 32 ? lse_h : del_h) + q;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + 2 * DKV_TILE), 4, 0, 0);
+    };
+    int stage = 0;
+    if (kb + sp < nkb) issue(kb + sp, mine);
+    for (int qb = kb + sp; qb < nkb; qb += S) {
+      char* st = mine + stage * DKV_STAGE;
+      const bool more = qb + S < nkb;
+      if (more) {
+        issue(qb + S, mine + (stage ^ 1) * DKV_STAGE);
+        asm volatile("s_waitcnt vmcnt(17)" ::: "memory");     // everything but the 17 DMA pieces just issued has landed (K / V rows included)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const char* qt = st;
+      const char* dot = st + DKV_TILE;
+      const float* ld = reinterpret_cast<const float*>(st + 2 * DKV_TILE);
+      f32x4 lse4[4], del4[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {      // rows rho(4c .. 4c+3, h) = 8c + 4h .. +3 are consecutive (rows past L hold row L-1's values: masked below)
+        lse4[c] = *reinterpret_cast<const f32x4*>(ld + 8 * c + 4 * h);
+        del4[c] = *reinterpret_cast<const f32x4*>(ld + 32 + 8 * c + 4 * h);
+      }
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const bf16x8 qrow = lds_row16(qt, r, 2 * t + h);
+        const bf16x8 dorow = lds_row16(dot, r, 2 * t + h);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qrow, kf[t], s, 0, 0, 0);      // S[q, key]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dorow, vf[t], dp, 0, 0, 0);   // dP[q, key]
+      }
+      f32x16 p;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qg = qb * 32 + rho(i, h);
+        const bool ok = key_ok && qg < L && key <= qg;
+        const float pv = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2e, -lse4[i >> 2][i & 3])) : 0.f;
+        p[i] = pv;
+        s[i] = pv * (dp[i] - del4[i >> 2][i & 3]) * scale;     // dS[q, key]
+      }
+#pragma unroll
+      for (int sp2 = 0; sp2 < 2; ++sp2) {
+        bf16x8 a[4];
+        lds_gather(dot, sp2, h, r, a);
+        const bf16x8 pf = pack8(p, sp2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[db], pf, dv[db], 0, 0, 0);
+        lds_gather(qt, sp2, h, r, a);
+        const bf16x8 dsf = pack8(s, sp2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[db], dsf, dk[db], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this stage's reads are done before the NEXT iteration's DMA lands on the other one's successor
+      stage ^= 1;
+    }
+  }
+  // sum the G query heads (as in qwen_flash_bwd_dkv_kernel); the reduction scratch sits behind the stages
+  float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(dkv_smem + 4 * 2 * DKV_STAGE);
+  bf16_t* dKr = dK + (((long)b * Hkv + hk) * L + kc) * D;
+  bf16_t* dVr = dV + (((long)b * Hkv + hk) * L + kc) * D;
+  f32x16 keep[2];
+#pragma unroll
+  for (int blk = 0; blk < 8; ++blk) {
+    const f32x16& mineacc = blk < 4 ? dk[blk] : dv[blk - 4];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[g][i][lane] = mineacc[i];
+    __syncthreads();
+    if ((blk & 3) == g) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) keep[blk >> 2][i] = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
+    }
+  }
+  if (key >= L) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    dKr[4 * rho(i, h) + g] = f2bf(keep[0][i]);
+    dVr[4 * rho(i, h) + g] = f2bf(keep[1][i]);
+  }
+}
+constexpr int DKV_SMEM = 4 * 2 * DKV_STAGE + 4 * 16 * 64 * 4;
+
 }  // namespace
 
 static int flash_check(const char* who, int B, int L, int Hq, int Hkv, int Dh) {
@@ -471,9 +651,25 @@ extern "C" int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, c
   hipLaunchKernelGGL(qwen_flash_bwd_dq_kernel, dim3(B * Hkv * nqb), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
                      (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)O, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dQ, L,
                      Hq, Hkv, (long)ldo, (long)lddo, scale);
-  hipLaunchKernelGGL(qwen_flash_bwd_dkv_kernel, dim3(B * Hkv * nqb * kv_parts), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
-                     (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dK, (bf16_t*)dV, L, Hq,
-                     Hkv, (long)lddo, scale, (int)kv_parts, (long)B * Hkv * L * D);
+  // dK / dV pass: the LDS-staged kernel (operands of the next q-block in flight while this one multiplies); VQ3_QWEN_DKV_LDS=0 = the
+  // register-staged one
+  static int dkv_lds = -1;
+  if (dkv_lds < 0) {
+    const char* e = getenv("VQ3_QWEN_DKV_LDS");
+    dkv_lds = e ? atoi(e) : 1;
+    if (dkv_lds && hipFuncSetAttribute((const void*)qwen_flash_bwd_dkv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_SMEM) != hipSuccess) {
+      (void)hipGetLastError();
+      dkv_lds = 0;
+    }
+  }
+  if (dkv_lds)
+    hipLaunchKernelGGL(qwen_flash_bwd_dkv_lds_kernel, dim3(B * Hkv * nqb * kv_parts), dim3(256), DKV_SMEM, s, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dK,
+                       (bf16_t*)dV, L, Hq, Hkv, (long)lddo, scale, (int)kv_parts, (long)B * Hkv * L * D);
+  else
+    hipLaunchKernelGGL(qwen_flash_bwd_dkv_kernel, dim3(B * Hkv * nqb * kv_parts), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dK, (bf16_t*)dV, L, Hq,
+                       Hkv, (long)lddo, scale, (int)kv_parts, (long)B * Hkv * L * D);
   VQ3_CHECK_LAUNCH("qwen_flash_bwd");
   return 0;
 }

@@ -402,7 +402,10 @@ class Qwen3ForCausalLM(nn.Module):
             attention_mask = torch.cat([attention_mask, attention_mask.new_zeros((B, L - L0))], dim=1)
         keymask = (attention_mask != 0).to(torch.uint8).contiguous()
         kv_parts = 1
-        if save and self._flash and L >= 128:
+        dkv_lds = os.environ.get("VQ3_QWEN_DKV_LDS", "1") != "0"
+        if "VQ3_QWEN_KV_PARTS" in os.environ:
+            kv_parts = int(os.environ["VQ3_QWEN_KV_PARTS"])
+        elif save and self._flash and L >= 128 and not dkv_lds:
             # The dK/dV pass walks, per 32-key tile, every query block behind it - its longest serial chain. Key tiles without an
             # attended key leave at once, so when most of a padded batch's tiles are empty there are CUs to spare and two
             # workgroups share each live tile's walk (partial slabs, summed by the q/k-prep backward); with dense masks every
@@ -413,6 +416,8 @@ class Qwen3ForCausalLM(nn.Module):
             count = lambda: int(km.view(B, nkb, 32).any(-1).sum().item())
             live = PLAN.get(("live_key_tiles", L), plan_key, count) if plan_key is not None else count()
             kv_parts = 2 if live * 2 <= B * nkb else 1
+        # (round 3: with the LDS-staged dK/dV kernel - the default - a q-block step costs ~1 us instead of ~4, a workgroup's fixed cost
+        # dominates and ONE workgroup per live key tile wins (133.7 against 132.4 samples/s): no split, and no host read to decide it)
         h = inputs_embeds.reshape(B * L, H)
         saved: List[dict] = []
         wd_off = self._wd_begin(B * L) if save else None       # row offset of this micro-batch in the deferred-wgrad slabs (or None)
