@@ -27,7 +27,8 @@ def timeit(fn, it=48):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it * 1e3
 for name, mask in (("padded (40 of 200 keys attended)", km), ("dense", torch.ones(B, L, device="cuda", dtype=torch.uint8))):
-    tf = timeit(lambda i: ops.qwen_flash_fwd(*sets[i % NC][:3], mask, B, L, Hq, Hkv, D, D ** -0.5))
-    for parts in (1, 2):
-        tb = timeit(lambda i: ops.qwen_flash_bwd(*sets[i % NC][:3], mask, outs[i % NC][0], sets[i % NC][3], outs[i % NC][1], B, L, Hq, Hkv, D, D ** -0.5, kv_parts=parts))
-        print(f"{name}: fwd {tf:6.1f} us   bwd (dQ + dK/dV, kv_parts={parts}) {tb:6.1f} us   total {tf + tb:6.1f} us/layer", flush=True)
+    for ml in (0, int(mask[0].view(-1).nonzero().max().item()) // 32 + 1):
+        tf = timeit(lambda i: ops.qwen_flash_fwd(*sets[i % NC][:3], mask, B, L, Hq, Hkv, D, D ** -0.5, max_live_tiles=ml))
+        for parts in (1, 2):
+            tb = timeit(lambda i: ops.qwen_flash_bwd(*sets[i % NC][:3], mask, outs[i % NC][0], sets[i % NC][3], outs[i % NC][1], B, L, Hq, Hkv, D, D ** -0.5, kv_parts=parts, max_live_tiles=ml))
+            print(f"{name}, max_live_tiles={ml}: fwd {tf:6.1f} us   bwd (dQ + dK/dV, kv_parts={parts}) {tb:6.1f} us   total {tf + tb:6.1f} us/layer", flush=True)

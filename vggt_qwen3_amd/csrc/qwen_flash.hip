@@ -112,33 +112,58 @@ __device__ __forceinline__ unsigned touch_tile(const bf16_t* base, long rowstrid
   return *reinterpret_cast<const unsigned*>(base + (long)row * rowstride + (lane & 1) * 64);
 }
 
+// ---- LDS staging helpers (the dK/dV pass's private stages, the fat kernels' K / V slots)
+constexpr int DKV_TILE = 32 * 256;                       // bytes of a 32-row x 128-feature bf16 tile
+constexpr int DKV_STAGE = 2 * DKV_TILE + 256;            // Q | dO | 32 LSE + 32 delta floats
+__device__ __forceinline__ void dma_tile(const bf16_t* base, long rowstride, int row0, int maxrow, char* dst, int lane) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = 4 * p + (lane >> 4);
+    const int lchunk = (lane & 15) ^ (row & 15);
+    int grow = row0 + row;
+    grow = grow < maxrow ? grow : maxrow;
+    const char* g = reinterpret_cast<const char*>(base + (long)grow * rowstride) + lchunk * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ bf16x8 lds_row16(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 256 + ((chunk ^ (row & 15)) << 4));
+}
+// the gather of gather_load / gather_split from an LDS tile: 4 consecutive features 4r .. 4r+3 of 8 rows per half
+__device__ __forceinline__ void lds_gather(const char* tile, int sp, int h, int r, bf16x8 (&a)[4]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = 16 * sp + 8 * (j >> 2) + 4 * h + (j & 3);
+    const u32x2 g = *reinterpret_cast<const u32x2*>(tile + row * 256 + (((r >> 1) ^ (row & 15)) << 4) + ((r & 1) << 3));
+    a[0][j] = (short)(g[0] & 0xffff);
+    a[1][j] = (short)(g[0] >> 16);
+    a[2][j] = (short)(g[1] & 0xffff);
+    a[3][j] = (short)(g[1] >> 16);
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------ forward
 // grid: B * Hkv * nqb blocks of 4 waves; wave g = query head hk*G + g (G = Hq / Hkv <= 4; spare waves idle)
-__global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                            const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
-                                                            bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Hq,
-                                                            int Hkv, long ldo, float scale) {
-  __shared__ unsigned sbits[4][MAX_TILES];
-  __shared__ unsigned slist[4][MAX_TILES];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+// One 32-row query block of one query head: the wave's whole forward. LDS_KV = false: K / V tiles come from global memory (rows +
+// 8-byte gathers, all loads of a tile issued before its first use); true: they sit in LDS slots (slot li = the li-th attended tile of
+// the sample: [K tile | V tile], 16-byte chunks XOR (row & 15), staged by dma_tile) and a step has no global load at all. Same
+// arithmetic in the same order either way.
+template <bool LDS_KV>
+__device__ __forceinline__ void fwd_block(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                          bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Hq, int Hkv, long ldo, float scale,
+                                          int b, int hk, int hq, int qb, const unsigned* bits_g, const unsigned* list_g, int nlist,
+                                          const char* slots, const bf16x8* qpre = nullptr) {
+  const int lane = threadIdx.x & 63;
   const int r = lane & 31, h = lane >> 5;
-  const int nqb = (L + 31) / 32;
-  // heaviest blocks first: block ids are handed out in order, so all (b, kv-head) pairs of the last query block (the
-  // most key tiles) start before any lighter one and the light blocks fill the tail
-  const int nbh = gridDim.x / nqb;                            // B * Hkv
-  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);
-  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
-  const int G = Hq / Hkv, hq = hk * G + g;
-  if (g >= G) return;
-  key_bits_all(keymask + (long)b * L, qb + 1, L, sbits[g]);
-  const int nlist = compact_tiles(sbits[g], qb + 1, slist[g]);
   const int q = qb * 32 + r, qc = q < L ? q : L - 1;
   const bf16_t* Qr = Q + (((long)b * Hq + hq) * L + qc) * D + 8 * h;
   const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
   const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
   bf16x8 qf[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) qf[s] = ld8(Qr + 16 * s);
+  for (int s = 0; s < 8; ++s) qf[s] = qpre ? qpre[s] : ld8(Qr + 16 * s);      // (qpre: the caller requested the rows a query block ahead)
   f32x16 o[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db)
@@ -147,21 +172,28 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
   float m_run = -INFINITY, l_run = 0.f;
   const float sl2e = scale * LOG2E;
   for (int li = 0; li < nlist; ++li) {
-    const int kb = (int)slist[g][li];
+    const int kb = (int)list_g[li];
     // every load of the tile is issued before its first use: one memory round trip per tile; the next attended tile is touched
     // into L2 meanwhile
-    const int nkb = (int)slist[g][li + 1 < nlist ? li + 1 : li];
-    const unsigned tk = touch_tile(Kb, D, nkb * 32, L - 1), tv = touch_tile(Vb, D, nkb * 32, L - 1);
+    unsigned tk = 0, tv = 0;
     bf16x8 kc[8];
     u32x2 vc[2][8];
-    rows_load(Kb, D, kb * 32 + r, h, L - 1, kc);
-    gather_load(Vb, D, kb * 32, h, r, L - 1, vc);
+    const char* slot = slots + li * (2 * 32 * 256);
+    if (LDS_KV) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) kc[t] = *reinterpret_cast<const bf16x8*>(slot + r * 256 + (((2 * t + h) ^ (r & 15)) << 4));
+    } else {
+      const int nkb = (int)list_g[li + 1 < nlist ? li + 1 : li];
+      tk = touch_tile(Kb, D, nkb * 32, L - 1); tv = touch_tile(Vb, D, nkb * 32, L - 1);
+      rows_load(Kb, D, kb * 32 + r, h, L - 1, kc);
+      gather_load(Vb, D, kb * 32, h, r, L - 1, vc);
+    }
     f32x16 s;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[t], qf[t], s, 0, 0, 0);
-    const unsigned bits = sbits[g][kb];
+    const unsigned bits = bits_g[kb];
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -190,12 +222,13 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
       bf16x8 vf[4];
-      gather_split(vc[sp], vf);
+      if (LDS_KV) lds_gather(slot + 32 * 256, sp, h, r, vf);
+      else gather_split(vc[sp], vf);
       const bf16x8 pf = pack8(s, sp);
 #pragma unroll
       for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db], pf, o[db], 0, 0, 0);
     }
-    asm volatile("" ::"v"(tk), "v"(tv));   // keeps the touch loads alive; their wait lands here, after the tile's MFMAs
+    if (!LDS_KV) asm volatile("" ::"v"(tk), "v"(tv));   // keeps the touch loads alive; their wait lands here, after the tile's MFMAs
   }
   if (q >= L) return;
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -210,25 +243,112 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
   if (h == 0) LSE[((long)b * Hq + hq) * L + q] = l_run > 0.f ? m_run + __builtin_amdgcn_logf(l_run) : INFINITY;
 }
 
-// ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-__global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                               const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
-                                                               const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
-                                                               const float* __restrict__ LSE, float* __restrict__ Delta,
-                                                               bf16_t* __restrict__ dQ, int L, int Hq, int Hkv, long ldo,
-                                                               long lddo, float scale) {
+// grid: B * Hkv * nqb blocks of 4 waves; wave g = query head hk*G + g (G = Hq / Hkv <= 4; spare waves idle)
+__global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                            const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
+                                                            bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Hq,
+                                                            int Hkv, long ldo, float scale) {
   __shared__ unsigned sbits[4][MAX_TILES];
   __shared__ unsigned slist[4][MAX_TILES];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
+  const int g = threadIdx.x >> 6;
   const int nqb = (L + 31) / 32;
-  const int nbh = gridDim.x / nqb;
-  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);           // heaviest first (see the forward kernel)
+  // heaviest blocks first: block ids are handed out in order, so all (b, kv-head) pairs of the last query block (the
+  // most key tiles) start before any lighter one and the light blocks fill the tail
+  const int nbh = gridDim.x / nqb;                            // B * Hkv
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);
   const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
   const int G = Hq / Hkv, hq = hk * G + g;
   if (g >= G) return;
   key_bits_all(keymask + (long)b * L, qb + 1, L, sbits[g]);
   const int nlist = compact_tiles(sbits[g], qb + 1, slist[g]);
+  fwd_block<false>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, nullptr);
+}
+
+// (the fat kernels' rare path - a sample with more attended tiles than LDS slots - as a real call: inlined beside the LDS path it costs
+// the common path 50 spilled registers)
+__device__ __attribute__((noinline)) void fwd_block_global(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE, int L,
+                                                           int Hq, int Hkv, long ldo, float scale, int b, int hk, int hq, int qb,
+                                                           const unsigned* bits_g, const unsigned* list_g, int nlist) {
+  fwd_block<false>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, bits_g, list_g, nlist, nullptr);
+}
+
+// number of list entries (ascending tile indices) that a query block may attend to: tiles <= qb
+__device__ __forceinline__ int tiles_upto(const unsigned* list, int n, int qb) {
+  int c = 0;
+  for (int i = 0; i < n; ++i) c += ((int)list[i] <= qb) ? 1 : 0;
+  return c;
+}
+
+// One workgroup per (sample, kv head) for short sequences (L <= 32 * FAT_TILES) whose attended key tiles are few - what the
+// reference's collator produces: the mask covers the 20-50 text positions of a 200-column row. The per-query-block kernels above pay
+// their start-up (key bits, tile list, the first K / V round trip) 7 x 384 times per layer for one or two tile steps each; here the
+// sample's attended K / V tiles are staged into LDS ONCE (at most nt_lds of them: the caller's bound; all four query heads and all
+// query blocks read them from there) and a wave walks its head's query blocks with no global load inside a tile step. A sample with
+// more attended tiles than slots takes the global-operand path for all its blocks - same results, the bound is only about speed.
+constexpr int FAT_TILES = 8;
+__global__ __launch_bounds__(256, 2) void qwen_flash_fwd_fat_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
+                                                                bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Hq,
+                                                                int Hkv, long ldo, float scale, int nt_lds) {
+  extern __shared__ __attribute__((aligned(16))) char fat_smem[];        // nt_lds slots of [K tile | V tile]
+  __shared__ unsigned sbits[4][FAT_TILES];
+  __shared__ unsigned slist[4][FAT_TILES];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int gu = __builtin_amdgcn_readfirstlane(g);
+  const int nqb = (L + 31) / 32;
+  const int hk = blockIdx.x % Hkv, b = blockIdx.x / Hkv;
+  const int G = Hq / Hkv, hq = hk * G + g;
+  key_bits_all(keymask + (long)b * L, nqb, L, sbits[g]);
+  const int nlive = compact_tiles(sbits[g], nqb, slist[g]);
+  const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
+  const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
+  const bool fits = nlive <= nt_lds;                              // workgroup-uniform (every wave computed the same list)
+  if (fits) {
+    for (int li = gu; li < nlive; li += 4) {
+      const int kb = (int)slist[g][li];
+      char* slot = fat_smem + li * (2 * 32 * 256);
+      dma_tile(Kb, D, kb * 32, L - 1, slot, lane);
+      dma_tile(Vb, D, kb * 32, L - 1, slot + 32 * 256, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (g >= G) return;
+  if (!fits) {
+    for (int qb = nqb - 1; qb >= 0; --qb)
+      fwd_block_global(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], tiles_upto(slist[g], nlive, qb));
+    return;
+  }
+  // the Q rows of query block qb - 1 are requested before block qb is multiplied: with K / V in LDS they are the only global loads
+  // left in a block, and their round trip would otherwise be paid once per block
+  const int r = lane & 31, h = lane >> 5;
+  auto qrows = [&](int qb, bf16x8 (&f)[8]) {
+    const int q = qb * 32 + r, qc = q < L ? q : L - 1;
+    const bf16_t* Qr = Q + (((long)b * Hq + hq) * L + qc) * D + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) f[s] = ld8(Qr + 16 * s);
+  };
+  bf16x8 qcur[8], qnext[8];
+  qrows(nqb - 1, qcur);
+  for (int qb = nqb - 1; qb >= 0; --qb) {
+    if (qb > 0) qrows(qb - 1, qnext);
+    fwd_block<true>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], tiles_upto(slist[g], nlive, qb), fat_smem, qcur);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qcur[s] = qnext[s];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
+// One 32-row query block of one query head in the dQ pass (LDS_KV as in fwd_block: K / V tiles from global memory or from the
+// workgroup's LDS slots; same arithmetic either way).
+template <bool LDS_KV>
+__device__ __forceinline__ void dq_block(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                         const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
+                                         float* __restrict__ Delta, bf16_t* __restrict__ dQ, int L, int Hq, int Hkv, long ldo, long lddo,
+                                         float scale, int b, int hk, int hq, int qb, const unsigned* bits_g, const unsigned* list_g,
+                                         int nlist, const char* slots) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
   const int q = qb * 32 + r, qc = q < L ? q : L - 1;
   const bf16_t* Qr = Q + (((long)b * Hq + hq) * L + qc) * D + 8 * h;
   const bf16_t* Or = O + ((long)b * L + qc) * ldo + (long)hq * D + 8 * h;
@@ -254,14 +374,24 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
     for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
   const float sl2e = scale * LOG2E;
   for (int li = 0; li < nlist; ++li) {
-    const int kb = (int)slist[g][li];
-    const int nkb = (int)slist[g][li + 1 < nlist ? li + 1 : li];
-    const unsigned tk = touch_tile(Kb, D, nkb * 32, L - 1), tv = touch_tile(Vb, D, nkb * 32, L - 1);
+    const int kb = (int)list_g[li];
+    unsigned tk = 0, tv = 0;
     bf16x8 kc[8], vc[8];
     u32x2 gc[2][8];
-    rows_load(Kb, D, kb * 32 + r, h, L - 1, kc);
-    rows_load(Vb, D, kb * 32 + r, h, L - 1, vc);
-    gather_load(Kb, D, kb * 32, h, r, L - 1, gc);
+    const char* slot = slots + li * (2 * 32 * 256);
+    if (LDS_KV) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        kc[t] = *reinterpret_cast<const bf16x8*>(slot + r * 256 + (((2 * t + h) ^ (r & 15)) << 4));
+        vc[t] = *reinterpret_cast<const bf16x8*>(slot + 32 * 256 + r * 256 + (((2 * t + h) ^ (r & 15)) << 4));
+      }
+    } else {
+      const int nkb = (int)list_g[li + 1 < nlist ? li + 1 : li];
+      tk = touch_tile(Kb, D, nkb * 32, L - 1); tv = touch_tile(Vb, D, nkb * 32, L - 1);
+      rows_load(Kb, D, kb * 32 + r, h, L - 1, kc);
+      rows_load(Vb, D, kb * 32 + r, h, L - 1, vc);
+      gather_load(Kb, D, kb * 32, h, r, L - 1, gc);
+    }
     f32x16 s, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -270,7 +400,7 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[t], qf[t], s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc[t], dof[t], dp, 0, 0, 0);
     }
-    const unsigned bits = sbits[g][kb];
+    const unsigned bits = bits_g[kb];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int kl = rho(i, h);
@@ -281,12 +411,13 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
       bf16x8 kf[4];
-      gather_split(gc[sp], kf);
+      if (LDS_KV) lds_gather(slot, sp, h, r, kf);
+      else gather_split(gc[sp], kf);
       const bf16x8 dsf = pack8(s, sp);
 #pragma unroll
       for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[db], dsf, dq[db], 0, 0, 0);
     }
-    asm volatile("" ::"v"(tk), "v"(tv));
+    if (!LDS_KV) asm volatile("" ::"v"(tk), "v"(tv));
   }
   if (q >= L) return;
   bf16_t* dQr = dQ + (((long)b * Hq + hq) * L + q) * D;
@@ -298,6 +429,71 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
     *reinterpret_cast<u32x2*>(dQr + 4 * rho(i, h)) = w;
   }
   if (h == 0) Delta[((long)b * Hq + hq) * L + q] = delta;
+}
+
+__global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                               const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
+                                                               const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
+                                                               const float* __restrict__ LSE, float* __restrict__ Delta,
+                                                               bf16_t* __restrict__ dQ, int L, int Hq, int Hkv, long ldo,
+                                                               long lddo, float scale) {
+  __shared__ unsigned sbits[4][MAX_TILES];
+  __shared__ unsigned slist[4][MAX_TILES];
+  const int g = threadIdx.x >> 6;
+  const int nqb = (L + 31) / 32;
+  const int nbh = gridDim.x / nqb;
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);           // heaviest first (see the forward kernel)
+  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
+  const int G = Hq / Hkv, hq = hk * G + g;
+  if (g >= G) return;
+  key_bits_all(keymask + (long)b * L, qb + 1, L, sbits[g]);
+  const int nlist = compact_tiles(sbits[g], qb + 1, slist[g]);
+  dq_block<false>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, nullptr);
+}
+
+__device__ __attribute__((noinline)) void dq_block_global(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* O, const bf16_t* dO,
+                                                          const float* LSE, float* Delta, bf16_t* dQ, int L, int Hq, int Hkv, long ldo,
+                                                          long lddo, float scale, int b, int hk, int hq, int qb, const unsigned* bits_g,
+                                                          const unsigned* list_g, int nlist) {
+  dq_block<false>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, bits_g, list_g, nlist, nullptr);
+}
+
+// the dQ pass in the one-workgroup-per-(sample, kv head) form of qwen_flash_fwd_fat_kernel
+__global__ __launch_bounds__(256, 2) void qwen_flash_bwd_dq_fat_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                      const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
+                                                                      const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
+                                                                      const float* __restrict__ LSE, float* __restrict__ Delta,
+                                                                      bf16_t* __restrict__ dQ, int L, int Hq, int Hkv, long ldo,
+                                                                      long lddo, float scale, int nt_lds) {
+  extern __shared__ __attribute__((aligned(16))) char fat_smem[];
+  __shared__ unsigned sbits[4][FAT_TILES];
+  __shared__ unsigned slist[4][FAT_TILES];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int gu = __builtin_amdgcn_readfirstlane(g);
+  const int nqb = (L + 31) / 32;
+  const int hk = blockIdx.x % Hkv, b = blockIdx.x / Hkv;
+  const int G = Hq / Hkv, hq = hk * G + g;
+  key_bits_all(keymask + (long)b * L, nqb, L, sbits[g]);
+  const int nlive = compact_tiles(sbits[g], nqb, slist[g]);
+  const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
+  const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
+  const bool fits = nlive <= nt_lds;
+  if (fits) {
+    for (int li = gu; li < nlive; li += 4) {
+      const int kb = (int)slist[g][li];
+      char* slot = fat_smem + li * (2 * 32 * 256);
+      dma_tile(Kb, D, kb * 32, L - 1, slot, lane);
+      dma_tile(Vb, D, kb * 32, L - 1, slot + 32 * 256, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (g >= G) return;
+  for (int qb = nqb - 1; qb >= 0; --qb) {
+    const int nlist = tiles_upto(slist[g], nlive, qb);
+    if (fits) dq_block<true>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, fat_smem);
+    else dq_block_global(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -443,36 +639,6 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_kernel(const bf16_t* _
 // MFMA work. Here each wave owns two LDS stages of {Q tile, dO tile, LSE | delta} (32 rows x 256 B each, 16-byte chunks XOR (row & 15))
 // filled by global_load_lds one q-block AHEAD (17 DMA instructions per stage, counted vmcnt - no barrier: a wave reads only what it
 // staged itself), and both operand forms are LDS reads: the rows as ds_read_b128, the gathers as ds_read_b64 of the same tile.
-constexpr int DKV_TILE = 32 * 256;                       // bytes of a 32-row x 128-feature bf16 tile
-constexpr int DKV_STAGE = 2 * DKV_TILE + 256;            // Q | dO | 32 LSE + 32 delta floats
-__device__ __forceinline__ void dma_tile(const bf16_t* base, long rowstride, int row0, int maxrow, char* dst, int lane) {
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int row = 4 * p + (lane >> 4);
-    const int lchunk = (lane & 15) ^ (row & 15);
-    int grow = row0 + row;
-    grow = grow < maxrow ? grow : maxrow;
-    const char* g = reinterpret_cast<const char*>(base + (long)grow * rowstride) + lchunk * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
-  }
-}
-__device__ __forceinline__ bf16x8 lds_row16(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(tile + row * 256 + ((chunk ^ (row & 15)) << 4));
-}
-// the gather of gather_load / gather_split from an LDS tile: 4 consecutive features 4r .. 4r+3 of 8 rows per half
-__device__ __forceinline__ void lds_gather(const char* tile, int sp, int h, int r, bf16x8 (&a)[4]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int row = 16 * sp + 8 * (j >> 2) + 4 * h + (j & 3);
-    const u32x2 g = *reinterpret_cast<const u32x2*>(tile + row * 256 + (((r >> 1) ^ (row & 15)) << 4) + ((r & 1) << 3));
-    a[0][j] = (short)(g[0] & 0xffff);
-    a[1][j] = (short)(g[0] >> 16);
-    a[2][j] = (short)(g[1] & 0xffff);
-    a[3][j] = (short)(g[1] >> 16);
-  }
-}
-
 __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_lds_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                     const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
                                                                     const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
@@ -638,6 +804,68 @@ extern "C" int vq3_qwen_flash_fwd(const void* Q, const void* K, const void* V, c
   return 0;
 }
 
+// LDS bytes of the fat kernels for a caller-supplied bound (0: the bound does not allow them)
+static int fat_slots(int L, int max_live_tiles) {
+  const int nqb = (L + 31) / 32;
+  if (max_live_tiles <= 0 || nqb > FAT_TILES) return 0;
+  static int fat_on = -1, fat_max = 4;
+  if (fat_on < 0) {
+    const char* e = getenv("VQ3_QWEN_FAT");
+    fat_on = e ? atoi(e) : 1;
+    const char* m = getenv("VQ3_QWEN_FAT_MAX");
+    if (m) fat_max = atoi(m);
+    if (fat_max > FAT_TILES) fat_max = FAT_TILES;
+    if (fat_on) {
+      const int bytes = FAT_TILES * 2 * 32 * 256;
+      if (hipFuncSetAttribute((const void*)qwen_flash_fwd_fat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+          hipFuncSetAttribute((const void*)qwen_flash_bwd_dq_fat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        fat_on = 0;
+      }
+    }
+  }
+  if (!fat_on) return 0;
+  const int nt = max_live_tiles < nqb ? max_live_tiles : nqb;
+  return nt <= fat_max ? nt : 0;              // more slots than that: one workgroup per CU, the per-block kernels do better
+}
+
+extern "C" int vq3_qwen_flash_fwd_b(const void* Q, const void* K, const void* V, const void* keymask, void* O, float* LSE,
+                                    int32_t B, int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, float scale,
+                                    int32_t max_live_tiles, void* stream) {
+  const int nt = fat_slots(L, max_live_tiles);
+  if (!nt) return vq3_qwen_flash_fwd(Q, K, V, keymask, O, LSE, B, L, Hq, Hkv, Dh, ldo, scale, stream);
+  VQ3_CHECK_ARG(Q && K && V && keymask && O && LSE, "qwen_flash_fwd: null pointer");
+  if (flash_check("qwen_flash_fwd", B, L, Hq, Hkv, Dh)) return 1;
+  VQ3_CHECK_ARG(ldo >= (long)Hq * D && ldo % 4 == 0, "qwen_flash_fwd: bad output row stride");
+  hipLaunchKernelGGL(qwen_flash_fwd_fat_kernel, dim3(B * Hkv), dim3(256), nt * 2 * 32 * 256, (hipStream_t)stream, (const bf16_t*)Q,
+                     (const bf16_t*)K, (const bf16_t*)V, (const uint8_t*)keymask, (bf16_t*)O, LSE, L, Hq, Hkv, (long)ldo, scale, nt);
+  VQ3_CHECK_LAUNCH("qwen_flash_fwd(fat)");
+  return 0;
+}
+
+static int launch_dkv(const void* Q, const void* K, const void* V, const void* keymask, const void* dO, const float* LSE, float* Delta,
+                      void* dK, void* dV, int kv_parts, int B, int L, int Hq, int Hkv, long lddo, float scale, hipStream_t s);
+
+extern "C" int vq3_qwen_flash_bwd_b(const void* Q, const void* K, const void* V, const void* keymask, const void* O,
+                                    const void* dO, const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t kv_parts,
+                                    int32_t B, int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, int64_t lddo,
+                                    float scale, int32_t max_live_tiles, void* stream) {
+  const int nt = fat_slots(L, max_live_tiles);
+  if (!nt) return vq3_qwen_flash_bwd(Q, K, V, keymask, O, dO, LSE, Delta, dQ, dK, dV, kv_parts, B, L, Hq, Hkv, Dh, ldo, lddo, scale, stream);
+  VQ3_CHECK_ARG(Q && K && V && keymask && O && dO && LSE && Delta && dQ && dK && dV, "qwen_flash_bwd: null pointer");
+  if (flash_check("qwen_flash_bwd", B, L, Hq, Hkv, Dh)) return 1;
+  VQ3_CHECK_ARG(ldo >= (long)Hq * D && lddo >= (long)Hq * D && ldo % 8 == 0 && lddo % 8 == 0, "qwen_flash_bwd: bad row strides");
+  VQ3_CHECK_ARG(kv_parts >= 1 && kv_parts <= 4, "qwen_flash_bwd: kv_parts must be 1..4");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(qwen_flash_bwd_dq_fat_kernel, dim3(B * Hkv), dim3(256), nt * 2 * 32 * 256, s, (const bf16_t*)Q, (const bf16_t*)K,
+                     (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)O, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dQ, L,
+                     Hq, Hkv, (long)ldo, (long)lddo, scale, nt);
+  const int rc = launch_dkv(Q, K, V, keymask, dO, LSE, Delta, dK, dV, kv_parts, B, L, Hq, Hkv, (long)lddo, scale, s);
+  if (rc) return rc;
+  VQ3_CHECK_LAUNCH("qwen_flash_bwd(fat dQ)");
+  return 0;
+}
+
 extern "C" int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* keymask, const void* O,
                                   const void* dO, const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t kv_parts,
                                   int32_t B, int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, int64_t lddo,
@@ -651,6 +879,15 @@ extern "C" int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, c
   hipLaunchKernelGGL(qwen_flash_bwd_dq_kernel, dim3(B * Hkv * nqb), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
                      (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)O, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dQ, L,
                      Hq, Hkv, (long)ldo, (long)lddo, scale);
+  const int rc_dkv = launch_dkv(Q, K, V, keymask, dO, LSE, Delta, dK, dV, kv_parts, B, L, Hq, Hkv, (long)lddo, scale, s);
+  if (rc_dkv) return rc_dkv;
+  VQ3_CHECK_LAUNCH("qwen_flash_bwd");
+  return 0;
+}
+
+static int launch_dkv(const void* Q, const void* K, const void* V, const void* keymask, const void* dO, const float* LSE, float* Delta,
+                      void* dK, void* dV, int kv_parts, int B, int L, int Hq, int Hkv, long lddo, float scale, hipStream_t s) {
+  const int nqb = (L + 31) / 32;
   // dK / dV pass: the LDS-staged kernel (operands of the next q-block in flight while this one multiplies); VQ3_QWEN_DKV_LDS=0 = the
   // register-staged one
   static int dkv_lds = -1;
@@ -670,6 +907,5 @@ extern "C" int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, c
     hipLaunchKernelGGL(qwen_flash_bwd_dkv_kernel, dim3(B * Hkv * nqb * kv_parts), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
                        (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dK, (bf16_t*)dV, L, Hq,
                        Hkv, (long)lddo, scale, (int)kv_parts, (long)B * Hkv * L * D);
-  VQ3_CHECK_LAUNCH("qwen_flash_bwd");
   return 0;
 }
