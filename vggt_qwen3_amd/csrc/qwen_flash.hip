@@ -144,6 +144,23 @@ __device__ __forceinline__ void lds_gather(const char* tile, int sp, int h, int 
 }
 
 
+// Output tiles leave through LDS as whole rows. The accumulator layout gives a lane 8-byte pieces (4 features) of ONE row, 16 of them
+// 16 bytes apart in pairs: stored straight from registers every store instruction scatters 64 pieces over 32 rows - 1 024 partial-line
+// write requests per 8-KiB tile, and for these short kernels the request rate of the L2 write path is what they wait for. put: the
+// piece goes to the wave's 8-KiB tile (32 rows x 256 B, 16-byte chunks XOR (row & 15)); flush: 8 passes of 4 whole rows, 16 B per lane.
+__device__ __forceinline__ void tile_put8(char* tile, int row, int piece, const u32x2& w) {      // piece = feature / 4
+  *reinterpret_cast<u32x2*>(tile + row * 256 + (((piece >> 1) ^ (row & 15)) << 4) + ((piece & 1) << 3)) = w;
+}
+__device__ __forceinline__ void tile_flush(const char* tile, bf16_t* base, long rowstride, int row0, int L, int lane) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = 4 * p + (lane >> 4);
+    const int phys = lane & 15, logical = phys ^ (row & 15);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * 256 + (phys << 4));
+    if (row0 + row < L) *reinterpret_cast<u32x4*>(base + (long)(row0 + row) * rowstride + logical * 8) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // grid: B * Hkv * nqb blocks of 4 waves; wave g = query head hk*G + g (G = Hq / Hkv <= 4; spare waves idle)
 // One 32-row query block of one query head: the wave's whole forward. LDS_KV = false: K / V tiles come from global memory (rows +
@@ -154,7 +171,7 @@ template <bool LDS_KV>
 __device__ __forceinline__ void fwd_block(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                           bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Hq, int Hkv, long ldo, float scale,
                                           int b, int hk, int hq, int qb, const unsigned* bits_g, const unsigned* list_g, int nlist,
-                                          const char* slots, const bf16x8* qpre = nullptr) {
+                                          const char* slots, char* otile, const bf16x8* qpre = nullptr) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, h = lane >> 5;
   const int q = qb * 32 + r, qc = q < L ? q : L - 1;
@@ -230,17 +247,16 @@ __device__ __forceinline__ void fwd_block(const bf16_t* __restrict__ Q, const bf
     }
     if (!LDS_KV) asm volatile("" ::"v"(tk), "v"(tv));   // keeps the touch loads alive; their wait lands here, after the tile's MFMAs
   }
-  if (q >= L) return;
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-  bf16_t* Or = O + ((long)b * L + q) * ldo + (long)hq * D;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     u32x2 w;
     w[0] = pack2bf(o[0][i] * inv, o[1][i] * inv);
     w[1] = pack2bf(o[2][i] * inv, o[3][i] * inv);
-    *reinterpret_cast<u32x2*>(Or + 4 * rho(i, h)) = w;
+    tile_put8(otile, r, rho(i, h), w);
   }
-  if (h == 0) LSE[((long)b * Hq + hq) * L + q] = l_run > 0.f ? m_run + __builtin_amdgcn_logf(l_run) : INFINITY;
+  tile_flush(otile, O + (long)b * L * ldo + (long)hq * D, ldo, qb * 32, L, lane);
+  if (h == 0 && q < L) LSE[((long)b * Hq + hq) * L + q] = l_run > 0.f ? m_run + __builtin_amdgcn_logf(l_run) : INFINITY;
 }
 
 // grid: B * Hkv * nqb blocks of 4 waves; wave g = query head hk*G + g (G = Hq / Hkv <= 4; spare waves idle)
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
                                                             int Hkv, long ldo, float scale) {
   __shared__ unsigned sbits[4][MAX_TILES];
   __shared__ unsigned slist[4][MAX_TILES];
+  __shared__ __attribute__((aligned(16))) char ostage[4][32 * 256];
   const int g = threadIdx.x >> 6;
   const int nqb = (L + 31) / 32;
   // heaviest blocks first: block ids are handed out in order, so all (b, kv-head) pairs of the last query block (the
@@ -261,15 +278,15 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
   if (g >= G) return;
   key_bits_all(keymask + (long)b * L, qb + 1, L, sbits[g]);
   const int nlist = compact_tiles(sbits[g], qb + 1, slist[g]);
-  fwd_block<false>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, nullptr);
+  fwd_block<false>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, nullptr, ostage[g]);
 }
 
 // (the fat kernels' rare path - a sample with more attended tiles than LDS slots - as a real call: inlined beside the LDS path it costs
 // the common path 50 spilled registers)
 __device__ __attribute__((noinline)) void fwd_block_global(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE, int L,
                                                            int Hq, int Hkv, long ldo, float scale, int b, int hk, int hq, int qb,
-                                                           const unsigned* bits_g, const unsigned* list_g, int nlist) {
-  fwd_block<false>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, bits_g, list_g, nlist, nullptr);
+                                                           const unsigned* bits_g, const unsigned* list_g, int nlist, char* otile) {
+  fwd_block<false>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, bits_g, list_g, nlist, nullptr, otile);
 }
 
 // number of list entries (ascending tile indices) that a query block may attend to: tiles <= qb
@@ -303,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void qwen_flash_fwd_fat_kernel(const bf16_t
   const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
   const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
   const bool fits = nlive <= nt_lds;                              // workgroup-uniform (every wave computed the same list)
+  char* const otile = fat_smem + nt_lds * (2 * 32 * 256) + gu * (32 * 256);      // behind the K / V slots: one output tile per wave
   if (fits) {
     for (int li = gu; li < nlive; li += 4) {
       const int kb = (int)slist[g][li];
@@ -316,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void qwen_flash_fwd_fat_kernel(const bf16_t
   if (g >= G) return;
   if (!fits) {
     for (int qb = nqb - 1; qb >= 0; --qb)
-      fwd_block_global(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], tiles_upto(slist[g], nlive, qb));
+      fwd_block_global(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], tiles_upto(slist[g], nlive, qb), otile);
     return;
   }
   // the Q rows of query block qb - 1 are requested before block qb is multiplied: with K / V in LDS they are the only global loads
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void qwen_flash_fwd_fat_kernel(const bf16_t
   qrows(nqb - 1, qcur);
   for (int qb = nqb - 1; qb >= 0; --qb) {
     if (qb > 0) qrows(qb - 1, qnext);
-    fwd_block<true>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], tiles_upto(slist[g], nlive, qb), fat_smem, qcur);
+    fwd_block<true>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], tiles_upto(slist[g], nlive, qb), fat_smem, otile, qcur);
 #pragma unroll
     for (int s = 0; s < 8; ++s) qcur[s] = qnext[s];
   }
@@ -346,7 +364,7 @@ __device__ __forceinline__ void dq_block(const bf16_t* __restrict__ Q, const bf1
                                          const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, const float* __restrict__ LSE,
                                          float* __restrict__ Delta, bf16_t* __restrict__ dQ, int L, int Hq, int Hkv, long ldo, long lddo,
                                          float scale, int b, int hk, int hq, int qb, const unsigned* bits_g, const unsigned* list_g,
-                                         int nlist, const char* slots) {
+                                         int nlist, const char* slots, char* otile) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, h = lane >> 5;
   const int q = qb * 32 + r, qc = q < L ? q : L - 1;
@@ -419,16 +437,15 @@ __device__ __forceinline__ void dq_block(const bf16_t* __restrict__ Q, const bf1
     }
     if (!LDS_KV) asm volatile("" ::"v"(tk), "v"(tv));
   }
-  if (q >= L) return;
-  bf16_t* dQr = dQ + (((long)b * Hq + hq) * L + q) * D;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     u32x2 w;
     w[0] = pack2bf(dq[0][i], dq[1][i]);
     w[1] = pack2bf(dq[2][i], dq[3][i]);
-    *reinterpret_cast<u32x2*>(dQr + 4 * rho(i, h)) = w;
+    tile_put8(otile, r, rho(i, h), w);
   }
-  if (h == 0) Delta[((long)b * Hq + hq) * L + q] = delta;
+  tile_flush(otile, dQ + ((long)b * Hq + hq) * L * D, D, qb * 32, L, lane);
+  if (h == 0 && q < L) Delta[((long)b * Hq + hq) * L + q] = delta;
 }
 
 __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
@@ -439,6 +456,7 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
                                                                long lddo, float scale) {
   __shared__ unsigned sbits[4][MAX_TILES];
   __shared__ unsigned slist[4][MAX_TILES];
+  __shared__ __attribute__((aligned(16))) char ostage[4][32 * 256];
   const int g = threadIdx.x >> 6;
   const int nqb = (L + 31) / 32;
   const int nbh = gridDim.x / nqb;
@@ -448,14 +466,14 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
   if (g >= G) return;
   key_bits_all(keymask + (long)b * L, qb + 1, L, sbits[g]);
   const int nlist = compact_tiles(sbits[g], qb + 1, slist[g]);
-  dq_block<false>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, nullptr);
+  dq_block<false>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, nullptr, ostage[g]);
 }
 
 __device__ __attribute__((noinline)) void dq_block_global(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* O, const bf16_t* dO,
                                                           const float* LSE, float* Delta, bf16_t* dQ, int L, int Hq, int Hkv, long ldo,
                                                           long lddo, float scale, int b, int hk, int hq, int qb, const unsigned* bits_g,
-                                                          const unsigned* list_g, int nlist) {
-  dq_block<false>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, bits_g, list_g, nlist, nullptr);
+                                                          const unsigned* list_g, int nlist, char* otile) {
+  dq_block<false>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, bits_g, list_g, nlist, nullptr, otile);
 }
 
 // the dQ pass in the one-workgroup-per-(sample, kv head) form of qwen_flash_fwd_fat_kernel
@@ -478,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void qwen_flash_bwd_dq_fat_kernel(const bf1
   const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
   const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
   const bool fits = nlive <= nt_lds;
+  char* const otile = fat_smem + nt_lds * (2 * 32 * 256) + gu * (32 * 256);
   if (fits) {
     for (int li = gu; li < nlive; li += 4) {
       const int kb = (int)slist[g][li];
@@ -491,8 +510,8 @@ __global__ __launch_bounds__(256, 2) void qwen_flash_bwd_dq_fat_kernel(const bf1
   if (g >= G) return;
   for (int qb = nqb - 1; qb >= 0; --qb) {
     const int nlist = tiles_upto(slist[g], nlive, qb);
-    if (fits) dq_block<true>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, fat_smem);
-    else dq_block_global(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist);
+    if (fits) dq_block<true>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, fat_smem, otile);
+    else dq_block_global(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, otile);
   }
 }
 
@@ -771,11 +790,29 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dkv_lds_kernel(const bf16_
       for (int i = 0; i < 16; ++i) keep[blk >> 2][i] = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
     }
   }
-  if (key >= L) return;
+  // wave g holds feature d = 4 rho(i) + g of both tiles: 2-byte pieces 8 bytes apart. Through two LDS tiles (the stages are dead: every
+  // wave passed the reduction's barriers) they leave as whole 256-byte rows, 16 B per thread
+  (void)dKr; (void)dVr;
+  char* const tk = dkv_smem;
+  char* const tv = dkv_smem + DKV_TILE;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    dKr[4 * rho(i, h) + g] = f2bf(keep[0][i]);
-    dVr[4 * rho(i, h) + g] = f2bf(keep[1][i]);
+    const int d = 4 * rho(i, h) + g;
+    const int off = r * 256 + (((d >> 3) ^ (r & 15)) << 4) + ((d & 7) << 1);
+    *reinterpret_cast<bf16_t*>(tk + off) = f2bf(keep[0][i]);
+    *reinterpret_cast<bf16_t*>(tv + off) = f2bf(keep[1][i]);
+  }
+  __syncthreads();
+  bf16_t* dKb = dK + ((long)b * Hkv + hk) * L * D;
+  bf16_t* dVb = dV + ((long)b * Hkv + hk) * L * D;
+#pragma unroll
+  for (int pss = 0; pss < 2; ++pss) {
+    const int idx = threadIdx.x + 256 * pss;                 // 512 chunks of 16 B per tile
+    const int row = idx >> 4, phys = idx & 15, logical = phys ^ (row & 15);
+    if (kb * 32 + row < L) {
+      *reinterpret_cast<u32x4*>(dKb + (long)(kb * 32 + row) * D + logical * 8) = *reinterpret_cast<const u32x4*>(tk + row * 256 + (phys << 4));
+      *reinterpret_cast<u32x4*>(dVb + (long)(kb * 32 + row) * D + logical * 8) = *reinterpret_cast<const u32x4*>(tv + row * 256 + (phys << 4));
+    }
   }
 }
 constexpr int DKV_SMEM = 4 * 2 * DKV_STAGE + 4 * 16 * 64 * 4;
@@ -816,7 +853,7 @@ static int fat_slots(int L, int max_live_tiles) {
     if (m) fat_max = atoi(m);
     if (fat_max > FAT_TILES) fat_max = FAT_TILES;
     if (fat_on) {
-      const int bytes = FAT_TILES * 2 * 32 * 256;
+      const int bytes = FAT_TILES * 2 * 32 * 256 + 4 * 32 * 256;
       if (hipFuncSetAttribute((const void*)qwen_flash_fwd_fat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
           hipFuncSetAttribute((const void*)qwen_flash_bwd_dq_fat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -837,7 +874,7 @@ extern "C" int vq3_qwen_flash_fwd_b(const void* Q, const void* K, const void* V,
   VQ3_CHECK_ARG(Q && K && V && keymask && O && LSE, "qwen_flash_fwd: null pointer");
   if (flash_check("qwen_flash_fwd", B, L, Hq, Hkv, Dh)) return 1;
   VQ3_CHECK_ARG(ldo >= (long)Hq * D && ldo % 4 == 0, "qwen_flash_fwd: bad output row stride");
-  hipLaunchKernelGGL(qwen_flash_fwd_fat_kernel, dim3(B * Hkv), dim3(256), nt * 2 * 32 * 256, (hipStream_t)stream, (const bf16_t*)Q,
+  hipLaunchKernelGGL(qwen_flash_fwd_fat_kernel, dim3(B * Hkv), dim3(256), nt * 2 * 32 * 256 + 4 * 32 * 256, (hipStream_t)stream, (const bf16_t*)Q,
                      (const bf16_t*)K, (const bf16_t*)V, (const uint8_t*)keymask, (bf16_t*)O, LSE, L, Hq, Hkv, (long)ldo, scale, nt);
   VQ3_CHECK_LAUNCH("qwen_flash_fwd(fat)");
   return 0;
@@ -857,7 +894,7 @@ extern "C" int vq3_qwen_flash_bwd_b(const void* Q, const void* K, const void* V,
   VQ3_CHECK_ARG(ldo >= (long)Hq * D && lddo >= (long)Hq * D && ldo % 8 == 0 && lddo % 8 == 0, "qwen_flash_bwd: bad row strides");
   VQ3_CHECK_ARG(kv_parts >= 1 && kv_parts <= 4, "qwen_flash_bwd: kv_parts must be 1..4");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(qwen_flash_bwd_dq_fat_kernel, dim3(B * Hkv), dim3(256), nt * 2 * 32 * 256, s, (const bf16_t*)Q, (const bf16_t*)K,
+  hipLaunchKernelGGL(qwen_flash_bwd_dq_fat_kernel, dim3(B * Hkv), dim3(256), nt * 2 * 32 * 256 + 4 * 32 * 256, s, (const bf16_t*)Q, (const bf16_t*)K,
                      (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)O, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dQ, L,
                      Hq, Hkv, (long)ldo, (long)lddo, scale, nt);
   const int rc = launch_dkv(Q, K, V, keymask, dO, LSE, Delta, dK, dV, kv_parts, B, L, Hq, Hkv, (long)lddo, scale, s);
