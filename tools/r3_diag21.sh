@@ -19,8 +19,8 @@ for k in a:
 print("mismatches:", bad, "of", 3 * len(a))
 PY
 tail -3 $O/compare.log
-timeout -k 10 200 python tools/bench_qwen_flash.py 48 > $O/bench48.log 2>&1 && echo bench48 ok
-grep -v amdgpu $O/bench48.log | grep "max_live_tiles=0"
+true
+true
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -o p -- python3 bench.py --steps 16 --grad-accum 8 --warmup 8 --no-variants --no-trim-variant --no-cpu-baseline > $O/prof.log 2>&1 && python tools/step_breakdown.py $O/p/p_kernel_trace.csv $O/breakdown.csv > /dev/null && echo prof ok
 rm -rf $O/p
 grep -E "qwen_flash|qkprep|TOTAL|window" $O/breakdown.csv

@@ -306,17 +306,22 @@ constexpr int FAT_TILES = 8;
 __global__ __launch_bounds__(256, 2) void qwen_flash_fwd_fat_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                 const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
                                                                 bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Hq,
-                                                                int Hkv, long ldo, float scale, int nt_lds) {
+                                                                int Hkv, long ldo, float scale, int nt_lds, int per_block) {
   extern __shared__ __attribute__((aligned(16))) char fat_smem[];        // nt_lds slots of [K tile | V tile]
   __shared__ unsigned sbits[4][FAT_TILES];
   __shared__ unsigned slist[4][FAT_TILES];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int gu = __builtin_amdgcn_readfirstlane(g);
   const int nqb = (L + 31) / 32;
-  const int hk = blockIdx.x % Hkv, b = blockIdx.x / Hkv;
+  // per_block: one workgroup per (sample, kv head, query block) - the grid of the per-block kernel, heaviest blocks first - that stages
+  // only the tiles ITS block attends to; otherwise one workgroup per (sample, kv head) walks all query blocks
+  const int nbh = per_block ? (int)gridDim.x / nqb : (int)gridDim.x;
+  const int qb_only = per_block ? nqb - 1 - (int)(blockIdx.x / nbh) : -1;
+  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
   const int G = Hq / Hkv, hq = hk * G + g;
-  key_bits_all(keymask + (long)b * L, nqb, L, sbits[g]);
-  const int nlive = compact_tiles(sbits[g], nqb, slist[g]);
+  const int ntile = per_block ? qb_only + 1 : nqb;
+  key_bits_all(keymask + (long)b * L, ntile, L, sbits[g]);
+  const int nlive = compact_tiles(sbits[g], ntile, slist[g]);
   const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
   const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
   const bool fits = nlive <= nt_lds;                              // workgroup-uniform (every wave computed the same list)
@@ -332,6 +337,11 @@ __global__ __launch_bounds__(256, 2) void qwen_flash_fwd_fat_kernel(const bf16_t
     __syncthreads();
   }
   if (g >= G) return;
+  if (per_block) {
+    if (fits) fwd_block<true>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb_only, sbits[g], slist[g], nlive, fat_smem, otile);
+    else fwd_block_global(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb_only, sbits[g], slist[g], nlive, otile);
+    return;
+  }
   if (!fits) {
     for (int qb = nqb - 1; qb >= 0; --qb)
       fwd_block_global(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], tiles_upto(slist[g], nlive, qb), otile);
@@ -482,17 +492,20 @@ __global__ __launch_bounds__(256, 2) void qwen_flash_bwd_dq_fat_kernel(const bf1
                                                                       const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
                                                                       const float* __restrict__ LSE, float* __restrict__ Delta,
                                                                       bf16_t* __restrict__ dQ, int L, int Hq, int Hkv, long ldo,
-                                                                      long lddo, float scale, int nt_lds) {
+                                                                      long lddo, float scale, int nt_lds, int per_block) {
   extern __shared__ __attribute__((aligned(16))) char fat_smem[];
   __shared__ unsigned sbits[4][FAT_TILES];
   __shared__ unsigned slist[4][FAT_TILES];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int gu = __builtin_amdgcn_readfirstlane(g);
   const int nqb = (L + 31) / 32;
-  const int hk = blockIdx.x % Hkv, b = blockIdx.x / Hkv;
+  const int nbh = per_block ? (int)gridDim.x / nqb : (int)gridDim.x;
+  const int qb_only = per_block ? nqb - 1 - (int)(blockIdx.x / nbh) : -1;
+  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
   const int G = Hq / Hkv, hq = hk * G + g;
-  key_bits_all(keymask + (long)b * L, nqb, L, sbits[g]);
-  const int nlive = compact_tiles(sbits[g], nqb, slist[g]);
+  const int ntile = per_block ? qb_only + 1 : nqb;
+  key_bits_all(keymask + (long)b * L, ntile, L, sbits[g]);
+  const int nlive = compact_tiles(sbits[g], ntile, slist[g]);
   const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
   const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
   const bool fits = nlive <= nt_lds;
@@ -508,6 +521,11 @@ __global__ __launch_bounds__(256, 2) void qwen_flash_bwd_dq_fat_kernel(const bf1
     __syncthreads();
   }
   if (g >= G) return;
+  if (per_block) {
+    if (fits) dq_block<true>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb_only, sbits[g], slist[g], nlive, fat_smem, otile);
+    else dq_block_global(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb_only, sbits[g], slist[g], nlive, otile);
+    return;
+  }
   for (int qb = nqb - 1; qb >= 0; --qb) {
     const int nlist = tiles_upto(slist[g], nlive, qb);
     if (fits) dq_block<true>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, fat_smem, otile);
@@ -841,6 +859,7 @@ extern "C" int vq3_qwen_flash_fwd(const void* Q, const void* K, const void* V, c
   return 0;
 }
 
+static int g_fat_per_block = 0;
 // LDS bytes of the fat kernels for a caller-supplied bound (0: the bound does not allow them)
 static int fat_slots(int L, int max_live_tiles) {
   const int nqb = (L + 31) / 32;
@@ -851,9 +870,10 @@ static int fat_slots(int L, int max_live_tiles) {
     fat_on = e ? atoi(e) : 1;
     const char* m = getenv("VQ3_QWEN_FAT_MAX");
     if (m) fat_max = atoi(m);
-    if (fat_max > FAT_TILES) fat_max = FAT_TILES;
+    if (fat_max > FAT_TILES - 1) fat_max = FAT_TILES - 1;        // 7 slots + 4 output tiles = 144 KiB (+ the key-bit words) of 160
+    if (fat_max < 1) fat_max = 1;
     if (fat_on) {
-      const int bytes = FAT_TILES * 2 * 32 * 256 + 4 * 32 * 256;
+      const int bytes = fat_max * 2 * 32 * 256 + 4 * 32 * 256;
       if (hipFuncSetAttribute((const void*)qwen_flash_fwd_fat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
           hipFuncSetAttribute((const void*)qwen_flash_bwd_dq_fat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -862,6 +882,7 @@ static int fat_slots(int L, int max_live_tiles) {
     }
   }
   if (!fat_on) return 0;
+  g_fat_per_block = fat_on == 2 ? 1 : 0;
   const int nt = max_live_tiles < nqb ? max_live_tiles : nqb;
   return nt <= fat_max ? nt : 0;              // more slots than that: one workgroup per CU, the per-block kernels do better
 }
@@ -874,8 +895,9 @@ extern "C" int vq3_qwen_flash_fwd_b(const void* Q, const void* K, const void* V,
   VQ3_CHECK_ARG(Q && K && V && keymask && O && LSE, "qwen_flash_fwd: null pointer");
   if (flash_check("qwen_flash_fwd", B, L, Hq, Hkv, Dh)) return 1;
   VQ3_CHECK_ARG(ldo >= (long)Hq * D && ldo % 4 == 0, "qwen_flash_fwd: bad output row stride");
-  hipLaunchKernelGGL(qwen_flash_fwd_fat_kernel, dim3(B * Hkv), dim3(256), nt * 2 * 32 * 256 + 4 * 32 * 256, (hipStream_t)stream, (const bf16_t*)Q,
-                     (const bf16_t*)K, (const bf16_t*)V, (const uint8_t*)keymask, (bf16_t*)O, LSE, L, Hq, Hkv, (long)ldo, scale, nt);
+  hipLaunchKernelGGL(qwen_flash_fwd_fat_kernel, dim3(B * Hkv * (g_fat_per_block ? (L + 31) / 32 : 1)), dim3(256), nt * 2 * 32 * 256 + 4 * 32 * 256,
+                     (hipStream_t)stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const uint8_t*)keymask, (bf16_t*)O, LSE, L, Hq, Hkv,
+                     (long)ldo, scale, nt, g_fat_per_block);
   VQ3_CHECK_LAUNCH("qwen_flash_fwd(fat)");
   return 0;
 }
@@ -894,9 +916,9 @@ extern "C" int vq3_qwen_flash_bwd_b(const void* Q, const void* K, const void* V,
   VQ3_CHECK_ARG(ldo >= (long)Hq * D && lddo >= (long)Hq * D && ldo % 8 == 0 && lddo % 8 == 0, "qwen_flash_bwd: bad row strides");
   VQ3_CHECK_ARG(kv_parts >= 1 && kv_parts <= 4, "qwen_flash_bwd: kv_parts must be 1..4");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(qwen_flash_bwd_dq_fat_kernel, dim3(B * Hkv), dim3(256), nt * 2 * 32 * 256 + 4 * 32 * 256, s, (const bf16_t*)Q, (const bf16_t*)K,
-                     (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)O, (const bf16_t*)dO, LSE, Delta, (bf16_t*)dQ, L,
-                     Hq, Hkv, (long)ldo, (long)lddo, scale, nt);
+  hipLaunchKernelGGL(qwen_flash_bwd_dq_fat_kernel, dim3(B * Hkv * (g_fat_per_block ? (L + 31) / 32 : 1)), dim3(256), nt * 2 * 32 * 256 + 4 * 32 * 256, s,
+                     (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)O, (const bf16_t*)dO, LSE, Delta,
+                     (bf16_t*)dQ, L, Hq, Hkv, (long)ldo, (long)lddo, scale, nt, g_fat_per_block);
   const int rc = launch_dkv(Q, K, V, keymask, dO, LSE, Delta, dK, dV, kv_parts, B, L, Hq, Hkv, (long)lddo, scale, s);
   if (rc) return rc;
   VQ3_CHECK_LAUNCH("qwen_flash_bwd(fat dQ)");
