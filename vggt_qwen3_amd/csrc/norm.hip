@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 // registers (one HBM read); the four waves' dw contributions meet in LDS and leave as ONE plain-store row of the
 // partial slab dw_part[blockIdx][cols] - no global atomics (300 blocks hammering one 10-KB row ran ~14x below the
 // atomic rate); vq3_colsum_f32_to_bf16 sums the slab straight into the bf16 gradient.
-template <int NCH>  // cols <= NCH * 512
+template <int NCH, int RB>  // cols <= NCH * 512; RB = rows per workgroup as a compile-time constant (0: the run-time argument)
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* dres, bf16_t* dx, float* __restrict__ dw,
@@ -65,8 +65,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     for (int j = 0; j < 8; ++j) dwacc[ch][j] = 0.f;
     if (c < cols) wv[ch] = *reinterpret_cast<const bf16x8*>(w + c);
   }
-  for (int rr = 0; rr < rb_rows / 4; ++rr) {          // rb_rows rows per workgroup (= per partial dw row), one row per wave and pass
-    const long row = (long)blockIdx.x * rb_rows + rr * 4 + wid;
+  const int nrb = RB > 0 ? RB : rb_rows;              // (4, the default, as a constant: one pass, every load of the row at the top - as a
+                                                      // run-time trip count the same kernel measured 73 us against 51)
+  for (int rr = 0; rr < nrb / 4; ++rr) {              // nrb rows per workgroup (= per partial dw row), one row per wave and pass
+    const long row = (long)blockIdx.x * nrb + rr * 4 + wid;
     if (row >= rows) break;
     const float rs = rstd[row];
     const bf16_t* xr = x + row * (long)cols;
@@ -486,9 +488,16 @@ static int rmsnorm_bwd_impl(const void* dy, const void* x, const void* w, const 
   VQ3_CHECK_ARG(rows_per_part >= 4 && rows_per_part <= 256 && rows_per_part % 4 == 0, "rmsnorm_bwd: rows_per_part=%d must be a multiple of 4 in 4..256", rows_per_part);
   const long nblk = (rows + rows_per_part - 1) / rows_per_part;
 #define VQ3_RB_LAUNCH(NCH)                                                                                           \
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel<NCH>, dim3((unsigned)nblk), dim3(256), 4 * cols * sizeof(float),              \
-                     (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd,               \
-                     (const bf16_t*)dres, (bf16_t*)dx, dw_f32, (long)rows, cols, (int)rows_per_part)
+  do {                                                                                                              \
+    if (rows_per_part == 4)                                                                                         \
+      hipLaunchKernelGGL((rmsnorm_bwd_kernel<NCH, 4>), dim3((unsigned)nblk), dim3(256), 4 * cols * sizeof(float),     \
+                         (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd,           \
+                         (const bf16_t*)dres, (bf16_t*)dx, dw_f32, (long)rows, cols, 4);                            \
+    else                                                                                                            \
+      hipLaunchKernelGGL((rmsnorm_bwd_kernel<NCH, 0>), dim3((unsigned)nblk), dim3(256), 4 * cols * sizeof(float),     \
+                         (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd,           \
+                         (const bf16_t*)dres, (bf16_t*)dx, dw_f32, (long)rows, cols, (int)rows_per_part);           \
+  } while (0)
   if (cols <= 512) VQ3_RB_LAUNCH(1);
   else if (cols <= 1024) VQ3_RB_LAUNCH(2);
   else if (cols <= 2560) VQ3_RB_LAUNCH(5);
