@@ -694,6 +694,15 @@ inline void choose_tile_order(GemmParams& p, int BM, int BN, int wg_per_cu) {
   if (env_band == -2) { const char* e = getenv("VQ3_GEMM_BAND"); env_band = e ? atoi(e) : -1; }
   if (env_xm == -2) { const char* e = getenv("VQ3_GEMM_XM"); env_xm = e ? atoi(e) : -1; }
   if (env_band == 0) { p.xm = choose_xm(p.mtiles, p.ntiles); p.nbw = 1; return; }
+  if (env_band < 0 && env_xm < 0 && p.mtiles >= 64 && p.mtiles >= 6 * p.ntiles) {
+    // Tall outputs (the tower at 49 392+ rows x 1024 .. 4096 columns): measured (tools/sweep_tile_order.sh, 4 XCD splits x 5 band widths) the
+    // best walk gives every XCD its own strip of M - the activation panels, 100+ MB, cross the fabric once; the weight panels, 2-8 MB and
+    // resident in the Infinity Cache, are what gets re-read - in bands of 2 n-tiles when N is wide: q|k|v 425 -> 412 us, fc1 519 -> 509 us
+    // against the byte-count model below, which weighs A and B bytes alike and splits N across XCDs for these shapes
+    p.xm = 8;
+    p.nbw = p.ntiles >= 8 ? 2 : p.ntiles;
+    return;
+  }
   const int conc = 32 * (wg_per_cu < 1 ? 1 : wg_per_cu);
   double best = 1e300;
   int bxm = 1, bnb = 1;
