@@ -264,6 +264,16 @@ int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, int
 int vq3_flash_attn_fwd_rows(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N,
                             int32_t q_rows, int32_t head_dim, int64_t ldo, float scale, void* stream);
 
+/* Fused cross-attention of a PerceiverLayer (src/models/projector_perceiver.py:33,44: nn.MultiheadAttention(latents, context,
+ * context) with attention-weight dropout): O[b N + n, h D + :] = dropout(softmax_t(alpha q[b,n,h] . k[b,t,h])) . v[b,t,h], one launch.
+ * q bf16 [B*N, ldq] (head h at columns h*D), kv bf16 [B*T, ldkv] (K at columns h*D, V at v_off + h*D), o bf16 [B*N, ldo].
+ * head_dim D in {64, 128, 256, 512}. P / Pd (bf16 [B*H, N, Tp], either may be NULL): the softmax and its dropped-out copy as
+ * vq3_softmax_fwd + vq3_dropout would have left them (pad columns zero), for callers that run a backward pass. The dropout decision
+ * for P[b, h, n, t] is vq3_dropout's for element ((b H + h) N + n) Tp + t at (seed, offset) whether or not P is kept. p_drop = 0: none. */
+int vq3_perceiver_xattn_fwd(const void* q, const void* kv, void* o, void* P, void* Pd, int32_t B, int32_t H, int32_t N, int32_t T,
+                            int32_t head_dim, int64_t ldq, int64_t ldkv, int64_t ldo, int64_t v_off, int32_t Tp, float alpha,
+                            float p_drop, uint64_t seed, uint64_t offset, void* stream);
+
 /* Inverted dropout in place (the four nn.Dropout sites of a PerceiverLayer, src/models/projector_perceiver.py:33,37,42,46-49,
  * which stay ACTIVE under `model.train()` although encode_images runs under no_grad): element i is zeroed with probability p,
  * else scaled by 1/(1-p); the decision is a counter-based hash of (seed, offset + i). x is bf16, or f32 when is_f32. */

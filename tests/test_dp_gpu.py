@@ -175,3 +175,29 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     c = d["comm"]
     assert c and c["allreduce_ms_per_opt_step"] > 0 and c["allreduce_bytes_per_opt_step"] > 0 and c["bus_gb_per_s"] > 0
     assert d["accum1_variant"]["comm"]["collectives_per_opt_step"] >= 2 and d["text_group_1_variant"]["value"] > 0
+
+
+def test_bench_one_rank_over_rccl():
+    """The same bench.py path over the backend the driver's multi-GPU launch uses: VQ3_FORCE_DIST=1 makes a single rank create an
+    RCCL communicator (`init_process_group("nccl", device_id=...)`), issue every gradient all-reduce on the communication stream with
+    HIP events around it, and take the barriers / MAX reductions of the timing contract through RCCL. One rank moves no data between
+    GPUs, so this checks plumbing (stream ordering, event timing, matched collectives, clean shutdown), not bandwidth."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, VQ3_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1", RANK="0",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VQ3_DIST_BACKEND", None)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--layers", "2",
+           "--no-trim-variant", "--no-cpu-baseline"]
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(root), text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    c = d["comm"]
+    assert c and c["allreduce_ms_per_opt_step"] > 0 and c["allreduce_bytes_per_opt_step"] > 0 and c["collectives_per_opt_step"] >= 2
+    assert d["accum1_variant"]["comm"]["collectives_per_opt_step"] >= 2

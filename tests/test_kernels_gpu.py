@@ -745,3 +745,80 @@ def test_gemm_tune_file_makes_the_choice_repeatable(tmp_path):
     assert second.returncode == 0 and "ok True" in second.stdout, second.stderr[-2000:]
     assert "[vq3 gemm autotune]" not in second.stderr                      # nothing was measured: the table came from the file
     assert tune.read_text().count("512 768 1024 1 ") == 1
+
+
+# ------------------------------------------------------------------------------------------ fused Perceiver cross-attention
+def _xattn_ref(q, kv, B, H, N, T, hd):
+    """fp32 torch: softmax(q k^T / sqrt(hd)) and its product with v, per (sample, head)."""
+    D = H * hd
+    qf = q.float().view(B, N, H, hd).permute(0, 2, 1, 3)
+    kf = kv.float()[:, :D].reshape(B, T, H, hd).permute(0, 2, 1, 3)
+    vf = kv.float()[:, D:].reshape(B, T, H, hd).permute(0, 2, 1, 3)
+    P = torch.softmax(qf @ kf.transpose(-1, -2) * hd ** -0.5, dim=-1)            # [B, H, N, T]
+    return P, vf
+
+
+@pytest.mark.parametrize("B,H,N,T,hd", [(2, 2, 16, 70, 64), (3, 8, 128, 128, 512), (2, 3, 100, 200, 128), (1, 2, 64, 33, 256),
+                                       (2, 1, 130, 1, 64), (1, 4, 8, 257, 128)])
+def test_perceiver_xattn_fused_vs_torch(ops, B, H, N, T, hd):
+    """vq3_perceiver_xattn_fwd against fp32 torch (projector_perceiver.py:44: MultiheadAttention(latents, context, context)):
+    ragged latent blocks (N not a multiple of 64), context lengths that are not multiples of the 32-key chunk (masked tail,
+    zero-filled V rows), a single key, every instantiated head size; the kept P has zero pad columns."""
+    D = H * hd
+    q, kv = _rand((B * N, D), 1.5, seed=1), _rand((B * T, 2 * D), 1.0, seed=2)
+    Tp = (T + 63) // 64 * 64
+    o, P, Pd = ops.perceiver_xattn(q, kv, B, H, N, T, hd, Tp, keep_p=True)
+    assert Pd is P
+    Pr, vf = _xattn_ref(q, kv, B, H, N, T, hd)
+    assert _maxerr(P.view(B, H, N, Tp)[..., :T], Pr) < 4e-3          # bf16 rounding of probabilities <= 1
+    assert P.view(B, H, N, Tp)[..., T:].abs().max().item() == 0 if Tp > T else True
+    oref = (Pr @ vf).permute(0, 2, 1, 3).reshape(B * N, D)
+    assert _relerr(o, oref) < 1e-2
+    o2 = ops.perceiver_xattn(q, kv, B, H, N, T, hd, Tp)               # without the kept P: the same product
+    assert torch.equal(o2, o)
+
+
+@pytest.mark.parametrize("B,H,N,T,hd", [(2, 2, 48, 70, 64), (2, 8, 128, 128, 512)])
+def test_perceiver_xattn_fused_dropout_is_vq3_dropouts_mask(ops, B, H, N, T, hd):
+    """Attention-weight dropout inside the fused kernel: Pd must be BIT-identical to vq3_dropout applied to the kept P with the same
+    (seed, offset) - the mask is indexed by the element's position in the [B*H, N, Tp] tensor - and O must be Pd . V."""
+    D = H * hd
+    q, kv = _rand((B * N, D), 1.5, seed=3), _rand((B * T, 2 * D), 1.0, seed=4)
+    Tp = (T + 63) // 64 * 64
+    seed, off, p = 0x1234567, 991, 0.25
+    o, P, Pd = ops.perceiver_xattn(q, kv, B, H, N, T, hd, Tp, p, seed, off, keep_p=True)
+    want = ops.dropout_(P.clone(), p, seed, off)
+    assert torch.equal(Pd, want)
+    frac = (Pd.view(B, H, N, Tp)[..., :T] == 0).float().mean().item()
+    assert abs(frac - p) < 0.03
+    vf = kv.float()[:, D:].reshape(B, T, H, hd).permute(0, 2, 1, 3)
+    oref = (Pd.float().view(B, H, N, Tp)[..., :T] @ vf).permute(0, 2, 1, 3).reshape(B * N, D)
+    assert _relerr(o, oref) < 4e-3                                   # same bf16 weights, f32 accumulation: only O's rounding differs
+    o2 = ops.perceiver_xattn(q, kv, B, H, N, T, hd, Tp, p, seed, off)
+    assert torch.equal(o2, o)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_perceiver_projector_fused_route_equals_three_launch_route(ops, train, monkeypatch):
+    """PerceiverProjector.forward with the fused cross-attention against the batched GEMM / softmax / batched GEMM route it replaces
+    (VQ3_PERCEIVER_FUSED=0), eval and train mode (the four dropout sites draw the same masks in both routes)."""
+    from vggt_qwen3_amd.perceiver import PerceiverConfig, PerceiverProjector
+    torch.manual_seed(0)
+    cfg = PerceiverConfig(latent_dim=512, num_latents=40, num_heads=4, num_layers=2, ffn_dim=1024, dropout=0.1)
+    m = PerceiverProjector(cfg, in_dim=192, out_dim=256).cuda()
+    m.train(train)
+    x = _rand((3, 72, 192), 1.0, F32, seed=5)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VQ3_PERCEIVER_FUSED", flag)
+        m._drop_offset = 0
+        outs.append(m(x).clone())
+    assert outs[0].shape == (3, 40, 256)
+    assert _relerr(outs[0], outs[1]) < 5e-3
+
+
+def test_perceiver_xattn_rejects_bad_args(ops):
+    from vggt_qwen3_amd import _lib
+    q, kv = _rand((16, 96), seed=1), _rand((16, 192), seed=2)
+    with pytest.raises((_lib.Vq3Error, AssertionError)):
+        ops.perceiver_xattn(q, kv, 1, 1, 16, 16, 96, 64)             # head size without an instantiation

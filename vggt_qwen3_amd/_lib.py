@@ -88,6 +88,8 @@ SIGNATURES = {
     "vq3_adamw_step": [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p, f32, c_p],
     "vq3_sumsq": [c_p, i32, i64, c_p, c_p, c_p],
     "vq3_dropout": [c_p, i32, i64, f32, C.c_uint64, C.c_uint64, c_p],
+    "vq3_perceiver_xattn_fwd": [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i64, i64, i64, i64, i32, f32, f32,
+                                C.c_uint64, C.c_uint64, c_p],
     "vq3_resample_ksize": [i32, i32],
     "vq3_resample_plan": [i32, i32, c_p, c_p],
     "vq3_resize_crop_u8": [c_p, i32, c_p, c_p, c_p, i32, i32, i32, c_p],

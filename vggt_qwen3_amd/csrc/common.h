@@ -93,6 +93,15 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2_t{x, x})[0]; }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 
+// Counter-based dropout decision (vq3_dropout, the fused Perceiver cross-attention): 24 uniform bits from (seed, element index);
+// an element is kept when they are >= (unsigned)(p * 2^24). Stateless, so a re-run with the same (seed, offset) repeats the mask.
+__device__ __forceinline__ unsigned drop_bits(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned)((z ^ (z >> 31)) >> 40);      // 24 uniform bits
+}
+
 // ---- host side error plumbing (C ABI returns int, message kept per thread) ----
 #ifdef __cplusplus
 extern "C" const char* vq3_last_error(void);

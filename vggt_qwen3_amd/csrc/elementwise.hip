@@ -429,12 +429,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
 
 // inverted dropout in place: element i is kept with probability 1 - p (and scaled by 1 / (1 - p)), decided by a counter-based
 // hash of (seed, offset + i) - stateless, so a graph replay or a re-run with the same (seed, offset) repeats the mask
-__device__ __forceinline__ unsigned drop_bits(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return (unsigned)((z ^ (z >> 31)) >> 40);      // 24 uniform bits
-}
+// (drop_bits: common.h - the fused Perceiver cross-attention regenerates the same mask)
 template <bool F32IO>
 __global__ __launch_bounds__(256) void dropout_kernel(void* __restrict__ xv, long n, unsigned thresh, float scale,
                                                       unsigned long long seed, unsigned long long offset) {

@@ -442,6 +442,27 @@ def adamw_step(master, m, v, grad, w, lr, beta1, beta2, eps, wd, step, gscale=1.
                                      lr, beta1, beta2, eps, wd, step, gscale, _p(sq), mx, _stream()), "vq3_adamw_step")
 
 
+def perceiver_xattn(q: torch.Tensor, kv: torch.Tensor, B: int, H: int, N: int, T: int, hd: int, Tp: int, p_drop: float = 0.0,
+                    seed: int = 0, offset: int = 0, keep_p: bool = False):
+    """Fused Perceiver cross-attention (projector_perceiver.py:33,44): q bf16 [B*N, H*hd], kv bf16 [B*T, 2*H*hd] (k | v) ->
+    o bf16 [B*N, H*hd]; with keep_p also (P, Pd) bf16 [B*H, N, Tp] as softmax_fwd + dropout_ would have left them (Pd is P when
+    p_drop == 0). The dropout mask is the one dropout_(P, p_drop, seed, offset) applies to the [B*H, N, Tp] tensor."""
+    _req(q, BF16, "perceiver_xattn q"); _req(kv, BF16, "perceiver_xattn kv")
+    D = H * hd
+    assert q.is_contiguous() and kv.is_contiguous() and q.shape == (B * N, D) and kv.shape == (B * T, 2 * D)
+    o = torch.empty((B * N, D), device=q.device, dtype=BF16)
+    P = Pd = None
+    if keep_p:
+        P = torch.empty((B * H, N, Tp), device=q.device, dtype=BF16)
+        Pd = torch.empty_like(P) if p_drop > 0.0 else None
+    check(_lib.load().vq3_perceiver_xattn_fwd(q.data_ptr(), kv.data_ptr(), o.data_ptr(), _p(P), _p(Pd), B, H, N, T, hd, D, 2 * D, D, D, Tp,
+                                              float(hd) ** -0.5, float(p_drop), seed & (2 ** 64 - 1), offset & (2 ** 64 - 1), _stream()),
+          "vq3_perceiver_xattn_fwd")
+    if keep_p:
+        return o, P, (Pd if Pd is not None else P)
+    return o
+
+
 def dropout_(x: torch.Tensor, p: float, seed: int, offset: int) -> torch.Tensor:
     """In-place inverted dropout (bf16 or f32), mask = hash(seed, offset + element index)."""
     assert x.is_contiguous() and x.is_cuda and x.dtype in (BF16, F32)

@@ -13,6 +13,7 @@ counter-based mask (statistically, not bitwise, torch's). `.eval()` (the inferen
 while the residual / LayerNorm stream stays fp32."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -30,6 +31,12 @@ class PerceiverConfig:
     num_layers: int = 6
     ffn_dim: int = 16384
     dropout: float = 0.1
+
+
+def _fused_xattn(hd: int) -> bool:
+    """One-launch cross-attention (csrc/perceiver_attn.hip) for the head sizes it is instantiated for; VQ3_PERCEIVER_FUSED=0 keeps the
+    batched-GEMM / softmax / batched-GEMM route (the A/B switch of tests/test_kernels_gpu.py::test_perceiver_xattn_*)."""
+    return hd in (64, 128, 256, 512) and os.environ.get("VQ3_PERCEIVER_FUSED", "1") != "0"
 
 
 def _xavier_(w: torch.Tensor) -> None:
@@ -121,6 +128,30 @@ class PerceiverProjector(nn.Module):
         return super().load_state_dict(*a, **k)
 
     # ------------------------------------------------------------------
+    def _xattn_three_launches(self, q, kv, B, T, Tp, drop):
+        """The cross-attention as batched GEMM -> softmax (+ dropout) -> batched GEMM with the f32 scores in HBM: what the fused
+        kernel replaces (kept as its A/B partner, VQ3_PERCEIVER_FUSED=0, and for head sizes it is not instantiated for)."""
+        cfg = self.cfg
+        D, N, Hh = cfg.latent_dim, cfg.num_latents, cfg.num_heads
+        hd, dev = D // Hh, q.device
+        S = torch.empty((B * Hh, N, Tp), device=dev, dtype=F32)
+        ops.gemm_raw(q, kv, S, N, T, hd, D, 2 * D, Tp, nb1=B, nb2=Hh, sA=(N * D, hd), sB=(T * 2 * D, hd),
+                     sC=(Hh * N * Tp, N * Tp), alpha=hd ** -0.5)
+        P = drop(ops.softmax_fwd(S, None, 1, T, Tp, False))                      # MHA's attention-weight dropout
+        o = torch.empty((B * N, D), device=dev, dtype=BF16)
+        if T % 8 == 0:
+            # O[b,h] = P[b,h] . V[b,h]: V (columns D + h*hd .. of kv) is read in place as the k-major B operand
+            ops.gemm_raw(P, kv, o, N, hd, T, Tp, 2 * D, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp),
+                         sB=(T * 2 * D, hd), sC=(N * D, hd), b_off=D, transB=True)
+        else:
+            Vt = torch.empty((B, Hh, hd, Tp), device=dev, dtype=BF16)
+            ops.transpose_raw(kv, Vt, T, hd, Tp, 2 * D, Tp, n=(1, B, Hh), s=(0, T * 2 * D, hd),
+                              d=(0, Hh * hd * Tp, hd * Tp), src_off=D)
+            ops.gemm_raw(P, Vt, o, N, hd, Tp, Tp, Tp, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp),
+                         sB=(Hh * hd * Tp, hd * Tp), sC=(N * D, hd))
+        return o
+
+    # ------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, tokens: torch.Tensor) -> torch.Tensor:
         """tokens [B, T, in_dim] (any float dtype) -> [B, num_latents, out_dim] fp32."""
@@ -139,6 +170,7 @@ class PerceiverProjector(nn.Module):
                 ops.dropout_(t, pdrop, self._drop_seed, self._drop_offset)
                 self._drop_offset += t.numel()
             return t
+        fused = _fused_xattn(hd)
         kin = cc["in"].shape[1]
         x = torch.zeros((B * T, kin), device=dev, dtype=BF16)
         x[:, :Cin] = tokens.reshape(B * T, Cin).to(BF16)
@@ -150,21 +182,14 @@ class PerceiverProjector(nn.Module):
             bq, bkv = l.self_attn.in_proj_bias[:D], l.self_attn.in_proj_bias[D:]
             q = ops.linear(lat16, w["q"], bias=bq.contiguous())                      # [B*N, D]
             kv = ops.linear(ctx, w["kv"], bias=bkv.contiguous())                     # [B*T, 2D] = k | v
-            S = torch.empty((B * Hh, N, Tp), device=dev, dtype=F32)
-            ops.gemm_raw(q, kv, S, N, T, hd, D, 2 * D, Tp, nb1=B, nb2=Hh, sA=(N * D, hd), sB=(T * 2 * D, hd),
-                         sC=(Hh * N * Tp, N * Tp), alpha=hd ** -0.5)
-            P = drop(ops.softmax_fwd(S, None, 1, T, Tp, False))                      # MHA's attention-weight dropout
-            o = torch.empty((B * N, D), device=dev, dtype=BF16)
-            if T % 8 == 0:
-                # O[b,h] = P[b,h] . V[b,h]: V (columns D + h*hd .. of kv) is read in place as the k-major B operand
-                ops.gemm_raw(P, kv, o, N, hd, T, Tp, 2 * D, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp),
-                             sB=(T * 2 * D, hd), sC=(N * D, hd), b_off=D, transB=True)
+            if fused:
+                # QK^T, softmax, MHA's attention-weight dropout and PV in one launch per layer (csrc/perceiver_attn.hip); the mask
+                # is the one dropout_ would apply to the [B*H, N, Tp] softmax tensor, and the offset advances as if it had
+                o = ops.perceiver_xattn(q, kv, B, Hh, N, T, hd, Tp, pdrop, self._drop_seed, self._drop_offset)
+                if pdrop > 0.0:
+                    self._drop_offset += B * Hh * N * Tp
             else:
-                Vt = torch.empty((B, Hh, hd, Tp), device=dev, dtype=BF16)
-                ops.transpose_raw(kv, Vt, T, hd, Tp, 2 * D, Tp, n=(1, B, Hh), s=(0, T * 2 * D, hd),
-                                  d=(0, Hh * hd * Tp, hd * Tp), src_off=D)
-                ops.gemm_raw(P, Vt, o, N, hd, Tp, Tp, Tp, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp),
-                             sB=(Hh * hd * Tp, hd * Tp), sC=(N * D, hd))
+                o = self._xattn_three_launches(q, kv, B, T, Tp, drop)
             if pdrop > 0.0:
                 # x = LN1(x + drop(attn)) ; x = LN2(x + drop(W2 drop(gelu(W1 x)))): the residual add moves out of the GEMM
                 # epilogue into the LayerNorm kernel so that the dropout sits between them
@@ -248,15 +273,21 @@ def perceiver_forward_train(self: "PerceiverProjector", tokens: torch.Tensor):
         sv = {"lat32_in": lat32, "lat16_in": lat16}
         q = ops.linear(lat16, w["q"], bias=l.self_attn.in_proj_bias[:D].contiguous())
         kv = ops.linear(ctxt, w["kv"], bias=l.self_attn.in_proj_bias[D:].contiguous())
-        S = torch.empty((B * Hh, N, Tp), device=dev, dtype=F32)
-        ops.gemm_raw(q, kv, S, N, T, hd, D, 2 * D, Tp, nb1=B, nb2=Hh, sA=(N * D, hd), sB=(T * 2 * D, hd),
-                     sC=(Hh * N * Tp, N * Tp), alpha=hd ** -0.5)
-        P = ops.softmax_fwd(S, None, 1, T, Tp, False)
-        sv["P"] = P.clone() if pdrop > 0.0 else P
-        sv["off_P"] = drop(P)
-        o = torch.empty((B * N, D), device=dev, dtype=BF16)
-        ops.gemm_raw(P, kv, o, N, hd, T, Tp, 2 * D, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp), sB=(T * 2 * D, hd),
-                     sC=(N * D, hd), b_off=D, transB=True)
+        if _fused_xattn(hd):
+            sv["off_P"] = self._drop_offset
+            o, sv["P"], P = ops.perceiver_xattn(q, kv, B, Hh, N, T, hd, Tp, pdrop, self._drop_seed, self._drop_offset, keep_p=True)
+            if pdrop > 0.0:
+                self._drop_offset += B * Hh * N * Tp
+        else:
+            S = torch.empty((B * Hh, N, Tp), device=dev, dtype=F32)
+            ops.gemm_raw(q, kv, S, N, T, hd, D, 2 * D, Tp, nb1=B, nb2=Hh, sA=(N * D, hd), sB=(T * 2 * D, hd),
+                         sC=(Hh * N * Tp, N * Tp), alpha=hd ** -0.5)
+            P = ops.softmax_fwd(S, None, 1, T, Tp, False)
+            sv["P"] = P.clone() if pdrop > 0.0 else P
+            sv["off_P"] = drop(P)
+            o = torch.empty((B * N, D), device=dev, dtype=BF16)
+            ops.gemm_raw(P, kv, o, N, hd, T, Tp, 2 * D, D, nb1=B, nb2=Hh, sA=(Hh * N * Tp, N * Tp), sB=(T * 2 * D, hd),
+                         sC=(N * D, hd), b_off=D, transB=True)
         a = ops.linear(o, w["o"], bias=l.self_attn.out_proj.bias, out_dtype=F32)
         sv["off_a"] = drop(a)
         lat16_1, lat32_1 = ops.layernorm_fwd(a, l.norm1.weight, l.norm1.bias, 1e-5, res=lat32, want_bf16=True, want_f32=True)
