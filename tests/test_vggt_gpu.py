@@ -26,6 +26,30 @@ def test_flash_attention_vs_sdpa(G, NH, N):
     assert e < 1e-2, f"flash attention rel err {e}"
 
 
+@pytest.mark.parametrize("G,NH,N", [(32, 16, 1029), (32, 16, 272), (64, 8, 513), (32, 16, 779)])
+def test_flash_attention_ragged_tail_rows(G, NH, N):
+    """The 1 .. 16 query rows past the last full 256-row block (flash_tail_hd64_kernel: keys split over four waves, partial (max, sum, O)
+    merged through LDS) checked ON THEIR OWN against SDPA - in the whole-tensor error they are 5 rows of 1029 - with one dominant key per
+    wave's share of the key tiles for some of them (every wave's running maximum moves, and the merge weighs four different maxima), a
+    tail of 16 (272), of 1 (513) and of 11 (779: a last 32-key tile with 11 keys)."""
+    from vggt_qwen3_amd import ops
+    g = torch.Generator().manual_seed(N)
+    Q = torch.randn(G, NH, N, 64, generator=g)
+    K = torch.randn(G, NH, N, 64, generator=g)
+    V = torch.randn(G, NH, N, 64, generator=g)
+    t0 = N // 256 * 256
+    for j, f in ((3, 2.0), (40, 3.0), (70, 4.0), (100, 2.5), (N - 2, 3.5)):       # keys in tiles 0, 1, 2, 3 (waves 0-3) and the last tile
+        K[0, 0, j] = Q[0, 0, N - 1] * f
+        K[1, 3, j] = Q[1, 3, t0] * f
+    Q, K, V = Q.to(BF16).cuda(), K.to(BF16).cuda(), V.to(BF16).cuda()
+    out = ops.flash_attn(Q, K, V).view(G, N, NH, 64).transpose(1, 2)
+    ref = torch.nn.functional.scaled_dot_product_attention(Q[:, :, t0:].float(), K.float(), V.float())
+    assert relerr(out[:, :, t0:], ref) < 1e-2
+    assert (out[:, :, t0:].float() - ref).abs().max().item() < 0.05
+    refm = torch.nn.functional.scaled_dot_product_attention(Q[:, :, :t0].float(), K.float(), V.float())
+    assert relerr(out[:, :, :t0], refm) < 1e-2
+
+
 @pytest.mark.parametrize("G,NH,N,nq", [(2, 2, 138, 40), (3, 16, 1029, 128), (1, 4, 2058, 128), (2, 4, 1029, 600), (1, 2, 300, 300)])
 def test_flash_attention_leading_query_rows(G, NH, N, nq):
     """vq3_flash_attn_fwd_rows: the first nq queries of every group against all N keys -> [G * nq, NH * 64]."""
