@@ -715,7 +715,11 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
 // ---- the ragged last rows of a sequence (<= 16 queries past the last full 256-row block; N = 1029 = 5 special tokens + 1024 patches
 // leaves 5) - keys split over the four waves. As a fifth four-wave block those rows held a workgroup slot for a whole key loop, as a
 // one-wave workgroup (flash_attn_hd64_kernel<1, 64>) they walked 17 key tiles one dependent round trip after the other (81 us beside
-// a 289 us main launch at 48 x 16 pairs; tools/bench_flash.py: 384 us together against 330 us without the tail rows). Here wave w
+// a 289 us main launch at 48 x 16 pairs; tools/bench_flash.py: 384 us together against 330 us without the tail rows). Measured with
+// this kernel: 35 us on its own - what reading every pair's K and V once more costs (202 MB at 5.8 TB/s) - and 367-369 us for the pair
+// of launches whether it runs on the side stream or in front of the main launch on the caller's: the floor of ANY separate pass over
+// the tail rows is that second read of K / V; only rows computed inside the main kernel's workgroups (whose K / V tiles are in LDS)
+// would avoid it, and the main kernel has no registers for a third query block (249 of 256). Here wave w
 // takes the 32-key tiles w, w + 4, ... on its own: K fragments straight from global memory (a 16-key S^T tile's A operand is 16 whole
 // 128-byte rows), V through a wave-private LDS tile read back transposed (ds_read_b64_tr_b16), no workgroup barrier inside the loop,
 // the next tile's rows requested before this one is multiplied; textbook online softmax on 16-query tiles (v_mfma_f32_16x16x32_bf16,
@@ -942,13 +946,6 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
   if (tail_ksplit < 0) { const char* e = getenv("VQ3_FLASH_TAIL_KSPLIT"); tail_ksplit = e ? atoi(e) : 1; }
   // (measured: 48 x 16 pairs 409 -> 364 us; 6 x 16 pairs 51 -> 61 us - the one-wave launch is as long as the main one there)
   if (tail_split && q_rows == N && qb == 2 && tail > 0 && tail <= 32 && N > 256 && (long)G * NH >= (tail_split > 1 ? tail_split : 512)) {
-    static int tail_serial = -1;
-    if (tail_serial < 0) { const char* e = getenv("VQ3_FLASH_TAIL_SERIAL"); tail_serial = e ? atoi(e) : 0; }
-    if (tail_serial && tail <= 16 && tail_ksplit) {     // the tail launch in front of the main one on the caller's stream (no fork / join)
-      q_main = N - tail;
-      hipLaunchKernelGGL(flash_tail_hd64_kernel, dim3(G * NH), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, (const bf16_t*)K,
-                         (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N);
-    } else
     if (!side) {
       if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -956,7 +953,7 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
         side = nullptr;
       }
     }
-    if (side && q_main == q_rows) {
+    if (side) {
       q_main = N - tail;
       forked = true;
       (void)hipEventRecord(ev_fork, (hipStream_t)stream);
