@@ -14,7 +14,8 @@ def relerr(a, b):
 
 @pytest.mark.parametrize("G,NH,N", [(2, 2, 21), (1, 4, 64), (3, 2, 138), (2, 16, 1029), (1, 2, 2058), (36, 16, 1029), (40, 16, 541)])
 def test_flash_attention_vs_sdpa(G, NH, N):
-    """(36 x 16 and 40 x 16 pairs with N = 4 x 256 + 5 / 2 x 256 + 29: the ragged rows run as a one-wave launch on a side stream)"""
+    """(N = 4 x 256 + 5: the ragged rows run as one more workgroup per pair with the keys split over its waves; 40 x 16 pairs with
+    N = 2 x 256 + 29: as a one-wave launch on a side stream)"""
     from vggt_qwen3_amd import ops
     g = torch.Generator().manual_seed(N)
     Q = torch.randn(G, NH, N, 64, generator=g).to(BF16).cuda()
@@ -28,8 +29,8 @@ def test_flash_attention_vs_sdpa(G, NH, N):
 
 @pytest.mark.parametrize("G,NH,N", [(32, 16, 1029), (32, 16, 272), (64, 8, 513), (32, 16, 779)])
 def test_flash_attention_ragged_tail_rows(G, NH, N):
-    """The 1 .. 16 query rows past the last full 256-row block (flash_tail_hd64_kernel: keys split over four waves, partial (max, sum, O)
-    merged through LDS) checked ON THEIR OWN against SDPA - in the whole-tensor error they are 5 rows of 1029 - with one dominant key per
+    """The 1 .. 16 query rows past the last full 256-row block (flash_tail_body: one more workgroup per pair, keys split over its four
+    waves, partial (max, sum, O) merged through LDS) checked ON THEIR OWN against SDPA - in the whole-tensor error they are 5 rows of 1029 - with one dominant key per
     wave's share of the key tiles for some of them (every wave's running maximum moves, and the merge weighs four different maxima), a
     tail of 16 (272), of 1 (513) and of 11 (779: a last 32-key tile with 11 keys)."""
     from vggt_qwen3_amd import ops

@@ -220,6 +220,181 @@ constexpr float FA_THR = 6.0f;
 __device__ __forceinline__ int fa_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int fa_vswz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
 
+// ---- the ragged last rows of a sequence (<= 16 queries past the last full 256-row block; N = 1029 = 5 special tokens + 1024 patches
+// leaves 5) - keys split over the four waves. As a fifth four-wave block those rows held a workgroup slot for a whole key loop, as a
+// one-wave workgroup (flash_attn_hd64_kernel<1, 64>) they walked 17 key tiles one dependent round trip after the other (81 us beside
+// a 289 us main launch at 48 x 16 pairs; tools/bench_flash.py: 384 us together against 330-340 us without the tail rows). As a launch
+// of its own this body takes 35 us - what reading every pair's K and V once more costs (202 MB at 5.8 TB/s) - so it runs as ONE MORE
+// workgroup per pair of the main launch (flash_attn_hd64_kernel, tail_begin), dispatched behind the pair's exact blocks while their
+// K / V rows are in L2. tools/bench_flash_tail.py (40 launches each behind a 320 MB flush, three alternating rounds, median / best us):
+// in-launch workgroup 326-341 / 307, side-stream launch 335-341 / 313-319, fifth four-wave block 340-342 / 320-323. The main kernel has
+// no registers for a third query block of its own (252 of 256), which is what would remove the second pass over K / V. Here wave w
+// takes the 32-key tiles w, w + 4, ... on its own: K fragments straight from global memory (a 16-key S^T tile's A operand is 16 whole
+// 128-byte rows), V through a wave-private LDS tile read back transposed (ds_read_b64_tr_b16), no workgroup barrier inside the loop,
+// the next tile's rows requested before this one is multiplied; textbook online softmax on 16-query tiles (v_mfma_f32_16x16x32_bf16,
+// query on the lane as in the main kernel: S^T = K . Q'^T, O^T += V^T . P^T), and one merge of the four (max, sum, O^T) partials
+// through LDS at the end. Q' = bf16(Q * scale * log2 e) and exp2 as in the main kernel.
+constexpr int FT_TK = 32;                 // keys per step and wave
+constexpr int FT_VP = 128 + 32;           // V row pitch in LDS (bytes): the 4 rows x 32 B of a transposed read fall into different banks
+constexpr int FT_STAGE = FT_TK * FT_VP;   // 5 KiB per wave: ONE stage - a tile's rows are written after the previous tile's transposed reads were
+                                          // issued, and a wave's LDS operations complete in the order they were issued
+typedef short ft_s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FT_SMEM = 4 * FT_STAGE > 4 * 4 * 64 * 16 + 512 ? 4 * FT_STAGE : 4 * 4 * 64 * 16 + 512;      // staging, then the merge area (16.5 KiB)
+__device__ __forceinline__ void flash_tail_body(char* smem, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int N, int NH, long ldo,
+                                                float scale_log2e, int q_begin, int o_rows, long nb) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const bf16_t* Qb = Q + nb * (long)N * 64;
+  const bf16_t* Kb = K + nb * (long)N * 64;
+  const bf16_t* Vb = V + nb * (long)N * 64;
+  const int nq = N - q_begin;                                   // 1 .. 16 valid query rows
+  // Q' fragments (B operand): lane (fr, g) holds Q'[q_begin + fr][32 s + 8 g .. + 8]
+  bf16x8 qf[2];
+  {
+    const int qr = q_begin + (fr < nq ? fr : nq - 1);
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const bf16x8 raw = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 32 * sidx + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[sidx][j] = (short)f2bf(bf2f((bf16_t)raw[j]) * scale_log2e);
+    }
+  }
+  char* const mine = smem + wid * FT_STAGE;
+  const int nt = (N + FT_TK - 1) / FT_TK;
+  // staging of this wave's V tile: 32 rows x 8 chunks of 16 B = 4 per lane (row = lane / 8 + 8 i, chunk = lane % 8);
+  // K fragments: [tile half][k step]: lane (fr, g) holds K[32 t + 16 half + fr][32 s + 8 g .. + 8]. Rows past N: zeros.
+  // A wave's tiles are one dependent chain (load -> scores -> max -> P -> P.V), and with one tile requested ahead every step waited out
+  // most of a memory round trip (9 tiles in ~25 us): THREE tiles are in flight, in a ring of register slots (unrolled by 3).
+  constexpr int FT_DEPTH = 3;
+  u32x4 vreg[FT_DEPTH][4];
+  bf16x8 kf[FT_DEPTH][2][2];
+  auto load_tile = [&](int t, u32x4 (&vr)[4], bf16x8 (&kr)[2][2]) {
+    const int k0 = t * FT_TK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = k0 + (lane >> 3) + 8 * i;
+      vr[i] = u32x4{0u, 0u, 0u, 0u};
+      if (row < N) vr[i] = *reinterpret_cast<const u32x4*>(Vb + (long)row * 64 + (lane & 7) * 8);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int row = k0 + 16 * hf + fr;
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        kr[hf][sidx] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < N) kr[hf][sidx] = *reinterpret_cast<const bf16x8*>(Kb + (long)row * 64 + 32 * sidx + 8 * g);
+      }
+    }
+  };
+  f32x4 oacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;                         // m: the same in the four lanes of a query; l: this lane's keys only
+  auto step = [&](int t, u32x4 (&vr)[4], bf16x8 (&kr)[2][2]) {
+    // this tile's V rows into the wave's LDS tile (behind the previous tile's transposed reads in the wave's LDS queue: a wave's LDS
+    // operations complete in issue order), its scores from the K fragments, then the slot is refilled with tile t + 12
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<u32x4*>(mine + ((lane >> 3) + 8 * i) * FT_VP + (lane & 7) * 16) = vr[i];
+    asm volatile("" ::: "memory");
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[0][sidx], qf[sidx], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[1][sidx], qf[sidx], s1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 4 * FT_DEPTH < nt) load_tile(t + 4 * FT_DEPTH, vr, kr);
+    const int k0 = t * FT_TK + 4 * g;                            // lane's keys: k0 + r (tile half 0), k0 + 16 + r (half 1)
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (k0 + r >= N) s0[r] = -INFINITY;
+      if (k0 + 16 + r >= N) s1[r] = -INFINITY;
+      tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mn = fmaxf(m_run, tmax);                         // finite: every tile of the loop holds at least one key < N
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mn);      // first tile: exp2(-inf) = 0 on O = l = 0
+    m_run = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(s0[r] - mn);
+      s1[r] = __builtin_amdgcn_exp2f(s1[r] - mn);
+      ps += s0[r] + s1[r];
+    }
+    l_run = l_run * alpha + ps;
+    const u32x4 pw = {pack2bf(s0[0], s0[1]), pack2bf(s0[2], s0[3]), pack2bf(s1[0], s1[1]), pack2bf(s1[2], s1[3])};
+    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);           // contraction slot 8 g + j = key 4 g + j (half 0), 16 + 4 g + j - 4 (half 1)
+    // V^T fragments in the same key order: lane fr of group g addresses row 4 g + (fr >> 2), 8-byte piece fr & 3 of a 4-row x 32-byte
+    // block and receives column fr of it
+    const char* vb = mine + (4 * g + (fr >> 2)) * FT_VP + (fr & 3) * 8;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const ft_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ft_s16x4*)(vb + d * 32));
+      const ft_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ft_s16x4*)(vb + 16 * FT_VP + d * 32));
+      const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[d][r] *= alpha;
+      oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[d], 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+  };
+#pragma unroll
+  for (int j = 0; j < FT_DEPTH; ++j)
+    if (wid + 4 * j < nt) load_tile(wid + 4 * j, vreg[j], kf[j]);
+  for (int t = wid; t < nt; t += 4 * FT_DEPTH) {
+    step(t, vreg[0], kf[0]);
+    if (t + 4 < nt) step(t + 4, vreg[1], kf[1]);
+    if (t + 8 < nt) step(t + 8, vreg[2], kf[2]);
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  // ---- merge the four waves' partials: O area [wave][d tile][lane] f32x4, then (m, l) per [wave][query]
+  __syncthreads();
+  f32x4* oarea = reinterpret_cast<f32x4*>(smem);
+  float* marea = reinterpret_cast<float*>(smem + 4 * 4 * 64 * 16);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) oarea[(wid * 4 + d) * 64 + lane] = oacc[d];
+  if (g == 0) { marea[wid * 16 + fr] = m_run; marea[64 + wid * 16 + fr] = l_run; }
+  __syncthreads();
+  float mw[4], M = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { mw[v] = marea[v * 16 + fr]; M = fmaxf(M, mw[v]); }
+  float L = 0.f, wgt[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    wgt[v] = (mw[v] > -INFINITY) ? __builtin_amdgcn_exp2f(mw[v] - M) : 0.f;      // a wave without a tile: no contribution
+    L += marea[64 + v * 16 + fr] * wgt[v];
+  }
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};                                // wave w finishes depth columns 16 w + 4 g .. + 3 of query fr
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const f32x4 x = oarea[(v * 4 + wid) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] += x[r] * wgt[v];
+  }
+  if (fr < nq) {
+    const float inv = 1.f / L;
+    const long gi = nb / NH;
+    const int hd = (int)(nb % NH);
+    bf16_t* orow = O + (gi * o_rows + q_begin + fr) * ldo + hd * 64 + 16 * wid + 4 * g;
+    *reinterpret_cast<u32x2*>(orow) = u32x2{pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv)};
+  }
+}
+
+__global__ __launch_bounds__(256) void flash_tail_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int N, int NH, long ldo,
+                                                               float scale_log2e, int q_begin, int o_rows) {
+  __shared__ __attribute__((aligned(16))) char smem[FT_SMEM];
+  flash_tail_body(smem, Q, K, V, O, N, NH, ldo, scale_log2e, q_begin, o_rows, (long)blockIdx.x);
+}
+
 // NT threads per workgroup: 256 (four waves, 128 * QB query rows) or 64 - ONE wave for the ragged last rows of a sequence whose
 // length is a multiple of 256 plus a few (1029 = 5 special tokens + 1024 patches): as a fifth four-wave block those 5 rows held a
 // workgroup slot (222 VGPRs x 4 waves, 32 KiB LDS) for a whole key loop in every (sample, head) pair; as a one-wave workgroup on a
@@ -229,8 +404,19 @@ __device__ __forceinline__ int fa_vswz(int row, int chunk) { return row * 128 + 
 template <int QB, int NT, int VAR = 0>
 __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-                                                                 int N, int NH, long ldo, float scale_log2e, int q_begin, int q_end, int o_rows) {
+                                                                 int N, int NH, long ldo, float scale_log2e, int q_begin, int q_end, int o_rows,
+                                                                 int tail_begin) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * FA_KV * 128];   // 2 stages x (K tile | V tile)
+  static_assert(FT_SMEM <= 2 * 2 * FA_KV * 128, "the tail rows' staging / merge area fits the key loop's LDS");
+  // tail_begin >= 0: the LAST workgroup of every (sample, head) pair takes the <= 16 ragged rows tail_begin .. N - 1 with its keys split
+  // over the four waves (flash_tail_body). It is dispatched right behind the pair's exact blocks, so its K / V rows come from the L2 they
+  // are filling - as a launch of its own the tail rows cost one more read of every K and V from HBM (35 us at 48 x 16 pairs)
+  if constexpr (NT == 256 && QB == 2) {      // (the host only asks for it with two query blocks per wave; kept out of the 168-register QB = 1 build)
+    if (tail_begin >= 0 && blockIdx.x == gridDim.x - 1) {
+      flash_tail_body(smem, Q, K, V, O, N, NH, ldo, scale_log2e, tail_begin, o_rows, (long)blockIdx.y);
+      return;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -712,169 +898,6 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   }
 }
 
-// ---- the ragged last rows of a sequence (<= 16 queries past the last full 256-row block; N = 1029 = 5 special tokens + 1024 patches
-// leaves 5) - keys split over the four waves. As a fifth four-wave block those rows held a workgroup slot for a whole key loop, as a
-// one-wave workgroup (flash_attn_hd64_kernel<1, 64>) they walked 17 key tiles one dependent round trip after the other (81 us beside
-// a 289 us main launch at 48 x 16 pairs; tools/bench_flash.py: 384 us together against 330 us without the tail rows). Measured with
-// this kernel: 35 us on its own - what reading every pair's K and V once more costs (202 MB at 5.8 TB/s) - and 367-369 us for the pair
-// of launches whether it runs on the side stream or in front of the main launch on the caller's: the floor of ANY separate pass over
-// the tail rows is that second read of K / V; only rows computed inside the main kernel's workgroups (whose K / V tiles are in LDS)
-// would avoid it, and the main kernel has no registers for a third query block (249 of 256). Here wave w
-// takes the 32-key tiles w, w + 4, ... on its own: K fragments straight from global memory (a 16-key S^T tile's A operand is 16 whole
-// 128-byte rows), V through a wave-private LDS tile read back transposed (ds_read_b64_tr_b16), no workgroup barrier inside the loop,
-// the next tile's rows requested before this one is multiplied; textbook online softmax on 16-query tiles (v_mfma_f32_16x16x32_bf16,
-// query on the lane as in the main kernel: S^T = K . Q'^T, O^T += V^T . P^T), and one merge of the four (max, sum, O^T) partials
-// through LDS at the end. Q' = bf16(Q * scale * log2 e) and exp2 as in the main kernel.
-constexpr int FT_TK = 32;                 // keys per step and wave
-constexpr int FT_VP = 128 + 32;           // V row pitch in LDS (bytes): the 4 rows x 32 B of a transposed read fall into different banks
-constexpr int FT_STAGE = FT_TK * FT_VP;   // 5 KiB
-typedef short ft_s16x4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256) void flash_tail_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int N, int NH, long ldo,
-                                                               float scale_log2e, int q_begin, int o_rows) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * 2 * FT_STAGE];     // 40 KiB: 4 waves x 2 stages; the merge area afterwards
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int fr = lane & 15, g = lane >> 4;
-  const long nb = blockIdx.x;
-  const bf16_t* Qb = Q + nb * (long)N * 64;
-  const bf16_t* Kb = K + nb * (long)N * 64;
-  const bf16_t* Vb = V + nb * (long)N * 64;
-  const int nq = N - q_begin;                                   // 1 .. 16 valid query rows
-  // Q' fragments (B operand): lane (fr, g) holds Q'[q_begin + fr][32 s + 8 g .. + 8]
-  bf16x8 qf[2];
-  {
-    const int qr = q_begin + (fr < nq ? fr : nq - 1);
-#pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx) {
-      const bf16x8 raw = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 32 * sidx + 8 * g);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qf[sidx][j] = (short)f2bf(bf2f((bf16_t)raw[j]) * scale_log2e);
-    }
-  }
-  char* const mine = smem + wid * (2 * FT_STAGE);
-  const int nt = (N + FT_TK - 1) / FT_TK;
-  // staging of this wave's V tile: 32 rows x 8 chunks of 16 B = 4 per lane (row = lane / 8 + 8 i, chunk = lane % 8);
-  // K fragments: [tile half][k step]: lane (fr, g) holds K[32 t + 16 half + fr][32 s + 8 g .. + 8]. Rows past N: zeros.
-  u32x4 vreg[4];
-  bf16x8 kf[2][2];
-  auto load_tile = [&](int t) {
-    const int k0 = t * FT_TK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = k0 + (lane >> 3) + 8 * i;
-      vreg[i] = u32x4{0u, 0u, 0u, 0u};
-      if (row < N) vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (long)row * 64 + (lane & 7) * 8);
-    }
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const int row = k0 + 16 * hf + fr;
-#pragma unroll
-      for (int sidx = 0; sidx < 2; ++sidx) {
-        kf[hf][sidx] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < N) kf[hf][sidx] = *reinterpret_cast<const bf16x8*>(Kb + (long)row * 64 + 32 * sidx + 8 * g);
-      }
-    }
-  };
-  auto store_v = [&](int stg) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<u32x4*>(mine + stg * FT_STAGE + ((lane >> 3) + 8 * i) * FT_VP + (lane & 7) * 16) = vreg[i];
-  };
-  f32x4 oacc[4];
-#pragma unroll
-  for (int d = 0; d < 4; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;                         // m: the same in the four lanes of a query; l: this lane's keys only
-  int stg = 0;
-  if (wid < nt) {
-    load_tile(wid);
-    store_v(0);
-  }
-  for (int t = wid; t < nt; t += 4, stg ^= 1) {
-    // this tile's scores from the K fragments in registers, then the next tile's rows are requested
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx) {
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][sidx], qf[sidx], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][sidx], qf[sidx], s1, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const bool more = t + 4 < nt;
-    if (more) load_tile(t + 4);
-    const int k0 = t * FT_TK + 4 * g;                            // lane's keys: k0 + r (tile half 0), k0 + 16 + r (half 1)
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (k0 + r >= N) s0[r] = -INFINITY;
-      if (k0 + 16 + r >= N) s1[r] = -INFINITY;
-      tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mn = fmaxf(m_run, tmax);                         // finite: every tile of the loop holds at least one key < N
-    const float alpha = __builtin_amdgcn_exp2f(m_run - mn);      // first tile: exp2(-inf) = 0 on O = l = 0
-    m_run = mn;
-    float ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s0[r] = __builtin_amdgcn_exp2f(s0[r] - mn);
-      s1[r] = __builtin_amdgcn_exp2f(s1[r] - mn);
-      ps += s0[r] + s1[r];
-    }
-    l_run = l_run * alpha + ps;
-    const u32x4 pw = {pack2bf(s0[0], s0[1]), pack2bf(s0[2], s0[3]), pack2bf(s1[0], s1[1]), pack2bf(s1[2], s1[3])};
-    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);           // contraction slot 8 g + j = key 4 g + j (half 0), 16 + 4 g + j - 4 (half 1)
-    // V^T fragments in the same key order: lane fr of group g addresses row 4 g + (fr >> 2), 8-byte piece fr & 3 of a 4-row x 32-byte
-    // block and receives column fr of it
-    const char* vb = mine + stg * FT_STAGE + (4 * g + (fr >> 2)) * FT_VP + (fr & 3) * 8;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const ft_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ft_s16x4*)(vb + d * 32));
-      const ft_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ft_s16x4*)(vb + 16 * FT_VP + d * 32));
-      const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[d][r] *= alpha;
-      oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[d], 0, 0, 0);
-    }
-    asm volatile("" ::: "memory");
-    if (more) store_v(stg ^ 1);                                  // the other stage: last read one iteration ago by this same wave (LDS is in order per wave)
-    asm volatile("" ::: "memory");
-  }
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
-  // ---- merge the four waves' partials: O area [wave][d tile][lane] f32x4, then (m, l) per [wave][query]
-  __syncthreads();
-  f32x4* oarea = reinterpret_cast<f32x4*>(smem);
-  float* marea = reinterpret_cast<float*>(smem + 4 * 4 * 64 * 16);
-#pragma unroll
-  for (int d = 0; d < 4; ++d) oarea[(wid * 4 + d) * 64 + lane] = oacc[d];
-  if (g == 0) { marea[wid * 16 + fr] = m_run; marea[64 + wid * 16 + fr] = l_run; }
-  __syncthreads();
-  float mw[4], M = -INFINITY;
-#pragma unroll
-  for (int v = 0; v < 4; ++v) { mw[v] = marea[v * 16 + fr]; M = fmaxf(M, mw[v]); }
-  float L = 0.f, wgt[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    wgt[v] = (mw[v] > -INFINITY) ? __builtin_amdgcn_exp2f(mw[v] - M) : 0.f;      // a wave without a tile: no contribution
-    L += marea[64 + v * 16 + fr] * wgt[v];
-  }
-  f32x4 o = {0.f, 0.f, 0.f, 0.f};                                // wave w finishes depth columns 16 w + 4 g .. + 3 of query fr
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const f32x4 x = oarea[(v * 4 + wid) * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] += x[r] * wgt[v];
-  }
-  if (fr < nq) {
-    const float inv = 1.f / L;
-    const long gi = nb / NH;
-    const int hd = (int)(nb % NH);
-    bf16_t* orow = O + (gi * o_rows + q_begin + fr) * ldo + hd * 64 + 16 * wid + 4 * g;
-    *reinterpret_cast<u32x2*>(orow) = u32x2{pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv)};
-  }
-}
-
 }  // namespace
 
 extern "C" int vq3_im2col_norm(const float* images, void* patches, int32_t NI, int32_t H, int32_t W, int32_t p,
@@ -935,17 +958,25 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
   const float sl2 = scale * 1.44269504088896340736f;
   int q_main = q_rows;
   bool forked = false;
-  // ragged tail of <= 32 rows past a multiple of 256 (and >= 512 (sample, head) pairs, so that the saved slots matter): the four-wave
-  // launch takes the exact blocks, a one-wave launch on a side stream (forked from / joined to `stream` by events) the tail
+  int tail_begin = -1;
+  // ragged tail of <= 32 rows past a multiple of 256 (N = 1029 = 5 special tokens + 1024 patches leaves 5), two query blocks per wave:
+  //   mode 2 (default, tail <= 16): the four-wave launch takes the exact blocks and ONE MORE workgroup per (sample, head) pair runs the tail
+  //          rows with the keys split over its four waves (flash_tail_body), reading K / V out of the L2 the pair's other blocks fill;
+  //   mode 1 (tail <= 32, >= 512 pairs): the tail as a launch of its own on a side stream, forked from / joined to `stream` by events
+  //          (keys split over four waves up to 16 rows, VQ3_FLASH_TAIL_KSPLIT=0 or 17-32 rows: one wave per pair);
+  //   mode 0: the tail rows as a fifth four-wave block of the main launch (three of its waves only help to stage K / V).
+  // Measured at 48 x 16 pairs x 1029 (tools/bench_flash.py, us): see DESIGN.md section 3 "Flash attention".
   const int tail = N % 256;
-  static int tail_split = -1;
+  static int tail_mode = -1, tail_ksplit = -1;
   static hipStream_t side = nullptr;
   static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  if (tail_split < 0) { const char* e = getenv("VQ3_FLASH_TAIL"); tail_split = e ? atoi(e) : 1; }
-  static int tail_ksplit = -1;
+  if (tail_mode < 0) { const char* e = getenv("VQ3_FLASH_TAIL_MODE"); tail_mode = e ? atoi(e) : 2; }
   if (tail_ksplit < 0) { const char* e = getenv("VQ3_FLASH_TAIL_KSPLIT"); tail_ksplit = e ? atoi(e) : 1; }
-  // (measured: 48 x 16 pairs 409 -> 364 us; 6 x 16 pairs 51 -> 61 us - the one-wave launch is as long as the main one there)
-  if (tail_split && q_rows == N && qb == 2 && tail > 0 && tail <= 32 && N > 256 && (long)G * NH >= (tail_split > 1 ? tail_split : 512)) {
+  const bool ragged = q_rows == N && qb == 2 && tail > 0 && tail <= 32 && N > 256;
+  if (ragged && tail_mode == 2 && tail <= 16) {
+    q_main = N - tail;
+    tail_begin = q_main;
+  } else if (ragged && tail_mode >= 1 && (long)G * NH >= 512) {
     if (!side) {
       if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -958,16 +989,16 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
       forked = true;
       (void)hipEventRecord(ev_fork, (hipStream_t)stream);
       (void)hipStreamWaitEvent(side, ev_fork, 0);
-      if (tail <= 16 && tail_ksplit)          // keys split over four waves (VQ3_FLASH_TAIL_KSPLIT=0: the one-wave kernel, for A/B runs)
+      if (tail <= 16 && tail_ksplit)
         hipLaunchKernelGGL(flash_tail_hd64_kernel, dim3(G * NH), dim3(256), 0, side, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
                            (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N);
       else
         hipLaunchKernelGGL((flash_attn_hd64_kernel<1, 64>), dim3(1, G * NH), dim3(64), 0, side, (const bf16_t*)Q, (const bf16_t*)K,
-                           (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N, N);
+                           (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N, N, -1);
       (void)hipEventRecord(ev_join, side);
     }
   }
-  dim3 grid((q_main + 128 * qb - 1) / (128 * qb), G * NH);
+  dim3 grid((q_main + 128 * qb - 1) / (128 * qb) + (tail_begin >= 0 ? 1 : 0), G * NH);
   // variant: measured (tools/bench_flash.py, 6 x 16 heads): 8232 keys 920 (0) / 951 (1) TF/s, 1029 keys 563 / 560 - the overlap pays once the
   // key loop is long; VQ3_FLASH_VAR pins one
   static int fvar_env = -2;
@@ -975,13 +1006,13 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
   const int fvar = fvar_env >= 0 ? fvar_env : (N >= 2048 ? 1 : 0);
   if (qb == 2 && fvar == 1)
     hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, tail_begin);
   else if (qb == 2)
     hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, tail_begin);
   else
     hipLaunchKernelGGL((flash_attn_hd64_kernel<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, -1);
   if (forked) (void)hipStreamWaitEvent((hipStream_t)stream, ev_join, 0);
   VQ3_CHECK_LAUNCH("flash_attn_fwd");
   return 0;
