@@ -74,6 +74,18 @@ def main():
                 gaps.append((s[j, 0] - s[i, 5]) / 100.0)
         if gaps:
             print(f"    gap between a workgroup's tiles: median {np.median(gaps):.2f} us, max {max(gaps):.2f}")
+        # per CU (XCC id, CU / SH / SE id of HW_REG_HW_ID): what lies between one workgroup's last store being issued and the next workgroup's
+        # first instruction on the same CU (dispatch + wave launch; the one-tile-per-workgroup kernels only)
+        cu = (s[:, 7] & 0xf) | (((s[:, 7] >> 16) & 0xff) << 4)
+        order = np.lexsort((s[:, 0], cu))
+        g04, g05 = [], []
+        for i, j in zip(order[:-1], order[1:]):
+            if cu[i] == cu[j] and wg[i] != wg[j]:
+                g04.append((s[j, 0] - s[i, 4]) / 100.0)
+                g05.append((s[j, 0] - s[i, 5]) / 100.0)
+        if g04:
+            print(f"    same CU, consecutive workgroups ({len(np.unique(cu))} CUs seen): next start - stores issued: median {np.median(g04):.2f} us p90 {np.percentile(g04, 90):.2f}; "
+                  f"next start - stores acknowledged: median {np.median(g05):.2f} us p90 {np.percentile(g05, 90):.2f}")
         ends = np.array([s[wg == w, 5].max() for w in np.unique(wg)])
         print(f"    workgroups finish between {(ends.min() - t0) / 100:.1f} and {(ends.max() - t0) / 100:.1f} us; starts spread {(s[:, 0].min() - t0) / 100:.1f}..{np.percentile(s[:, 0] - t0, 5) / 100:.1f} us (p5)")
         print(f"    XCC ids seen: {sorted(set(xcc.tolist()))}; tiles per XCC: {[int((xcc == x).sum()) for x in sorted(set(xcc.tolist()))]}")

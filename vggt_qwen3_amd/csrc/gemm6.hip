@@ -181,7 +181,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   tile_coords_id(p, tile, BM, BN, m0, n0);
   V6_STAMP(0);
   if (p.stamps && tid == 0)
-    p.stamps[(long)tile * 8 + 7] = ((unsigned long long)blockIdx.x << 32) | __builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, 4 bits */);
+    p.stamps[(long)tile * 8 + 7] = ((unsigned long long)blockIdx.x << 32) | __builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID, 4 bits */) |
+                                   ((unsigned long long)(__builtin_amdgcn_s_getreg(63492 /* HW_REG_HW_ID, 32 bits */) & 0xff00u) << 8);   // CU / SH / SE id -> bits 16-23
   if (HAS_LN && LN_EARLY && p.ln_in && tid < BM) ln_row(p, m0 + tid, ln_mu, ln_rs);
 #pragma unroll
   for (int i = 0; i < AH * 4; ++i)
