@@ -109,7 +109,7 @@ int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* desc, const void* gu, void* dgu, vo
  * x [M, K] . W_gate|up [2 I, K]^T (N = 2 I, I % 128 == 0, K % 64 == 0, no bias / residual / batch); every tile multiplies a block of gate
  * rows of W and the same block of up rows, so the epilogue holds both halves of a feature: gu bf16 [M, 2 I] = gate | up is written as the
  * backward reads it, and desc->C / ldc receive act bf16 [M, I] = bf16(bf16(silu(gate)) * up) - same arithmetic and rounding as
- * vq3_silu_mul_fwd on the materialised gu. */
+ * vq3_silu_mul_fwd on the materialised gu. gu == NULL: only act is written (a forward that no backward follows: eval / no_grad). */
 int vq3_gemm_swiglu_fwd(const vq3_gemm_desc* desc, void* gu, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -327,6 +327,13 @@ def test_gemm_swiglu_fwd_epilogue_equals_two_launches(ops, cfg, M, H, I):
     assert (slab[:2] == 7.0).all() and (slab[2 + M:] == 7.0).all()            # nothing outside the row block
     ref = torch.nn.functional.silu(gu_ref[:, :I].float()).to(BF16).float() * gu_ref[:, I:].float()
     assert _relerr(act, ref) < 4e-3
+    # without the gate|up output (a forward that no backward follows): the same act, bit for bit
+    try:
+        ops.gemm_force_config(cfg)
+        none, act_only = ops.gemm_swiglu_fwd(x, W, keep_gu=False)
+    finally:
+        ops.gemm_force_config(-3)
+    assert none is None and (torch.equal(act_only, act) if cfg != -3 else _relerr(act_only, act) < 1e-3)
     with pytest.raises(RuntimeError):
         ops.gemm_swiglu_fwd(x, _rand((2 * 200, H), 0.05, seed=52))             # I % 128 != 0
 

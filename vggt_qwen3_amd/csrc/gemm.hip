@@ -378,6 +378,7 @@ int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStr
 
 }  // namespace
 
+static char kSwigluNoGu;      // vq3_gemm_swiglu_fwd without a gate|up output (a forward that no backward follows): "mode on, pointer null"
 static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve, void* stream, const void* sw_gu = nullptr,
                          void* sw_dgu = nullptr, const vq3_gemm_ln_fold* ln = nullptr, void* sw_fwd_gu = nullptr) {
   VQ3_CHECK_ARG(d != nullptr, "gemm: null descriptor");
@@ -451,9 +452,10 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
                       d->act == 0 && d->ksplit <= 1 && d->nb1 == 1 && d->nb2 == 1 && d->alpha == 1.f,
                   "gemm_swiglu_fwd: plain NT bf16 GEMM (no epilogue, no batch), K %% 64 == 0");
     VQ3_CHECK_ARG(d->N % 256 == 0 && d->ldc >= d->N / 2 && d->ldc % 8 == 0, "gemm_swiglu_fwd: N = 2 I with I %% 128 == 0, act rows of >= I elements (ld %% 8)");
+    if (sw_fwd_gu == (void*)&kSwigluNoGu) sw_fwd_gu = nullptr;
     VQ3_CHECK_ARG(((uintptr_t)sw_fwd_gu | (uintptr_t)d->C) % 16 == 0, "gemm_swiglu_fwd: gate|up / act must be 16-byte aligned");
     p.epi = 3;
-    p.sw_dgu = (bf16_t*)sw_fwd_gu;
+    p.sw_dgu = (bf16_t*)sw_fwd_gu;                 // null: the epilogue stores act only
     p.sC1 = p.sC2 = 0;
   }
   const int esz = d->out_f32 ? 4 : 2;
@@ -595,8 +597,8 @@ extern "C" int vq3_gemm_swiglu_bwd(const vq3_gemm_desc* d, const void* gu, void*
 }
 
 extern "C" int vq3_gemm_swiglu_fwd(const vq3_gemm_desc* d, void* gu, void* stream) {
-  VQ3_CHECK_ARG(gu != nullptr && d != nullptr && d->C != nullptr, "gemm_swiglu_fwd: null output pointer");
-  return gemm_dispatch(d, nullptr, stream, nullptr, nullptr, nullptr, gu);
+  VQ3_CHECK_ARG(d != nullptr && d->C != nullptr, "gemm_swiglu_fwd: null output pointer");
+  return gemm_dispatch(d, nullptr, stream, nullptr, nullptr, nullptr, gu ? gu : (void*)&kSwigluNoGu);     // gu == NULL: act only
 }
 
 extern "C" int vq3_gemm_tile_order(int32_t M, int32_t N, int32_t bm, int32_t bn, int32_t wg_per_cu, int32_t* xm_out, int32_t* band_out,

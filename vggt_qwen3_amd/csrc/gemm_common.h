@@ -426,9 +426,11 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
         }
         o[k] = pack2bf(r[0], r[1]);
       }
-      bf16_t* gp = p.sw_dgu + (long)m * p.N + n;
-      *reinterpret_cast<u32x4*>(gp) = gv;
-      *reinterpret_cast<u32x4*>(gp + inter) = uv;
+      if (p.sw_dgu) {                            // (null under no_grad: nobody reads gate|up again)
+        bf16_t* gp = p.sw_dgu + (long)m * p.N + n;
+        *reinterpret_cast<u32x4*>(gp) = gv;
+        *reinterpret_cast<u32x4*>(gp + inter) = uv;
+      }
       *reinterpret_cast<u32x4*>(act + (long)m * p.ldc + n) = o;
     }
     return;

@@ -549,16 +549,19 @@ def swiglu_fwd_fusable(M: int, inter: int, K: int) -> bool:
     return K % 64 == 0 and inter % 128 == 0 and M >= 1 and os.environ.get("VQ3_SWIGLU_FWD_FUSED", "1") != "0"
 
 
-def gemm_swiglu_fwd(x: torch.Tensor, w_gu: torch.Tensor, gu_out: Optional[torch.Tensor] = None, act_out: Optional[torch.Tensor] = None):
+def gemm_swiglu_fwd(x: torch.Tensor, w_gu: torch.Tensor, gu_out: Optional[torch.Tensor] = None, act_out: Optional[torch.Tensor] = None,
+                    keep_gu: bool = True):
     """(gu, act) with gu = x @ w_gu^T [M, 2 I] = gate | up and act = silu_mul_fwd(gu) [M, I], in ONE launch (vq3_gemm_swiglu_fwd):
-    x bf16 [M, K], w_gu bf16 [2 I, K] (gate rows, then up rows - the fused weight of modeling_qwen3.py:81-83)."""
+    x bf16 [M, K], w_gu bf16 [2 I, K] (gate rows, then up rows - the fused weight of modeling_qwen3.py:81-83).
+    keep_gu=False (a forward without a backward): gate|up is not written, (None, act) is returned."""
     _req(x, BF16, "swiglu_fwd x"); _req(w_gu, BF16, "swiglu_fwd w")
     assert x.dim() == 2 and w_gu.dim() == 2 and x.stride(1) == 1 and w_gu.stride(1) == 1 and x.shape[1] == w_gu.shape[1]
     M, K = x.shape
     N = w_gu.shape[0]
-    gu = _out2d(gu_out, M, N, x, "gemm_swiglu_fwd gu")
+    gu = _out2d(gu_out, M, N, x, "gemm_swiglu_fwd gu") if keep_gu else None
     act = _out2d(act_out, M, N // 2, x, "gemm_swiglu_fwd act")
-    assert gu.is_contiguous()
+    assert gu is None or gu.is_contiguous()
+    gu_ptr = gu.data_ptr() if gu is not None else None
     d = GemmDesc()
     d.A = x.data_ptr(); d.B = w_gu.data_ptr(); d.C = act.data_ptr()
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = M, N, K, x.stride(0), w_gu.stride(0), act.stride(0), 0
@@ -567,11 +570,11 @@ def gemm_swiglu_fwd(x: torch.Tensor, w_gu: torch.Tensor, gu_out: Optional[torch.
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_lib.load().vq3_gemm_swiglu_fwd(d, gu.data_ptr(), _stream()), "vq3_gemm_swiglu_fwd")
+        check(_lib.load().vq3_gemm_swiglu_fwd(d, gu_ptr, _stream()), "vq3_gemm_swiglu_fwd")
         e1.record()
-        GEMM_PROFILE.append((2.0 * M * N * K, 2.0 * M * K + 2.0 * N * K + 2.0 * M * N * 1.5, e0, e1, (M, N, K, 1)))
+        GEMM_PROFILE.append((2.0 * M * N * K, 2.0 * M * K + 2.0 * N * K + 2.0 * M * N * (1.5 if keep_gu else 0.5), e0, e1, (M, N, K, 1)))
     else:
-        check(_lib.load().vq3_gemm_swiglu_fwd(d, gu.data_ptr(), _stream()), "vq3_gemm_swiglu_fwd")
+        check(_lib.load().vq3_gemm_swiglu_fwd(d, gu_ptr, _stream()), "vq3_gemm_swiglu_fwd")
     return gu, act
 
 

@@ -447,7 +447,7 @@ class Qwen3ForCausalLM(nn.Module):
             xn2, r2 = ops.rmsnorm_fwd(h_mid, self._w[f"l{i}.ln2"], c.rms_norm_eps, want_rstd=True, out=wv(i, "gu.X"))
             if getattr(self, "_fp8", None) is None and ops.swiglu_fwd_fusable(B * L, c.intermediate_size, H):
                 # gate|up projection with silu(gate) * up in its epilogue: act leaves with gu, no second pass over [rows, 2 I]
-                gu, act = ops.gemm_swiglu_fwd(xn2, self._w[f"l{i}.gu"], act_out=wv(i, "down.X"))
+                gu, act = ops.gemm_swiglu_fwd(xn2, self._w[f"l{i}.gu"], act_out=wv(i, "down.X"), keep_gu=save)   # (no backward: act only)
             else:
                 gu = self._proj(xn2, f"l{i}.gu")
                 act = ops.silu_mul_fwd(gu, out=wv(i, "down.X"))
