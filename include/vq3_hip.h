@@ -191,8 +191,10 @@ int vq3_qwen_qkprep_fwd(const void* qkv, const void* q_w, const void* k_w, const
                         void* K, void* V, float* q_rstd, float* k_rstd, int32_t B, int32_t L, int32_t Hq, int32_t Hkv,
                         int32_t D, float eps, void* stream);
 /* Backward: dQ,dK,dV (layouts as above) + saved qkv, rstd -> dqkv bf16 [B*L,(Hq+2Hkv)*D];
- * dq_w_part, dk_w_part f32 [B*L, D]: one partial row per token (plain stores); reduce with vq3_colsum_f32_to_bf16.
+ * dq_w_part, dk_w_part f32 [ceil(B*L / VQ3_QKPREP_BWD_TOKENS_PER_PART), D]: one partial row per workgroup = per 8 consecutive tokens
+ * (plain stores); reduce that many rows with vq3_colsum_f32_to_bf16.
  * kv_parts: dK and dV are [kv_parts, B, Hkv, L, D] partial slabs (vq3_qwen_flash_bwd), summed here in f32. */
+#define VQ3_QKPREP_BWD_TOKENS_PER_PART 8
 int vq3_qwen_qkprep_bwd(const void* dQ, const void* dK, const void* dV, const void* qkv, const void* q_w,
                         const void* k_w, const void* cos, const void* sin, const float* q_rstd, const float* k_rstd,
                         void* dqkv, float* dq_w_part, float* dk_w_part, int32_t kv_parts, int32_t B, int32_t L, int32_t Hq,

@@ -32,6 +32,14 @@ def test_binding_matches_header():
     assert lib.vq3_target_arch() == b"gfx950"
 
 
+def test_header_constants_match_the_binding():
+    """Sizes the host allocates from a constant of the header."""
+    from vggt_qwen3_amd import ops
+    text = (ROOT / "include" / "vq3_hip.h").read_text()
+    m = re.search(r"#define\s+VQ3_QKPREP_BWD_TOKENS_PER_PART\s+(\d+)", text)
+    assert m and int(m.group(1)) == ops.QKPREP_BWD_TOKENS_PER_PART
+
+
 def test_bad_args_fail_loudly_without_gpu():
     """Argument validation runs on the host before any launch."""
     from vggt_qwen3_amd import _lib

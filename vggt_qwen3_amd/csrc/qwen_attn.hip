@@ -98,26 +98,30 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
                                                          const float* __restrict__ q_rstd,
                                                          const float* __restrict__ k_rstd, bf16_t* __restrict__ dqkv,
                                                          float* __restrict__ dq_w, float* __restrict__ dk_w, int L,
-                                                         int Hq, int Hkv, int kv_parts, long part_stride) {
+                                                         int Hq, int Hkv, int kv_parts, long part_stride, long T) {
+  // VQ3_QKPREP_BWD_TOKENS_PER_PART tokens per workgroup: the norm-weight partials of a workgroup's tokens are summed in registers and
+  // meet in LDS once (one zeroing, one round of LDS atomics, two barriers and one partial row per 8 tokens instead of per token: kernel 150 -> 114-118 us cold at 9600 tokens, the two column sums 2 x 50 -> 2 x 5-14 us)
   __shared__ float dw_s[2][D];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
   const int e = 2 * j;
   if (threadIdx.x < 2 * D) (&dw_s[0][0])[threadIdx.x] = 0.f;
   __syncthreads();
-  const long t = blockIdx.x;
-  const int b = (int)(t / L), l = (int)(t - (long)b * L);
   const int HT = Hq + 2 * Hkv;
-  const bf16_t* row = qkv + t * (long)HT * D;
-  bf16_t* drow = dqkv + t * (long)HT * D;
-  float c1[2], c2[2], s1[2], s2[2];
-  ld2(cs + l * D + e, c1[0], c1[1]); ld2(cs + l * D + e + 64, c2[0], c2[1]);
-  ld2(sn + l * D + e, s1[0], s1[1]); ld2(sn + l * D + e + 64, s2[0], s2[1]);
   float aq1[2] = {0.f, 0.f}, aq2[2] = {0.f, 0.f}, ak1[2] = {0.f, 0.f}, ak2[2] = {0.f, 0.f};
   float wq1[2], wq2[2], wk1[2], wk2[2];
   ld2(q_w + e, wq1[0], wq1[1]); ld2(q_w + e + 64, wq2[0], wq2[1]);
   ld2(k_w + e, wk1[0], wk1[1]); ld2(k_w + e + 64, wk2[0], wk2[1]);
   const int np = kv_parts < 2 ? 1 : 2;             // slabs fetched with the batch (further ones, kv_parts 3..4: in the arithmetic loop)
+  for (int tt = 0; tt < VQ3_QKPREP_BWD_TOKENS_PER_PART; ++tt) {
+  const long t = (long)blockIdx.x * VQ3_QKPREP_BWD_TOKENS_PER_PART + tt;
+  if (t >= T) break;
+  const int b = (int)(t / L), l = (int)(t - (long)b * L);
+  const bf16_t* row = qkv + t * (long)HT * D;
+  bf16_t* drow = dqkv + t * (long)HT * D;
+  float c1[2], c2[2], s1[2], s2[2];
+  ld2(cs + l * D + e, c1[0], c1[1]); ld2(cs + l * D + e + 64, c2[0], c2[1]);
+  ld2(sn + l * D + e, s1[0], s1[1]); ld2(sn + l * D + e + 64, s2[0], s2[1]);
   // the gradient rows (first two partial slabs), the saved q|k|v rows and the row statistics of QK_IT heads are requested before the
   // first is used: one memory round trip per batch instead of one per head (Qwen3-4B: 48 heads = 6 per half-wave = one batch)
   for (int hb = 2 * wid + half; hb < HT; hb += 8 * QK_IT) {
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
       }
     }
   }
+  }   // tokens of this workgroup
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     atomicAdd(&dw_s[0][e + u], aq1[u]);
@@ -196,11 +201,11 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
     atomicAdd(&dw_s[1][e + u + 64], ak2[u]);
   }
   __syncthreads();
-  // plain-store partial rows [token][D] (summed by vq3_colsum_f32_to_bf16): no contended global atomics
+  // plain-store partial rows [workgroup][D] (summed by vq3_colsum_f32_to_bf16): no contended global atomics
   if (threadIdx.x < D) {
-    dq_w[t * D + threadIdx.x] = dw_s[0][threadIdx.x];
+    dq_w[(long)blockIdx.x * D + threadIdx.x] = dw_s[0][threadIdx.x];
   } else {
-    dk_w[t * D + threadIdx.x - D] = dw_s[1][threadIdx.x - D];
+    dk_w[(long)blockIdx.x * D + threadIdx.x - D] = dw_s[1][threadIdx.x - D];
   }
 }
 
@@ -227,10 +232,12 @@ extern "C" int vq3_qwen_qkprep_bwd(const void* dQ, const void* dK, const void* d
                 "qkprep_bwd: null pointer");
   VQ3_CHECK_ARG(Dh == D, "qkprep_bwd: head_dim must be %d, got %d", D, Dh);
   VQ3_CHECK_ARG(B > 0 && L > 0 && Hq > 0 && Hkv > 0 && kv_parts >= 1 && kv_parts <= 4, "qkprep_bwd: bad shape");
-  hipLaunchKernelGGL(qkprep_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dQ,
+  const long T = (long)B * L;
+  const unsigned nblk = (unsigned)((T + VQ3_QKPREP_BWD_TOKENS_PER_PART - 1) / VQ3_QKPREP_BWD_TOKENS_PER_PART);
+  hipLaunchKernelGGL(qkprep_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dQ,
                      (const bf16_t*)dK, (const bf16_t*)dV, (const bf16_t*)qkv, (const bf16_t*)q_w, (const bf16_t*)k_w,
                      (const bf16_t*)cos, (const bf16_t*)sin, q_rstd, k_rstd, (bf16_t*)dqkv, dq_w_f32, dk_w_f32, L, Hq,
-                     Hkv, (int)kv_parts, (long)B * Hkv * L * D);
+                     Hkv, (int)kv_parts, (long)B * Hkv * L * D, T);
   VQ3_CHECK_LAUNCH("qkprep_bwd");
   return 0;
 }

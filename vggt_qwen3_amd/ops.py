@@ -345,6 +345,9 @@ def qwen_qkprep_fwd(qkv, q_w, k_w, cos, sin, B, L, Hq, Hkv, D, eps, want_rstd=Tr
     return Q, K, V, qr, kr
 
 
+QKPREP_BWD_TOKENS_PER_PART = 8      # include/vq3_hip.h: VQ3_QKPREP_BWD_TOKENS_PER_PART (tests/test_abi.py keeps the two equal)
+
+
 def qwen_qkprep_bwd(dQ, dK, dV, qkv, q_w, k_w, cos, sin, qr, kr, dq_w_out, dk_w_out, accumulate, B, L, Hq, Hkv, D,
                     defer: Optional[list] = None, out: Optional[torch.Tensor] = None):
     """dq_w_out / dk_w_out: bf16 [D] gradient vectors, (+)= per `accumulate`."""
@@ -353,19 +356,20 @@ def qwen_qkprep_bwd(dQ, dK, dV, qkv, q_w, k_w, cos, sin, qr, kr, dq_w_out, dk_w_
     kv_parts = dK.shape[0] if dK.dim() == 5 else 1            # [parts, B, Hkv, L, D] partial slabs of the split dK/dV pass
     assert dV.shape == dK.shape
     dqkv = _out2d(out, qkv.shape[0], qkv.shape[1], qkv, "qwen_qkprep_bwd")
-    part = torch.empty((2, B * L, D), device=qkv.device, dtype=F32)
+    rows = (B * L + QKPREP_BWD_TOKENS_PER_PART - 1) // QKPREP_BWD_TOKENS_PER_PART      # one partial row per workgroup
+    part = torch.empty((2, rows, D), device=qkv.device, dtype=F32)
     lib = _lib.load()
     check(lib.vq3_qwen_qkprep_bwd(dQ.data_ptr(), dK.data_ptr(), dV.data_ptr(), qkv.data_ptr(), q_w.data_ptr(),
                                   k_w.data_ptr(), cos.data_ptr(), sin.data_ptr(), qr.data_ptr(), kr.data_ptr(),
                                   dqkv.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), kv_parts, B, L, Hq, Hkv, D,
                                   _stream()), "vq3_qwen_qkprep_bwd")
     if defer is not None:
-        defer.append((part[0], B * L, D, dq_w_out, accumulate))
-        defer.append((part[1], B * L, D, dk_w_out, accumulate))
+        defer.append((part[0], rows, D, dq_w_out, accumulate))
+        defer.append((part[1], rows, D, dk_w_out, accumulate))
         return dqkv
     acc = 1 if accumulate else 0
-    check(lib.vq3_colsum_f32_to_bf16(part[0].data_ptr(), B * L, D, dq_w_out.data_ptr(), acc, _stream()), "colsum dq_w")
-    check(lib.vq3_colsum_f32_to_bf16(part[1].data_ptr(), B * L, D, dk_w_out.data_ptr(), acc, _stream()), "colsum dk_w")
+    check(lib.vq3_colsum_f32_to_bf16(part[0].data_ptr(), rows, D, dq_w_out.data_ptr(), acc, _stream()), "colsum dq_w")
+    check(lib.vq3_colsum_f32_to_bf16(part[1].data_ptr(), rows, D, dk_w_out.data_ptr(), acc, _stream()), "colsum dk_w")
     return dqkv
 
 
