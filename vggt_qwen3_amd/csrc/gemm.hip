@@ -265,7 +265,9 @@ int launch_split_rows(GemmParams p, int nbatch, hipStream_t s) {
   if (p.ln_in) b.ln_in = p.ln_in + (long)m_main * p.ln_parts * 2;
   if (p.st_out) b.st_out = p.st_out + (long)m_main * (p.N >> 7) * 2;
   // (tried: the row tail on a side stream forked from / joined to `s` by events so that it overlaps the main launch instead of following it -
-  // no gain, fc1 +3 %: the dispatcher does not interleave the two grids; gpurun_out r3_diag9 epi_30 vs epi_30_serial)
+  // no gain, fc1 +3 %: the dispatcher does not interleave the two grids; gpurun_out r3_diag9 epi_30 vs epi_30_serial. Second try: the tail
+  // FIRST, on a HIGH-priority side stream, the main launch behind it on `s` - fc1 519 -> 507 us, q|k|v-shaped 338 -> 335, fc2 374 -> 379,
+  // proj 156 -> 166: the two event hops cost what the overlap gives)
   int rc = launch_gemm_v6(a, 0, nbatch, s);
   if (rc) return rc;
   const long t128 = (long)((b.M + 127) / 128) * ((b.N + 127) / 128);
