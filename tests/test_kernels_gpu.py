@@ -829,3 +829,25 @@ def test_perceiver_xattn_rejects_bad_args(ops):
     q, kv = _rand((16, 96), seed=1), _rand((16, 192), seed=2)
     with pytest.raises((_lib.Vq3Error, AssertionError)):
         ops.perceiver_xattn(q, kv, 1, 1, 16, 16, 96, 64)             # head size without an instantiation
+
+
+@pytest.mark.parametrize("dt", [BF16, F32])
+def test_dropout_mask_does_not_depend_on_the_access_width(ops, dt):
+    """vq3_dropout keeps / zeroes element i by a hash of (seed, offset + i) alone: the 16-byte-per-lane walk over an aligned tensor and the
+    element-wise walk a misaligned view takes must produce the same values, tail elements included; the kept fraction is 1 - p."""
+    n = 1_000_003
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(n + 8, generator=g).to(dt).cuda()
+    a = base[:n].clone()                               # 16-byte aligned: vector path + scalar tail
+    buf = torch.empty(n + 8, device="cuda", dtype=dt)
+    b = buf[1:1 + n]                                   # misaligned by one element: scalar path
+    b.copy_(base[:n])
+    assert a.data_ptr() % 16 == 0 and b.data_ptr() % 16 != 0 and b.is_contiguous()
+    ops.dropout_(a, 0.3, 987654321, 12345)
+    ops.dropout_(b, 0.3, 987654321, 12345)
+    assert torch.equal(a, b)
+    kept = (a != 0).float().mean().item()
+    assert abs(kept - 0.7) < 5e-3
+    ref = (base[:n].float() * (1.0 / 0.7)).to(dt)
+    m = a != 0
+    assert torch.equal(a[m], ref[m])
