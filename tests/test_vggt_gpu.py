@@ -125,6 +125,34 @@ def test_aggregator_vs_cpu_restatement(H, W, S, B, C):
         assert e32 < max(2e-2, 3 * noise), f"iterate {i}: HIP vs fp32 restatement {e32}, bf16 CPU noise {noise}"
 
 
+def test_aggregator_row_split_chain_equals_the_unsplit_blocks(monkeypatch):
+    """Aggregator._block with the proj -> fc1 -> fc2 chain split by rows (whole rounds of 16 384 rows on the caller's stream, the rows
+    behind them as a chain of their own on a second stream, joined before the next block's q|k|v) against the unsplit blocks: the three
+    GEMMs are row-wise, so both iterates agree to GEMM-configuration noise. 64 frames x 261 tokens = 16 704 rows: a 320-row tail."""
+    from vggt_qwen3_amd.vggt import Aggregator
+    C = 128
+    agg = Aggregator(img_size=224, patch_size=14, embed_dim=C, depth=2, num_heads=C // 64, dino_depth=2, device="cuda", seed=3)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n, t in agg.named_tensors().items():
+            if n.endswith("gamma"):
+                t.copy_((0.5 + 0.5 * torch.rand(t.shape, generator=g)).to(BF16))
+            elif t.dim() >= 2:
+                t.copy_((0.05 * torch.randn(t.shape, generator=g)).to(BF16))
+    agg._cc = None; agg._pos_cache.clear()
+    images = torch.rand(4, 16, 3, 224, 224, generator=g).cuda()
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("VQ3_VGGT_ROW_SPLIT", mode)
+        assert (agg._split_rows(64 * 261) == 16384) == (mode == "2")
+        o, _ = agg(images, return_all=True)
+        torch.cuda.synchronize()
+        outs[mode] = [t.clone() for t in o]
+    for a, b in zip(outs["2"], outs["0"]):
+        assert relerr(a, b) < 2e-3
+        assert relerr(a[-1, -1], b[-1, -1]) < 2e-3           # the last frame holds the tail rows
+
+
 @pytest.mark.parametrize("use_norm,use_rope", [(True, True), (False, False), (True, False), (False, True)])
 def test_vit_qkprep_vs_fp32_reference(monkeypatch, use_norm, use_rope):
     """Per-head LayerNorm(64) + 2-D rotate-half RoPE + head-major split, both lane layouts (4 features per lane; the

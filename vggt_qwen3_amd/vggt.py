@@ -214,6 +214,26 @@ class Aggregator(nn.Module):
             self._rope_cache[maxpos] = (ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous())
         return self._rope_cache[maxpos]
 
+    # ------------------------------------------------------------------ row split of the row-wise chain of a block
+    ROW_UNIT = 256 * 64          # rows that make whole rounds of 256 CUs for 4, 12 and 16 column tiles of 256 (N = C, 3 C, 4 C at C = 1024)
+
+    def _split_rows(self, T: int) -> int:
+        """Rows of the main chain (0: no split): whole multiples of ROW_UNIT, when 1 .. 2048 rows are left behind them."""
+        mode = os.environ.get("VQ3_VGGT_ROW_SPLIT", "1")        # 0: never; 2: at any width (tests); default: at the width ROW_UNIT is for
+        if mode == "0" or (self.embed_dim != 1024 and mode != "2"):
+            return 0
+        main = T // self.ROW_UNIT * self.ROW_UNIT
+        return main if (main > 0 and 0 < T - main <= 2048) else 0
+
+    def _tail_stream_for(self, dev) -> "torch.cuda.Stream":
+        ts = getattr(self, "_tail_streams", None)
+        if ts is None:
+            ts = self._tail_streams = {}
+        key = torch.device(dev).index
+        if key not in ts:
+            ts[key] = torch.cuda.Stream(device=dev)
+        return ts[key]
+
     # ------------------------------------------------------------------ one transformer block
     def _block(self, x, w, N, *, rope, eps, P, Wp, st=None, keep=None):
         """One pre-norm block. Returns (x_out, statistics of x_out's rows for the next block's first LayerNorm, or None).
@@ -240,10 +260,36 @@ class Aggregator(nn.Module):
             o = ops.flash_attn(Q, K, V, q_rows=keep)
             x = head(x)
             st2 = torch.empty((x.shape[0], C // 128, 2), device=x.device, dtype=torch.float32)
+            st3 = torch.empty_like(st2)
+            Mm = self._split_rows(x.shape[0]) if keep is None else 0
+            if Mm:
+                # proj -> fc1 -> fc2 are row-wise: the rows that fill whole rounds of the 256 x 256 kernel go down the caller's stream,
+                # the <= 2048 rows behind them as a chain of their own on a second stream - forked here (the attention output is
+                # complete), joined before the next block's q|k|v, which reads every row. Inside one GEMM call the row tail is a
+                # 20-40 us launch that 64 CUs run ALONE behind the main launch (cfg 30: 36 of them per micro-batch, 0.95 ms); as a chain
+                # beside the main one its workgroups are dispatched whenever a CU has nothing else.
+                T = x.shape[0]
+                x1, x2 = torch.empty_like(x), torch.empty_like(x)
+                h = torch.empty((T, w["fc1_wf"].shape[0]), device=x.device, dtype=BF16)
+                cur = torch.cuda.current_stream()
+                side = self._tail_stream_for(x.device)
+
+                def chain(sl):
+                    ops.linear(o[sl], w["proj_w"], bias=w["proj_b"], colscale=w["ls1"], residual=x[sl], out=x1[sl],
+                               ln_fold=ops.ln_fold(stats_out=st2[sl]))
+                    ops.linear(x1[sl], w["fc1_wf"], bias=w["fc1_d"], act=ops.ACT_GELU, out=h[sl],
+                               ln_fold=ops.ln_fold(stats_in=st2[sl], eps=eps, colsum=w["fc1_c"]))
+                    ops.linear(h[sl], w["fc2_w"], bias=w["fc2_b"], colscale=w["ls2"], residual=x1[sl], out=x2[sl],
+                               ln_fold=ops.ln_fold(stats_out=st3[sl]))
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    chain(slice(Mm, T))
+                chain(slice(0, Mm))
+                cur.wait_stream(side)
+                return x2, st3
             x = ops.linear(o, w["proj_w"], bias=w["proj_b"], colscale=w["ls1"], residual=x, ln_fold=ops.ln_fold(stats_out=st2))
             h = ops.linear(x, w["fc1_wf"], bias=w["fc1_d"], act=ops.ACT_GELU,
                            ln_fold=ops.ln_fold(stats_in=st2, eps=eps, colsum=w["fc1_c"]))
-            st3 = torch.empty_like(st2)
             x = ops.linear(h, w["fc2_w"], bias=w["fc2_b"], colscale=w["ls2"], residual=x, ln_fold=ops.ln_fold(stats_out=st3))
             return x, st3
         xn, _ = ops.layernorm_fwd(x, w["n1"][0], w["n1"][1], eps)
