@@ -469,6 +469,8 @@ def main():
     roof = None
     if rank == 0:
         model.text_model._wgrad_stream = None   # serial launches: per-launch event times are not inflated by overlap
+        row_split_env = os.environ.get("VQ3_VGGT_ROW_SPLIT")
+        os.environ["VQ3_VGGT_ROW_SPLIT"] = "0"  # (likewise the tower's second stream: one chain per block while the events are in)
         # one group of the deferred weight-gradient schedule (every projection's weight-gradient GEMM runs over nroof micro-batches'
         # rows): per-step figures below are the group's totals / nroof
         nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)) * max(1, trainer.text_group), accum))
@@ -490,6 +492,10 @@ def main():
             for k, (c, m_, f_) in sorted(tab.items(), key=lambda kv: -kv[1][1])[:40]:
                 print(f"  {k}: {c:6.1f} {m_:8.3f} ms {f_ / m_ / 1e9:8.1f} TF/s", file=sys.stderr)
         ops.GEMM_PROFILE = None
+        if row_split_env is None:
+            os.environ.pop("VQ3_VGGT_ROW_SPLIT", None)
+        else:
+            os.environ["VQ3_VGGT_ROW_SPLIT"] = row_split_env
         ach = fl / (ms * 1e-3) / 1e12
         # PMC counters cannot be read from inside the run: `traffic` is the rocprofv3 --pmc result of THIS command at the
         # commit named beside it (tools/summarize_pmc.py writes the file); null when no such profile has been committed
