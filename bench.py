@@ -419,7 +419,7 @@ def main():
 
         # the same forward over 8 micro-batches at once (48 samples): what the tower / text GEMMs reach when the batch is not the limit
         if trainer.text_group > 1:
-            nb = trainer.text_group
+            nb = 8                                   # (a fixed 48 samples: comparable from round to round whatever the training pass size is)
 
             def fwd_big():
                 big, _sizes = trainer._merge([stream.pop() for _ in range(nb)])      # (the torch.cat is inside the timed call)

@@ -82,7 +82,11 @@ class Stage1Trainer:
         # 200 under-filled 128 x 128 ones), the tower 8 x 6174; each micro-batch's loss stays the mean over ITS labelled rows and the
         # gradient is that of their sum - what the micro-batches produce one by one (Qwen3ForCausalLM.loss_head(groups=...)).
         if text_group is None:
-            text_group = int(os.environ.get("VQ3_TEXT_GROUP", "8"))     # measured: 1: 96.6, 2: 106.5, 4: 115.1, 8: 119.1, 16: 115.3 samples/s
+            # measured (round 2, window of 32): 1: 96.6, 2: 106.5, 4: 115.1, 8: 119.1, 16: 115.3 samples/s. Round 3: a window that is a multiple of
+            # 10 runs in passes of 10 - [12000, 2560] outputs are 470 tiles of 256 x 256 = 1.84 rounds of 256 CUs (92 % full) where 9600 rows
+            # give 380 tiles = 1.48 rounds (74 %), and a window of 20 is two whole passes instead of 8 + 8 + 4 (same box, alternating runs:
+            # 137.0 / 137.7 -> 148.5 / 147.6 samples/s at grad_accum 20; 124 GB peak instead of 114)
+            text_group = int(os.environ.get("VQ3_TEXT_GROUP", "10" if (grad_accum >= 10 and grad_accum % 10 == 0) else "8"))
         self.text_group = max(1, text_group)
         self._merged_pending: List = []     # [(batch dict, loss)] of a merged pass, handed out by the following micro_step() calls
         self._opt_due = False               # the merged pass held the window's boundary: AdamW runs when its last loss is handed out
