@@ -365,7 +365,12 @@ int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStr
   const int flags = (transA ? 1 : 0) | (transB ? 2 : 0) | (p.out_f32 ? 4 : 0) | (p.accumulate ? 8 : 0) | (p.R ? 16 : 0) |
                     (p.bias ? 32 : 0) | (p.act << 6) | (p.colscale ? 256 : 0) | (p.epi << 9) | (p.ln_in ? 4096 : 0) | (p.st_out ? 8192 : 0) |
                     (p.vec_ok ? 0 : 16384) | (rows16 ? 0 : 32768);
-  const TuneKey key(p.M, p.N, p.K, nbatch, flags);
+  // small extents are remembered per bucket (M < 256 in steps of 32, K < 512 in steps of 64): the labelled rows of a pass - the lm_head's M,
+  // its weight gradient's K - change from pass to pass, and a measurement (a device synchronisation, ~10 ms of trial launches) for every new
+  // count landed inside training steps: bench.py's instrumented window showed a 15.6 ms "launch" of the [149, 151 937, 2560] product
+  const int mkey = p.M < 256 ? (p.M + 31) / 32 * 32 : p.M;
+  const int kkey = p.K < 512 ? (p.K + 63) / 64 * 64 : p.K;
+  const TuneKey key(mkey, p.N, kkey, nbatch, flags);
   std::lock_guard<std::mutex> lock(g_tune_mutex);
   if (!g_tune_file_read) tune_file_read();
   auto it = g_tuned.find(key);
