@@ -473,7 +473,7 @@ def main():
         os.environ["VQ3_VGGT_ROW_SPLIT"] = "0"  # (likewise the tower's second stream: one chain per block while the events are in)
         # one group of the deferred weight-gradient schedule (every projection's weight-gradient GEMM runs over nroof micro-batches'
         # rows): per-step figures below are the group's totals / nroof
-        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)) * max(1, trainer.text_group), accum))
+        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)) * max(1, trainer.pass_size(accum)), accum))
         run_window(nroof)       # (the serial schedule's shapes are tuned before the events go in)
         torch.cuda.synchronize()
         ops.GEMM_PROFILE = []
@@ -512,7 +512,7 @@ def main():
                 "algorithmic_bytes_per_launch": round(by / nlaunch), "launches_per_step": round(nlaunch, 1), "avg_launch_us": round(ms * 1e3 / nlaunch, 2),
                 "gemm_ms_per_step": round(ms, 2), "gemm_tflop_per_step": round(fl / 1e12, 3)}
     elif world > 1:
-        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)) * max(1, trainer.text_group), accum))
+        nroof = max(1, min(int(getattr(model.text_model, "_wd_depth", 1)) * max(1, trainer.pass_size(accum)), accum))
         run_window(nroof)       # keep collectives matched across ranks
         run_window(nroof)
     if use_dist:
@@ -527,9 +527,9 @@ def main():
             "config": {"workload": ("Stage-1 ScanQA bf16: VGGT-1B aggregator @%dpx x %d view(s) + 128-latent/6-layer "
                                     "Perceiver + Qwen3-4B fwd+bwd + RCCL all-reduce + AdamW(fp32 master); random-init "
                                     "weights; a step = one micro-batch of %d samples, run %d micro-batches per forward/backward pass "
-                                    "with each micro-batch's loss normalised by its own labelled rows" % (args.image_size, V, B, trainer.text_group)),
+                                    "with each micro-batch's loss normalised by its own labelled rows" % (args.image_size, V, B, trainer.pass_size(accum))),
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": L, "views": V,
-                       "grad_accum": accum, "optimizer_steps_timed": len(cycles), "micro_batches_per_pass": int(trainer.text_group),
+                       "grad_accum": accum, "optimizer_steps_timed": len(cycles), "micro_batches_per_pass": int(trainer.pass_size(accum)),
                        "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
                        "trim_padding": bool(args.trim_pad), "fp8_text_forward": bool(args.fp8),
                        "train_projector": bool(args.train_projector), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},

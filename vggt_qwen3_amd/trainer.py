@@ -86,7 +86,8 @@ class Stage1Trainer:
             # 10 runs in passes of 10 - [12000, 2560] outputs are 470 tiles of 256 x 256 = 1.84 rounds of 256 CUs (92 % full) where 9600 rows
             # give 380 tiles = 1.48 rounds (74 %), and a window of 20 is two whole passes instead of 8 + 8 + 4 (same box, alternating runs:
             # 137.0 / 137.7 -> 148.5 / 147.6 samples/s at grad_accum 20; 124 GB peak instead of 114)
-            text_group = int(os.environ.get("VQ3_TEXT_GROUP", "10" if (grad_accum >= 10 and grad_accum % 10 == 0) else "8"))
+            # text_group is the CAP; pass_size() cuts a window into equal passes under it (32 -> 4 x 8, 20 -> 2 x 10, 18 -> 2 x 9)
+            text_group = int(os.environ.get("VQ3_TEXT_GROUP", "10"))
         self.text_group = max(1, text_group)
         self._merged_pending: List = []     # [(batch dict, loss)] of a merged pass, handed out by the following micro_step() calls
         self._opt_due = False               # the merged pass held the window's boundary: AdamW runs when its last loss is handed out
@@ -154,6 +155,15 @@ class Stage1Trainer:
         if not hasattr(model, "_trainers"):
             model._trainers = []
         model._trainers.append(weakref.ref(self))
+
+    def pass_size(self, remaining: int) -> int:
+        """Micro-batches of the next merged pass when `remaining` are left in the accumulation window: the window's rest is cut into the
+        fewest passes of at most `text_group` micro-batches, of equal size up to one (32 -> 8 + 8 + 8 + 8 and 20 -> 10 + 10 at the default
+        cap of 10, 18 -> 9 + 9 rather than 8 + 8 + 2: a short last pass is the one-micro-batch regime again - every [rows, 2560] output of
+        a 2-micro-batch pass is 100 tiles for 256 CUs)."""
+        cap = max(1, self.text_group)
+        passes = (remaining + cap - 1) // cap
+        return max(1, (remaining + passes - 1) // passes)
 
     def set_schedule(self, *, text_group: Optional[int] = None, grad_accum: Optional[int] = None) -> None:
         """Change micro-batches per pass and / or per optimiser step between two accumulation windows (bench.py times the same job
@@ -226,7 +236,7 @@ class Stage1Trainer:
         k = self.micro % self.grad_accum
         members = [batch]
         if self.text_group > 1 and upcoming:
-            cand = [batch] + list(upcoming)[: min(self.text_group, self.grad_accum - k) - 1]     # never across a window boundary
+            cand = [batch] + list(upcoming)[: self.pass_size(self.grad_accum - k) - 1]           # never across a window boundary
             if len(cand) > 1 and self._mergeable(cand):
                 members = cand
         gsize = len(members)
