@@ -370,3 +370,30 @@ def test_trainer_batch_merge_helpers():
     assert again is merged                                            # same batch objects: same merged tensors (memoised host facts hit)
     other, _ = Stage1Trainer._merge(holder, [a, c, b])
     assert other is not merged and torch.equal(other["input_ids"][2:4], c["input_ids"])
+
+
+def test_trainer_pass_sizes_cut_a_window_into_equal_passes():
+    """Stage1Trainer.pass_size: what is left of an accumulation window goes into the fewest passes of at most `text_group` micro-batches,
+    equal up to one - never a short last pass (a pass of 2 micro-batches is the one-micro-batch regime again), never across the window."""
+    from types import SimpleNamespace
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+
+    def passes(window, cap):
+        tr, out, left = SimpleNamespace(text_group=cap), [], window
+        while left:
+            g = Stage1Trainer.pass_size(tr, left)
+            assert 1 <= g <= min(cap, left)
+            out.append(g)
+            left -= g
+        return out
+
+    assert passes(32, 10) == [8, 8, 8, 8]
+    assert passes(20, 10) == [10, 10]
+    assert passes(18, 10) == [9, 9]
+    assert passes(21, 10) == [7, 7, 7]
+    assert passes(8, 10) == [8] and passes(1, 10) == [1] and passes(5, 1) == [1] * 5
+    assert passes(5, 3) == [3, 2]                       # (tests/test_trainer_gpu.py::test_merged_micro_batches_match_one_by_one runs this one)
+    for w in range(1, 70):
+        for cap in (1, 3, 8, 10, 16):
+            p = passes(w, cap)
+            assert sum(p) == w and max(p) - min(p) <= 1 and len(p) == -(-w // cap)
