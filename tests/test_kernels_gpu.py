@@ -79,7 +79,7 @@ def test_gemm_epilogues(ops):
     assert _relerr(C, base + C0) < 1e-5
 
 
-@pytest.mark.parametrize("cfg", [20, 21, 22, 23, 11, 13, 7, 9, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [20, 21, 22, 23, 24, 11, 13, 7, 9, 15, 16, 17])
 def test_gemm_forced_configs_with_epilogues(ops, cfg):
     """Every tile configuration behind vq3_gemm_bf16_nt (20 = the 256x256 8-phase kernel; 11 / 13 / 7 / 9 = loader-wave and
     2-stage kernels) through the whole epilogue surface - bias, GELU, LayerScale, residual, accumulate, f32 output - with M and N
@@ -87,7 +87,7 @@ def test_gemm_forced_configs_with_epilogues(ops, cfg):
     try:
         ops.gemm_force_config(cfg)
         shapes = ((300, 520, 192), (1029, 1024, 1024), (257, 264, 64))
-        if cfg in (21, 22, 23):
+        if cfg in (21, 22, 23, 24):
             # more tiles than CUs: the two-phase kernels are persistent (a workgroup walks several tiles and requests the next tile's
             # first K tiles during the current epilogue) - 65 x 8 / 129 x 4 tiles, ragged last row tile, 1 / 3 / 4 K tiles per tile
             shapes += ((16500, 1024, 256), (16500, 1000, 64), (33000, 520, 192))
@@ -159,7 +159,7 @@ def test_gemm_whole_rounds_plus_row_tail(ops):
         ops.gemm_force_config(-3)
 
 
-@pytest.mark.parametrize("cfg", [-3, 20, 21, 22, 23, 11, 13, 7, 30])
+@pytest.mark.parametrize("cfg", [-3, 20, 21, 22, 23, 24, 11, 13, 7, 30])
 def test_gemm_layernorm_fold(ops, cfg):
     """LayerNorm folded into the GEMMs either side of it (vq3_gemm_bf16_nt_ln): the producer (residual GEMM) leaves per-row
     (sum, sum of squares) over 128-column groups of what it stored, the consumer reads the RAW rows and applies
@@ -167,7 +167,7 @@ def test_gemm_layernorm_fold(ops, cfg):
     configuration; M with a ragged last tile; GELU on the consumer; statistics also from vq3_rowstats128 and bit-identical twice."""
     try:
         ops.gemm_force_config(cfg)
-        M, C, N2 = (16500 if cfg in (30, 21, 22, 23) else 1029), 1024, (1024 if cfg in (21, 22, 23) else 512)
+        M, C, N2 = (16500 if cfg in (30, 21, 22, 23, 24) else 1029), 1024, (1024 if cfg in (21, 22, 23, 24) else 512)
         eps = 1e-5
         h = _rand((M, 256), 0.5, seed=1); Wp = _rand((C, 256), 0.3, seed=2)
         R = _rand((M, C), 1.0, seed=3) + 0.7                      # non-zero row means
@@ -301,7 +301,7 @@ def test_gemm_swiglu_bwd_epilogue_equals_two_launches(ops, transB):
     assert _relerr(got[:, :I], g32.grad) < 1e-2 and _relerr(got[:, I:], u32.grad) < 1e-2
 
 
-@pytest.mark.parametrize("cfg", [-3, 20, 21, 22])
+@pytest.mark.parametrize("cfg", [-3, 20, 21, 22, 24])
 @pytest.mark.parametrize("M,H,I", [(300, 256, 384), (1200, 2560, 9728), (77, 128, 128)])
 def test_gemm_swiglu_fwd_epilogue_equals_two_launches(ops, cfg, M, H, I):
     """vq3_gemm_swiglu_fwd (gate|up projection with silu(gate) * up in its epilogue) against the two launches it replaces - vq3_gemm_bf16_nt

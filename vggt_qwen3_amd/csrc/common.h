@@ -25,8 +25,21 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 // round a float through bf16 (emulates a PyTorch op that returns a bf16 tensor)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// two floats -> one dword of two bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN). Written as
+// two scalar casts + shift + or, hipcc 7.2 emits two conversions, a shift and an SDWA or - four instructions for every pair of every
+// epilogue and element-wise kernel.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 vq3_bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, vq3_bf16x2_t));
+}
+__device__ __forceinline__ f32x2_t unpack2bf(uint32_t u) {
+  return f32x2_t{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+// a pair rounded through bf16 (three instructions: the conversion, a shift and a mask)
+__device__ __forceinline__ f32x2_t rbf2(f32x2_t v) {
+  const uint32_t u = pack2bf(v[0], v[1]);
+  return f32x2_t{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -75,7 +88,6 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // the result is rounded to bf16 (2^-9 relative) right after. No v_rcp, no log2(e) multiply, none of libm erff's range checks:
 // on the VGGT fc1 GEMM (25 M outputs per launch, one workgroup per CU: nothing overlaps the epilogue) the activation is what the
 // tile's tail costs - 18.6 us of an 88.6 us launch with the Abramowitz-Stegun 7.1.26 form (v_rcp + v_exp + 12 scalar-lane ops).
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
   const f32x2_t a = {fminf(fabsf(x[0]), 5.5f), fminf(fabsf(x[1]), 5.5f)};
   f32x2_t q = {-1.921234625e-06f, -1.921234625e-06f};

@@ -280,6 +280,7 @@ int launch_candidate(GemmParams p, int cand, int transA, int transB, int nbatch,
   if (cand == 30) return launch_split_rows(p, nbatch, s);
   if (cand >= 20 && cand <= 22) return launch_gemm_v6(p, cand - 20, nbatch, s);
   if (cand == 23) return launch_gemm_v8(p, nbatch, s);          // (-1: outside its contract - the tuner skips it)
+  if (cand == 24) return launch_gemm_v7(p, nbatch, s);          // (likewise)
   return launch_gemm_v2(p, cand, nbatch, s);
 }
 
@@ -512,8 +513,17 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   }
   if (p.epi == 3) {
     // the 8-phase kernels only (the epilogue needs gate and up of a feature in ONE tile: gemm6.hip stages the two weight row ranges)
-    int cfg = (g_forced_cfg >= 20 && g_forced_cfg <= 22) ? g_forced_cfg : 20;
+    int cfg = ((g_forced_cfg >= 20 && g_forced_cfg <= 22) || g_forced_cfg == 24) ? g_forced_cfg : 20;
     if (g_forced_cfg == -3 && (long)d->M * d->N * d->K >= (1L << 24)) cfg = tuned_choice(p, 0, 0, nbatch, s, {20, 21, 22}, 20);
+    if (cfg == 24) {
+      const int rc7 = launch_gemm_v7(p, nbatch, s);
+      if (rc7 > 0) return rc7;
+      if (rc7 == 0) {
+        VQ3_CHECK_LAUNCH("gemm_swiglu_fwd(v7)");
+        return 0;
+      }
+      cfg = 20;
+    }
     const int rc = launch_gemm_v6(p, cfg - 20, nbatch, s);
     if (rc) return rc;
     VQ3_CHECK_LAUNCH("gemm_swiglu_fwd(v6)");
@@ -540,6 +550,15 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
       return 0;
     }
     cfg = 13;      // outside v8's contract: a kernel that takes everything
+  }
+  if (cfg == 24) {
+    const int rc = launch_gemm_v7(p, nbatch, s);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      VQ3_CHECK_LAUNCH("gemm_bf16_nt(v7)");
+      return 0;
+    }
+    cfg = 13;      // outside v7's contract: a kernel that takes everything
   }
   if (cfg == 30) {
     const int rc = launch_split_rows(p, nbatch, s);

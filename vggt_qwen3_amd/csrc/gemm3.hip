@@ -364,11 +364,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLOAD), (NSTAGE == 2 ? 2 : 1) * ((W
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = ln_apply(acc[i][j], mu[i], rs[i], cc[j]);
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        stage_quad<BN>(p, smem, wm * (BM / WM) + i * 16 + fr, wn * (BN / WN) + j * 16 + 4 * fq, acc[i][j], bias_v[j], cs_v[j]);
+#define V3_STAGE(ACT_, MODE_)                                                                                                       \
+  do {                                                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                                \
+        stage_quad<BN, ACT_, MODE_>(p, smem, wm * (BM / WM) + i * 16 + fr, wn * (BN / WN) + j * 16 + 4 * fq, acc[i][j], bias_v[j], cs_v[j]); \
+  } while (0)
+    VQ3_STAGE_DISPATCH(p, V3_STAGE);
+#undef V3_STAGE
     __syncthreads();
     staged_store<BM, BN>(p, smem, coff, roff, m0, n0, tid, 64 * NW);
     return;

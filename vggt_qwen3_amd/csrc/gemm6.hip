@@ -379,29 +379,42 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       if (nt > 1) stage_tile(1, smem + BUF);
       __builtin_amdgcn_sched_barrier(0);
     }
-    auto stage_all = [&](auto act_tag) {
-      constexpr int ACT = decltype(act_tag)::value;
+    auto stage_all = [&](auto act_tag, auto mode_tag, auto ln_tag) {
+      constexpr int ACT = decltype(act_tag)::value, MODE = decltype(mode_tag)::value;
+      constexpr bool LN = LN_FUSED && decltype(ln_tag)::value;
 #pragma unroll
       for (int i = 0; i < AH; ++i)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           float2 lv = float2{0.f, 1.f};
-          if (LN_FUSED && ln_on) lv = lnp[i * 128 + wr * 64 + mt * 16 + fr];
+          if (LN) lv = lnp[i * 128 + wr * 64 + mt * 16 + fr];
 #pragma unroll
           for (int j = 0; j < BH; ++j)
 #pragma unroll
             for (int nt2 = 0; nt2 < 2; ++nt2) {
               f32x4 a = acc[i * 4 + mt][j * 2 + nt2];
-              if (LN_FUSED && ln_on) a = ln_apply(a, lv.x, lv.y, cc[j * 2 + nt2]);
-              stage_quad<BN, ACT>(p, smem_c, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq, a, bias_r[j][nt2], cs_r[j][nt2]);
+              if (LN) a = ln_apply(a, lv.x, lv.y, cc[j * 2 + nt2]);
+              stage_quad<BN, ACT, MODE>(p, smem_c, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq, a, bias_r[j][nt2], cs_r[j][nt2]);
             }
           if (LN_FUSED) __builtin_amdgcn_sched_barrier(0);      // one 16-row group at a time (register pressure)
         }
     };
-    // the activation is dispatched ONCE (the fused q|k|v and SwiGLU-backward epilogues never carry one)
-    if (EK != 1 && EK != 2 && EK != 4 && p.act == 1) stage_all(std::integral_constant<int, 1>{});
-    else if (EK != 1 && EK != 2 && EK != 4 && p.act == 2) stage_all(std::integral_constant<int, 2>{});
-    else stage_all(std::integral_constant<int, 0>{});
+    // activation, bias / LayerScale / alpha and the LayerNorm fold are dispatched ONCE per tile (gemm_common.h: VQ3_STAGE_DISPATCH); the
+    // fused q|k|v and SwiGLU epilogues never carry an activation or LayerScale
+#define V6_STAGE(ACT_, MODE_)                                                                                                     \
+  do {                                                                                                                            \
+    if constexpr (EK == 3) stage_all(std::integral_constant<int, ACT_>{}, std::integral_constant<int, MODE_>{}, std::true_type{}); \
+    else if constexpr (EK == 1) {                                                                                                 \
+      if (ln_on) stage_all(std::integral_constant<int, ACT_>{}, std::integral_constant<int, MODE_>{}, std::true_type{});          \
+      else stage_all(std::integral_constant<int, ACT_>{}, std::integral_constant<int, MODE_>{}, std::false_type{});               \
+    } else stage_all(std::integral_constant<int, ACT_>{}, std::integral_constant<int, MODE_>{}, std::false_type{});               \
+  } while (0)
+    if constexpr (EK == 2 || EK == 4) V6_STAGE(0, 0);            // (host: no bias, no LayerScale, alpha == 1)
+    else if constexpr (EK == 1) {
+      if (p.bias && p.alpha == 1.f) V6_STAGE(0, 1);
+      else V6_STAGE(0, -1);
+    } else VQ3_STAGE_DISPATCH(p, V6_STAGE);
+#undef V6_STAGE
     V6_STAMP(6);    // this wave's quads are in the C image
     if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's K tiles 0 and 1 has landed
     __syncthreads();

@@ -332,35 +332,46 @@ __device__ __forceinline__ int cstage_off(int row, int chunk) {
 // ACT >= 0: the activation is a compile-time constant (the caller dispatches on p.act ONCE, outside its quad loops: with the run-time
 // form every one of a thread's 32 quads carries all three activation bodies, and the 256 x 256 kernel's epilogue was 22 000 instructions
 // for an 8 000-instruction instruction cache line budget); -1: run-time p.act
-template <int BN, int ACT = -1>
+// MODE >= 0: which of alpha / bias / LayerScale apply is a compile-time constant too - bit 0 bias, bit 1 LayerScale, bit 2 alpha != 1
+// (the caller dispatches ONCE per tile on the combinations its launches use; -1: run-time, from p). Round 4: with the run-time form
+// hipcc turned the wave-uniform `if (p.bias)` / `if (p.colscale)` into per-element v_cndmask selects and every intermediate rounding was
+// followed by a second conversion at the final pack: 45 vector instructions per quad with no activation at all (stage C: 4-6 us of a
+// 45 us tile at K = 1024). The roundings themselves are unchanged: after the bias, after the activation, after LayerScale - the LAST of
+// them is the pack's own v_cvt_pk_bf16_f32.
+template <int BN, int ACT = -1, int MODE = -1>
 __device__ __forceinline__ void stage_quad(const GemmParams& p, char* smem, int ml, int nl, const f32x4& a, const f32x4& bias_v,
                                            const f32x4& cs_v) {
   const int act = ACT >= 0 ? ACT : p.act;
-  float v[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
-  if (p.bias) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += bias_v[r];
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-  if (act == 1) {
-    const f32x2_t g0 = gelu_erf2(f32x2_t{v[0], v[1]}), g1 = gelu_erf2(f32x2_t{v[2], v[3]});
-    v[0] = rbf(g0[0]); v[1] = rbf(g0[1]); v[2] = rbf(g1[0]); v[3] = rbf(g1[1]);
-  } else if (act) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = rbf(apply_act(v[r], act));
-  }
-  if (p.colscale) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = rbf(v[r] * cs_v[r]);
+  const bool has_bias = MODE >= 0 ? (MODE & 1) != 0 : p.bias != nullptr;
+  const bool has_cs = MODE >= 0 ? (MODE & 2) != 0 : p.colscale != nullptr;
+  const bool unit_alpha = MODE >= 0 ? (MODE & 4) == 0 : false;
+  f32x2_t v0 = {a[0], a[1]}, v1 = {a[2], a[3]};
+  if (!unit_alpha) { v0 *= p.alpha; v1 *= p.alpha; }
+  if (has_bias) { v0 += f32x2_t{bias_v[0], bias_v[1]}; v1 += f32x2_t{bias_v[2], bias_v[3]}; }
+  if (act || has_cs) {
+    v0 = rbf2(v0); v1 = rbf2(v1);
+    if (act == 1) { v0 = gelu_erf2(v0); v1 = gelu_erf2(v1); }
+    else if (act) { v0 = f32x2_t{apply_act(v0[0], act), apply_act(v0[1], act)}; v1 = f32x2_t{apply_act(v1[0], act), apply_act(v1[1], act)}; }
+    if (has_cs) {
+      if (act) { v0 = rbf2(v0); v1 = rbf2(v1); }
+      v0 *= f32x2_t{cs_v[0], cs_v[1]}; v1 *= f32x2_t{cs_v[2], cs_v[3]};
+    }
   }
   u32x2 o;
-  o[0] = pack2bf(v[0], v[1]);
-  o[1] = pack2bf(v[2], v[3]);
+  o[0] = pack2bf(v0[0], v0[1]);
+  o[1] = pack2bf(v1[0], v1[1]);
   *reinterpret_cast<u32x2*>(smem + cstage_off<BN>(ml, nl >> 3) + ((nl & 4) << 1)) = o;
 }
+// the (ACT, MODE) pairs the launches of a step use get a compiled form each; anything else takes the run-time form
+#define VQ3_STAGE_DISPATCH(P, CALL)                                                                           \
+  do {                                                                                                        \
+    const int mode__ = ((P).bias ? 1 : 0) | ((P).colscale ? 2 : 0) | ((P).alpha != 1.f ? 4 : 0);              \
+    if ((P).act == 0 && mode__ == 0) CALL(0, 0);                                                              \
+    else if ((P).act == 0 && mode__ == 1) CALL(0, 1);                                                         \
+    else if ((P).act == 1 && mode__ == 1) CALL(1, 1);                                                         \
+    else if ((P).act == 0 && mode__ == 3) CALL(0, 3);                                                         \
+    else CALL(-1, -1);                                                                                        \
+  } while (0)
 
 template <int BM, int BN>
 __device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* smem, int m0, int n0, int tid, int nthreads);
@@ -519,23 +530,20 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
         const int row = row0 + u * rpp, m = m0 + row;
         if (!(row < BM && m < p.M)) continue;
         const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row, c));
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[2 * k] = bf2f((bf16_t)(sv[k] & 0xffff)); v[2 * k + 1] = bf2f((bf16_t)(sv[k] >> 16)); }
-        if (R) {
+        u32x4 o = sv;
+        if (R || p.accumulate) {
+          // (a pair per step; the LAST rounding is the pack's own conversion: rbf(x) packed again is x's packing)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            v[2 * k] = rbf(v[2 * k] + bf2f((bf16_t)(rv[u][k] & 0xffff)));
-            v[2 * k + 1] = rbf(v[2 * k + 1] + bf2f((bf16_t)(rv[u][k] >> 16)));
+            f32x2_t v = unpack2bf(sv[k]);
+            if (R) {
+              v += unpack2bf(rv[u][k]);
+              if (p.accumulate) v = rbf2(v);
+            }
+            if (p.accumulate) v += unpack2bf(cv[u][k]);
+            o[k] = pack2bf(v[0], v[1]);
           }
         }
-        if (p.accumulate) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { v[2 * k] += bf2f((bf16_t)(cv[u][k] & 0xffff)); v[2 * k + 1] += bf2f((bf16_t)(cv[u][k] >> 16)); }
-        }
-        u32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = pack2bf(v[2 * k], v[2 * k + 1]);
         *reinterpret_cast<u32x4*>(C + (long)m * p.ldc + n) = o;
         if (p.st_out) {
           // (sum, sum of squares) of the 128 stored values around this thread's 8: the 16 lanes of a 16-lane row hold them
@@ -732,6 +740,9 @@ int launch_gemm_v6(GemmParams& p, int shape, int nbatch, hipStream_t stream);   
 // v8 (128x256 tile, compute / service wave teams, row-wise epilogue under the next tile's main loop), defined in gemm8.hip.
 // Returns -1 (nothing launched) when the problem is outside its contract: the caller picks another kernel.
 int launch_gemm_v8(GemmParams& p, int nbatch, hipStream_t stream);
+// v7 (256x128 tile, four waves, two workgroups per CU: a tile's epilogue runs under the co-resident workgroup's main loop), gemm7.hip.
+// Returns -1 (nothing launched) when the problem is outside its contract: the caller picks another kernel.
+int launch_gemm_v7(GemmParams& p, int nbatch, hipStream_t stream);
 // v3 (any operand layout, K % 8 == 0), defined in gemm3.hip. nstage: 2 or 3.
 int launch_gemm_v3(GemmParams& p, int transA, int transB, int nstage, int nbatch, hipStream_t stream);
 
