@@ -369,6 +369,16 @@ def main():
                 "micro_batches_per_pass": 1, "grad_accum": accum, "loss": round(float(l1.item()), 4),
                 "note": "one micro-batch of %d samples per forward/backward pass, as the reference's loop runs them; the vision tower still "
                         "shares one pass per %d micro-batches" % (B, trainer.vision_group)}
+        if accum != 32:
+            # the reference's own window (configs/stage1_3d.yaml:31: grad_accum 32) under the trainer's default pass rule, whatever --steps
+            # made of the headline's window: one warm-up window, one timed window = one optimiser step
+            trainer.set_schedule(text_group=tg0, grad_accum=32)
+            d32, l32 = timed_windows([32], [32])
+            sched_variants["accum32_variant"] = {
+                "value": round(world * B * 32 / d32, 3), "unit": "samples/s", "ms_per_step": round(d32 / 32 * 1e3, 2), "steps": 32, "grad_accum": 32,
+                "micro_batches_per_pass": int(trainer.pass_size(32)), "loss": round(float(l32.item()), 4),
+                "note": "one accumulation window of the reference's schedule (32 micro-batches of %d, one all-reduce + AdamW), cut into "
+                        "passes as Stage1Trainer.pass_size() does" % B}
         n1 = min(args.steps, 16)
         trainer.set_schedule(text_group=1, grad_accum=1)
         if use_dist:

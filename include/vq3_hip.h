@@ -416,7 +416,8 @@ int vq3_qwen_flash_bwd_b(const void* Q, const void* K, const void* V, const void
 
 /* Benchmarking / test hook for vq3_gemm_bf16_nt's kernel choice on NT, K % 64 == 0 shapes: cfg = -3 restores the automatic
  * choice (the default), -1 the register-staged reference kernel, 0..14 a gemm2.hip tile configuration, 20 / 21 / 22 the
- * 8-phase kernels of gemm6.hip (256x256 / 256x128 / 128x256 tiles), 23 the overlapped-epilogue kernel of gemm8.hip; 102 / 103 / 105 pin the schedule of the any-layout kernel
+ * 8-phase kernels of gemm6.hip (256x256 / 256x128 / 128x256 tiles), 24 the two-workgroups-per-CU 256x128 kernel of gemm7.hip, 25 the
+ * 256x256 kernel with the last round's tiles split along K, 30 whole rounds of 256x256 tiles + a row tail; 102 / 103 / 105 pin the schedule of the any-layout kernel
  * (gemm3.hip: 128x128 2-stage, 128x128 loader ring, 256x128 loader ring; -3 releases it too). Process-wide; not meant for concurrent use with launches on other threads. */
 int vq3_gemm_force_config(int32_t cfg);
 
@@ -428,6 +429,16 @@ int vq3_gemm_force_config(int32_t cfg);
  * There is no counterpart in the reference (cuBLAS picks its own rasterisation behind torch.nn.functional.linear). */
 int vq3_gemm_tile_order(int32_t M, int32_t N, int32_t bm, int32_t bn, int32_t wg_per_cu, int32_t* xm_out, int32_t* band_out,
                         int32_t* order);
+
+/* Last-round K split of the 256x256 GEMM kernel (cfg 25; chosen by measurement like every other configuration). An M x N output is
+ * ceil(M/256) * ceil(N/256) tiles; when the last round of `ncu` CUs would be at most half full, its `rem` tiles are cut into `slices`
+ * K ranges run by rem * slices workgroups: all but the last slice of a tile leave f32 partial tiles in a per-stream workspace (allocated on
+ * first use outside graph capture) and count themselves in, the last slice adds them and runs the epilogue. No counterpart in the reference
+ * (cuBLAS's stream-K is its own). vq3_gemm_split_plan is host-only (no launch): writes the plan, *slices = 0 where the split does not apply.
+ * vq3_gemm_split_status synchronises `stream` and writes 1 to *gave_up if a bounded wait of a split launch on it ever expired (a broken
+ * launch; results of that launch are then incomplete), else 0. */
+int vq3_gemm_split_plan(int32_t M, int32_t N, int32_t K, int32_t ncu, int32_t* full_out, int32_t* rem_out, int32_t* slices_out);
+int vq3_gemm_split_status(void* stream, int32_t* gave_up);
 
 #ifdef __cplusplus
 }

@@ -92,3 +92,20 @@ def test_gemm_tile_order_is_a_bijection_and_blocks_per_xcd():
         strips.sort()
         width = -(-mt // 8)
         assert all(lo2 > lo1 and hi1 - lo1 < 2 * width for (lo1, hi1), (lo2, _) in zip(strips, strips[1:])), strips
+
+
+def test_gemm_split_plan_host_side():
+    """vq3_gemm_split_plan (cfg 25): which launches cut their last round of 256 x 256 tiles along K, and how - host arithmetic only."""
+    from vggt_qwen3_amd import ops
+    assert ops.gemm_split_plan(9600, 2560, 4096) == (256, 124, 2)          # o-projection of a pass of 8 micro-batches: 380 tiles
+    assert ops.gemm_split_plan(1200, 2560, 2560) == (0, 50, 4)             # one micro-batch: 50 tiles x 4 slices of 10 K tiles
+    assert ops.gemm_split_plan(12000, 2560, 4096)[2] == 0                  # 470 tiles: the last round is 84 % full
+    assert ops.gemm_split_plan(9600, 2560, 512)[2] == 0                    # 8 K tiles: nothing to split
+    assert ops.gemm_split_plan(2048, 2048, 4096)[2] == 4                   # 64 tiles x 4
+    for (M, N, K) in [(9600, 2560, 9728), (2000, 2560, 1088), (300, 300, 1024), (40000, 1024, 1024)]:
+        full, rem, sl = ops.gemm_split_plan(M, N, K)
+        tiles = -(-M // 256) * -(-N // 256)
+        if sl:
+            per = -(-(K // 64) // sl)
+            assert full + rem == tiles and full % 256 == 0 and 2 <= sl <= 4 and rem * sl <= 256
+            assert (K // 64) - (sl - 1) * per >= 1 and K // 64 // sl >= 8

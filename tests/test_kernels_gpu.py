@@ -79,7 +79,7 @@ def test_gemm_epilogues(ops):
     assert _relerr(C, base + C0) < 1e-5
 
 
-@pytest.mark.parametrize("cfg", [20, 21, 22, 23, 24, 11, 13, 7, 9, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [20, 21, 22, 24, 25, 11, 13, 7, 9, 15, 16, 17])
 def test_gemm_forced_configs_with_epilogues(ops, cfg):
     """Every tile configuration behind vq3_gemm_bf16_nt (20 = the 256x256 8-phase kernel; 11 / 13 / 7 / 9 = loader-wave and
     2-stage kernels) through the whole epilogue surface - bias, GELU, LayerScale, residual, accumulate, f32 output - with M and N
@@ -87,7 +87,7 @@ def test_gemm_forced_configs_with_epilogues(ops, cfg):
     try:
         ops.gemm_force_config(cfg)
         shapes = ((300, 520, 192), (1029, 1024, 1024), (257, 264, 64))
-        if cfg in (21, 22, 23, 24):
+        if cfg in (21, 22, 24, 25):
             # more tiles than CUs: the two-phase kernels are persistent (a workgroup walks several tiles and requests the next tile's
             # first K tiles during the current epilogue) - 65 x 8 / 129 x 4 tiles, ragged last row tile, 1 / 3 / 4 K tiles per tile
             shapes += ((16500, 1024, 256), (16500, 1000, 64), (33000, 520, 192))
@@ -127,6 +127,41 @@ def test_gemm_forced_configs_with_epilogues(ops, cfg):
         ops.gemm_force_config(-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(9600, 2560, 4096), (1200, 2560, 2560), (2000, 2560, 1088), (5000, 2560, 1024), (9600, 2560, 9728)])
+def test_gemm_last_round_split(ops, M, N, K):
+    """cfg 25 (gemm6.hip): the tiles of a last round that is at most half full are cut along K over the idle CUs - 9600 x 2560 is 380 tiles of
+    256 x 256 = one round of 256 + 124 tiles x 2 halves; 1200 x 2560 is 50 tiles x 4 slices; K = 1088 is 17 K tiles (9 + 8); 5000 x 2560 is 200
+    tiles (no split: the plain launch). Partial sums meet in f32, so the result equals the unsplit kernel's up to the order of the f32 sum;
+    the whole epilogue surface behind it; the bounded wait never gives up."""
+    full, rem, sl = ops.gemm_split_plan(M, N, K)
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    assert (sl == 0) == (M == 5000) and (sl == 0 or (full + rem == tiles and rem * sl <= 256 and K // 64 // sl >= 8))
+    A = _rand((M, K), 0.5, seed=3); W = _rand((N, K), 0.5, seed=4)
+    bias = _rand((N,), 1.0, F32, seed=5); cs = _rand((N,), 1.0, F32, seed=6)
+    R16 = _rand((M, N), 1.0, seed=7)
+    try:
+        ops.gemm_force_config(20)
+        ref_plain = ops.linear(A, W)
+        ref_epi = ops.linear(A, W, bias=bias, colscale=cs, residual=R16, act=ops.ACT_GELU, alpha=0.5)
+        ops.gemm_force_config(25)
+        for _ in range(3):                                     # (the arrival counts are zeroed per launch: repeatable)
+            out = ops.linear(A, W)
+            assert _relerr(out, ref_plain) < 2e-3 and _maxerr(out, ref_plain) <= 2 ** -7 * ref_plain.float().abs().max().item()
+        base = A.float() @ W.float().t()
+        assert _relerr(out, base) < 4e-3
+        out = ops.linear(A, W, bias=bias, colscale=cs, residual=R16, act=ops.ACT_GELU, alpha=0.5)
+        assert _relerr(out, ref_epi) < 2e-3
+        C = _rand((M, N), 1.0, seed=8); C0 = C.clone()
+        ops.linear(A, W, out=C, accumulate=True)
+        assert _relerr(C, base + C0.float()) < 4e-3
+        view = R16.clone()                                     # in-place residual (R is C), as the transformer blocks call it
+        ops.gemm_raw(A, W, view, M, N, K, K, K, N, R=view, ldr=N, c_off=0, r_off=0)
+        assert _relerr(view, (base.to(BF16).float() + R16.float())) < 4e-3
+        assert not ops.gemm_split_gave_up()
+    finally:
+        ops.gemm_force_config(-3)
+
+
 def test_gemm_whole_rounds_plus_row_tail(ops):
     """cfg 30 (gemm.hip: launch_split_rows): the 256 x 256 kernel on the row tiles that fill whole rounds of the chip + a second launch
     for the remaining rows - here 65 x 4 = 260 tiles = one round of 256 CUs + 4: rows 0..16383 and a 116-row tail. Same contract as
@@ -159,7 +194,7 @@ def test_gemm_whole_rounds_plus_row_tail(ops):
         ops.gemm_force_config(-3)
 
 
-@pytest.mark.parametrize("cfg", [-3, 20, 21, 22, 23, 24, 11, 13, 7, 30])
+@pytest.mark.parametrize("cfg", [-3, 20, 21, 22, 24, 11, 13, 7, 30])
 def test_gemm_layernorm_fold(ops, cfg):
     """LayerNorm folded into the GEMMs either side of it (vq3_gemm_bf16_nt_ln): the producer (residual GEMM) leaves per-row
     (sum, sum of squares) over 128-column groups of what it stored, the consumer reads the RAW rows and applies
@@ -167,7 +202,7 @@ def test_gemm_layernorm_fold(ops, cfg):
     configuration; M with a ragged last tile; GELU on the consumer; statistics also from vq3_rowstats128 and bit-identical twice."""
     try:
         ops.gemm_force_config(cfg)
-        M, C, N2 = (16500 if cfg in (30, 21, 22, 23, 24) else 1029), 1024, (1024 if cfg in (21, 22, 23, 24) else 512)
+        M, C, N2 = (16500 if cfg in (30, 21, 22, 24) else 1029), 1024, (1024 if cfg in (21, 22, 24) else 512)
         eps = 1e-5
         h = _rand((M, 256), 0.5, seed=1); Wp = _rand((C, 256), 0.3, seed=2)
         R = _rand((M, C), 1.0, seed=3) + 0.7                      # non-zero row means

@@ -438,3 +438,27 @@ def test_merged_group_keeps_counters_and_weights_in_phase():
     tr.flush_pending()
     assert tr.micro == 6 and tr.opt_step == 2 and not tr._opt_due and not torch.equal(model.text_model.flat_w, w1)
     assert tr.flush_pending() == [] and tr.opt_step == 2
+
+
+def test_set_schedule_never_rewinds_the_micro_batch_counter():
+    """set_schedule() between two windows keeps `micro` (max_steps, step_N names, the saved state count from it); a new
+    grad_accum moves it UP to the next window boundary of the new schedule, so boundaries and the counter stay in phase."""
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z, m, build, batch = _vlm()
+    model = build()
+    model.vision_model = _Tower(model.vision_model.agg)
+    tr = Stage1Trainer(model, lr=1e-3, proj_lr=1e-3, weight_decay=0.0, warmup_ratio=0.0, max_steps=100, grad_accum=2, text_group=1)
+    for _ in range(4):
+        tr.micro_step(dict(batch))
+    assert tr.micro == 4 and tr.opt_step == 2
+    tr.set_schedule(text_group=2)                       # same window: the counter is untouched
+    assert tr.micro == 4
+    tr.set_schedule(grad_accum=3)                       # 4 -> 6: the next multiple of the new window, never back to 0 or 3
+    assert tr.micro == 6 and tr.micro % tr.grad_accum == 0
+    for i in range(3):
+        tr.micro_step(dict(batch))
+        assert tr.opt_step == (3 if i == 2 else 2)      # the optimiser step closes the new window of 3
+    assert tr.micro == 9
+    tr.micro_step(dict(batch))
+    with pytest.raises(RuntimeError):
+        tr.set_schedule(grad_accum=2)                   # mid-window: refused

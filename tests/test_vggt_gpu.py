@@ -219,7 +219,7 @@ def test_dino_backbone_vs_transformers_golden():
 
 
 @pytest.mark.parametrize("use_norm,use_rope", [(True, True), (False, False)])
-@pytest.mark.parametrize("cfg", [-3, 20, 23, 24, 11, 7])
+@pytest.mark.parametrize("cfg", [-3, 20, 24, 11, 7])
 def test_fused_qkv_epilogue_equals_linear_plus_vit_qkprep(use_norm, use_rope, cfg):
     """vq3_gemm_vit_qkv (head split + q/k LayerNorm + 2-D RoPE in the GEMM epilogue, qkv never materialised) against the two-launch
     form it replaces - vq3_gemm_bf16_nt followed by vq3_vit_qkprep - on the same inputs, for every tile configuration that can be
@@ -280,8 +280,6 @@ def test_fused_qkv_epilogue_with_row_tail_launch():
         ref = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
         ops.gemm_force_config(30)
         got = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
-        ops.gemm_force_config(23)                        # the persistent overlapped-epilogue kernel: 130 x 12 tiles on 256 workgroups
-        got8 = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
         ops.gemm_force_config(24)                        # two workgroups per CU, 256 x 128 tiles: 65 x 12 tiles
         got7 = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
     finally:
@@ -292,10 +290,8 @@ def test_fused_qkv_epilogue_with_row_tail_launch():
         assert ((af - bf).norm() / bf.norm()).item() < 2e-3, name
         # the tail rows are the last 248 tokens of the last group
         assert ((af[-1, :, -248:] - bf[-1, :, -248:]).norm() / bf[-1, :, -248:].norm()).item() < 2e-3, name
-    for name, a, b in zip("QKV", got8, ref):
-        assert torch.equal(a, b), name                   # same arithmetic, same rounding points: bit-identical
     for name, a, b in zip("QKV", got7, ref):
-        assert torch.equal(a, b), name
+        assert torch.equal(a, b), name                   # same arithmetic, same rounding points: bit-identical
 
 
 def test_aggregator_is_batch_invariant():

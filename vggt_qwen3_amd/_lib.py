@@ -111,6 +111,8 @@ SIGNATURES = {
     "vq3_gelu_bwd": [c_p, c_p, c_p, i64, c_p],
     "vq3_gelu_fwd": [c_p, c_p, i64, c_p],
     "vq3_gemm_tile_order": [i32, i32, i32, i32, i32, c_p, c_p, c_p],
+    "vq3_gemm_split_plan": [i32, i32, i32, i32, c_p, c_p, c_p],
+    "vq3_gemm_split_status": [c_p, c_p],
     "vq3_pack_tokens": [c_p, c_p, c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p, c_p],
 }
 _RESTYPES = {"vq3_last_error": C.c_char_p, "vq3_target_arch": C.c_char_p}

@@ -279,8 +279,8 @@ int launch_candidate(GemmParams p, int cand, int transA, int transB, int nbatch,
   if (cand >= 100) return launch_gemm_v3(p, transA, transB, cand - 100, nbatch, s);
   if (cand == 30) return launch_split_rows(p, nbatch, s);
   if (cand >= 20 && cand <= 22) return launch_gemm_v6(p, cand - 20, nbatch, s);
-  if (cand == 23) return launch_gemm_v8(p, nbatch, s);          // (-1: outside its contract - the tuner skips it)
-  if (cand == 24) return launch_gemm_v7(p, nbatch, s);          // (likewise)
+  if (cand == 24) return launch_gemm_v7(p, nbatch, s);          // (-1: outside its contract - the tuner skips it)
+  if (cand == 25) return launch_gemm_v6(p, 3, nbatch, s);       // (likewise: 256 x 256 with the last round's tiles split along K)
   return launch_gemm_v2(p, cand, nbatch, s);
 }
 
@@ -422,6 +422,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   p.stamps = nullptr;
   p.nbw = 1;
   p.stagger = 0;
+  p.sk_full = p.sk_rem = p.sk_s = 0; p.sk_ws = nullptr; p.sk_cnt = nullptr;
   if (ve) {
     VQ3_CHECK_ARG(ve->Q && ve->K && ve->V, "gemm_vit_qkv: null output pointer");
     VQ3_CHECK_ARG(!d->transA && !d->transB && d->K % BK == 0 && !d->out_f32 && !d->accumulate && !d->R && !d->colscale && d->act == 0 &&
@@ -538,18 +539,8 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     if ((long)((d->M + 255) / 256) * ((d->N + 127) / 128) * nbatch >= 64) cands.push_back(21);
     if ((long)((d->M + 127) / 128) * ((d->N + 255) / 256) * nbatch >= 64) cands.push_back(22);
     if (split_rows_main(p, nbatch)) cands.push_back(30);
-    // (cfg 23, the overlapped-epilogue kernel of gemm8.hip, is not a candidate: correct, but 20-30 % behind cfg 20 / 30 on every
-    // shape measured - DESIGN.md section 9; vq3_gemm_force_config(23) selects it)
+    cands.push_back(25);          // (skipped by the tuner where the last-round split does not apply: the launcher returns -1)
     cfg = tuned_choice(p, 0, 0, nbatch, s, cands, cfg);
-  }
-  if (cfg == 23) {
-    const int rc = launch_gemm_v8(p, nbatch, s);
-    if (rc > 0) return rc;
-    if (rc == 0) {
-      VQ3_CHECK_LAUNCH("gemm_bf16_nt(v8)");
-      return 0;
-    }
-    cfg = 13;      // outside v8's contract: a kernel that takes everything
   }
   if (cfg == 24) {
     const int rc = launch_gemm_v7(p, nbatch, s);
@@ -559,6 +550,15 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
       return 0;
     }
     cfg = 13;      // outside v7's contract: a kernel that takes everything
+  }
+  if (cfg == 25) {
+    const int rc = launch_gemm_v6(p, 3, nbatch, s);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      VQ3_CHECK_LAUNCH("gemm_bf16_nt(v6, last round split)");
+      return 0;
+    }
+    cfg = 20;      // the split does not apply to this shape / stream state: the plain 256 x 256 launch
   }
   if (cfg == 30) {
     const int rc = launch_split_rows(p, nbatch, s);
@@ -647,6 +647,26 @@ extern "C" int vq3_gemm_tile_order(int32_t M, int32_t N, int32_t bm, int32_t bn,
       order[2 * i + 1] = n0 / bn;
     }
   }
+  return 0;
+}
+
+extern "C" int vq3_gemm_split_plan(int32_t M, int32_t N, int32_t K, int32_t ncu, int32_t* full_out, int32_t* rem_out, int32_t* slices_out) {
+  VQ3_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 64 == 0 && ncu >= 8 && slices_out, "gemm_split_plan: bad arguments");
+  GemmParams p{};
+  p.M = M; p.N = N; p.K = K;
+  int full = 0, rem = 0;
+  const int sl = gemm_split_plan(p, 1, ncu, &full, &rem);
+  *slices_out = sl >= 2 ? sl : 0;
+  if (full_out) *full_out = sl >= 2 ? full : 0;
+  if (rem_out) *rem_out = sl >= 2 ? rem : 0;
+  return 0;
+}
+
+extern "C" int vq3_gemm_split_status(void* stream, int32_t* gave_up) {
+  VQ3_CHECK_ARG(gave_up != nullptr, "gemm_split_status: null output");
+  const int r = gemm_split_gave_up((hipStream_t)stream);
+  VQ3_CHECK_ARG(r != -2, "gemm_split_status: could not read the stream's workspace");
+  *gave_up = r > 0 ? 1 : 0;
   return 0;
 }
 

@@ -20,6 +20,9 @@
 //     leading group passes on its way into phase p+1).
 //   * RAW: the vmcnt(6) of phase 4 sits before that phase's first barrier and retires every half-tile of tile t+1; tile
 //     t+1 is first read in the next phase, i.e. after a barrier every issuing wave reached after its wait.
+#include <map>
+#include <mutex>
+
 #include "gemm_common.h"
 
 namespace vq3gemm {
@@ -46,7 +49,10 @@ constexpr int HALF = 128 * 128;          // bytes per half-tile (128 rows x 64 k
 // 4 = SwiGLU forward (B = gate|up weight [2 I, K]: a tile multiplies BN/2 gate rows and the SAME BN/2 up rows, see set_offsets).
 // Compiled into ONE kernel they cost the 256 x 256 instantiation (256 VGPRs) 80 spilled registers in every launch's epilogue: the plain
 // fc1 launch (49 392 x 4096 x 1024) took 524 us with them and 443 us without (tools/gemm_stamps.py: "stage C" 13.1 -> 6.6 us per tile).
-template <int AH, int BH, bool OUT_F32, int EK = 0>
+// SPLIT (256 x 256, plain epilogue only): the launch's last, partly filled round of tiles is cut along K over the CUs it would leave idle
+// (GemmParams: sk_*). 9600 x 2560 outputs - every o / down projection and two of the four dgrads of a pass of 8 micro-batches - are 380
+// tiles = 1.48 rounds of 256 CUs: 124 tiles x 2 K halves run as ONE half-length round instead of a full one.
+template <int AH, int BH, bool OUT_F32, int EK = 0, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   constexpr bool HAS_LN = (EK == 1 || EK == 3);
   constexpr int BM = 128 * AH, BN = 128 * BH;
@@ -153,7 +159,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);  \
   } while (0)
 
-  const int nt = p.K / BK6;
+  int nt = p.K / BK6;
+  int sk_slice = -1, sk_j = 0;       // (SPLIT) this workgroup's K slice of tile sk_full + sk_j; -1: a whole tile
   // two-phase variants keep THREE K-tile buffers (3 x 48 KiB): tile t+2 is staged whole while tile t is multiplied, into the
   // buffer tile t-1 left a full tile ago. Slots: A0 A1 B (256 x 128) or A B0 B1 (128 x 256).
   auto stage_tile = [&](int t, char* buf) {
@@ -169,6 +176,23 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   };
   bool prefetched = false;         // this tile's first K tiles were requested during the previous tile's epilogue (and have landed)
   int tile = blockIdx.x;           // (< ntile: the grid never exceeds the tile count)
+  if constexpr (SPLIT) {
+    if (p.sk_s > 1 && tile >= p.sk_full) {
+      // workgroup sk_full + s * R8 + j, R8 = sk_rem rounded up to a multiple of 8: the slices of a tile run on the XCD whose L2 holds the
+      // panels its neighbours in the tile order share (workgroup id mod 8 = XCD under round-robin placement; speed only)
+      const int r8 = (p.sk_rem + 7) & ~7;
+      const int r = tile - p.sk_full;
+      sk_slice = r / r8;
+      sk_j = r - sk_slice * r8;
+      if (sk_j >= p.sk_rem) return;                  // (padding ids of a slice group)
+      tile = p.sk_full + sk_j;
+      const int per = (nt + p.sk_s - 1) / p.sk_s;
+      const int kt0 = sk_slice * per;
+      nt = nt - kt0 < per ? nt - kt0 : per;        // (the host keeps every slice non-empty)
+      A += (long)kt0 * BK6;
+      B += (long)kt0 * BK6;
+    }
+  }
   // Start-up stagger: every tile of a launch costs the same, so the CUs run in lockstep and reach their epilogues - the C-tile stores, the
   // residual reads - in the same microseconds: bursts of 32-64 MB against an otherwise idle memory system, with the MFMA pipes waiting
   // (tools/gemm_stamps.py: "issue stores" 13.7 us per tile with a residual). Workgroups of the first round wait (workgroup % 8) * stagger
@@ -318,6 +342,60 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
 
   // ---- epilogue
   V6_STAMP(2);      // main loop done
+  if constexpr (SPLIT) {
+    if (sk_slice >= 0) {
+      // partial tiles in the accumulators' own order: quad q of thread tid at [q][tid] (a wave instruction moves 1 KiB contiguous)
+      float* ws = p.sk_ws + (long)sk_j * (p.sk_s - 1) * (BM * BN);
+      if (sk_slice < p.sk_s - 1) {
+        // publish (cdna guide, Guideline 16 R1 / price list "publish-large"): WRITE-THROUGH (sc1) 16-byte stores - a 256 KiB partial tile
+        // behind plain stores + an agent-scope release costs the write-back of everything the XCD's L2 holds dirty (the neighbours' C
+        // tiles included) - every storing wave drains its own stores, the workgroup meets, ONE lane counts the slice in
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(ws + (long)sk_slice * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < AH * 4; ++i)
+#pragma unroll
+          for (int j = 0; j < BH * 2; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, (tid * 4 + (i * BH * 2 + j) * 2048) * 4, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.sk_cnt + sk_j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      // the last slice (highest workgroup id of the tile: dispatched last) adds the others' partials, then runs the usual epilogue.
+      // Bounded wait: all sk_rem * sk_s <= #CUs split workgroups can be resident together and the unsplit tiles ahead of them wait
+      // for nobody, so the count always arrives; the bound only turns a broken launch into an error word instead of a hang.
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(p.sk_cnt + sk_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.sk_s - 1)) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > (1u << 23)) {
+            __hip_atomic_store(p.sk_cnt + SK_MAX_TILES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      // 16 quads (16 KiB per wave) in flight per batch: the partials come from another XCD's write-back, a 2-4 us round trip each
+      // (4 in flight: 8 dependent round trips per partial tile, +25 us per split tile)
+      for (int sl = 0; sl < p.sk_s - 1; ++sl) {
+        const float* src = ws + (long)sl * (BM * BN) + tid * 4;
+#pragma unroll
+        for (int i0 = 0; i0 < AH * 4; i0 += 4) {
+          f32x4 t[4][BH * 2];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < BH * 2; ++j) t[i][j] = *reinterpret_cast<const f32x4*>(src + ((i0 + i) * BH * 2 + j) * 2048);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < BH * 2; ++j) acc[i0 + i][j] += t[i][j];
+        }
+      }
+    }
+  }
   const int next_tile = tile + (int)gridDim.x;
   const bool more = PERSIST && next_tile < ntile;
   if constexpr (!OUT_F32) {      // (the host launches the bf16 instantiations only when host_staged_ok holds)
@@ -456,8 +534,55 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   } while (PERSIST && tile < ntile);
 }
 
+// per-stream workspace of the last-round K split: f32 partial tiles + arrival counts (launches of one stream run in order)
+struct SkWs { float* ws = nullptr; unsigned* cnt = nullptr; };
+std::mutex g_sk_mutex;
+std::map<hipStream_t, SkWs> g_sk;
+constexpr size_t SK_WS_BYTES = (size_t)192 * 256 * 256 * 4;          // rem * (slices - 1) <= 192 partial tiles (48 MiB)
+constexpr size_t SK_CNT_BYTES = (SK_MAX_TILES + 4) * sizeof(unsigned);
+bool sk_workspace(hipStream_t s, float** ws, unsigned** cnt) {
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  SkWs& w = g_sk[s];
+  if (!w.ws) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+    if (hipMalloc(&w.ws, SK_WS_BYTES) != hipSuccess || hipMalloc(&w.cnt, SK_CNT_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      w.ws = nullptr;
+      return false;
+    }
+  }
+  // counts (and the error word) are zeroed on the caller's stream before every launch that uses them (a memset node when captured)
+  static_assert(SK_CNT_BYTES % 16 == 0, "count block: multiple of 16 bytes");
+  if (hipMemsetAsync(w.cnt, 0, SK_CNT_BYTES, s) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  *ws = w.ws; *cnt = w.cnt;
+  return true;
+}
+
+// The split applies when the tile grid leaves a last round at most half full: R = tiles % CUs (or all tiles, when there are fewer than
+// CUs) tiles are cut into S = min(CUs / R, 4) K slices of at least 8 K tiles each. Returns S (0: does not apply).
+int sk_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem) {
+  if (nbatch != 1 || p.out_f32 || p.epi != 0 || p.ln_in) return 0;
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const int r = tiles % ncu;
+  if (r == 0 || r > ncu / 2 || r > SK_MAX_TILES) return 0;
+  int sl = ncu / r;
+  sl = sl > 4 ? 4 : sl;
+  const int nt = p.K / BK6;
+  if (sl > nt / 8) sl = nt / 8;
+  while (sl >= 2 && (long)r * (sl - 1) > 192) --sl;
+  // every slice non-empty: per = ceil(nt / sl) slices cover nt with the last one holding nt - (sl - 1) per >= 1 K tiles
+  while (sl >= 2 && nt - (sl - 1) * ((nt + sl - 1) / sl) < 1) --sl;
+  if (sl < 2) return 0;
+  *full = tiles - r; *rem = r;
+  return sl;
+}
+
 template <int AH, int BH>
-int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
+int launch_v6(GemmParams& p, int nbatch, hipStream_t stream, bool split = false) {
   // (two-phase variants: two K-tile buffers of the NEXT tile + the C image of the current one, or three K-tile buffers: 160 KiB)
   constexpr int SMEM = (AH + BH == 4) ? 2 * 4 * HALF + 2048 : 2 * 3 * HALF + 128 * AH * 128 * BH * 2;   // (+ 2 KiB: LayerNorm pairs above the C image)
   static_assert(SMEM <= 160 * 1024 && (AH + BH == 4 || SMEM >= 3 * (AH + BH) * HALF), "LDS budget");
@@ -469,6 +594,8 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if constexpr (AH + BH == 4)
+      if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<2, 2, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       vq3_set_error("gemm v6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
       return 2;
@@ -496,6 +623,17 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
   if (stagger_env < 0) { const char* e = getenv("VQ3_V6_STAGGER"); stagger_env = e ? atoi(e) : 0; }
   p.stagger = stagger_env;
   int nwg = p.mtiles * p.ntiles;
+  if constexpr (AH + BH == 4) {
+    if (split) {
+      if (!host_staged_ok(p)) return -1;
+      int full = 0, rem = 0;
+      const int sl = sk_plan(p, nbatch, ncu, &full, &rem);
+      if (sl < 2 || !sk_workspace(stream, &p.sk_ws, &p.sk_cnt)) return -1;
+      p.sk_full = full; p.sk_rem = rem; p.sk_s = sl;
+      hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 0, true>), dim3(full + ((rem + 7) & ~7) * sl, 1, 1), dim3(512), SMEM, stream, p);
+      return 0;
+    }
+  }
   if (AH + BH < 4 && nwg > ncu && getenv("VQ3_V6_PERSIST") == nullptr) nwg = ncu;      // (VQ3_V6_PERSIST=0: one tile per workgroup, for A/B runs)
   else if (AH + BH < 4 && nwg > ncu && atoi(getenv("VQ3_V6_PERSIST")) != 0) nwg = ncu;
   dim3 grid(nwg, 1, nbatch);
@@ -516,8 +654,26 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream) {
 
 }  // namespace
 
-// shape: 0 = 256 x 256, 1 = 256 x 128, 2 = 128 x 256
+int gemm_split_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem) { return sk_plan(p, nbatch, ncu, full, rem); }
+int gemm_split_gave_up(hipStream_t stream) {
+  unsigned* cnt = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_sk_mutex);
+    auto it = g_sk.find(stream);
+    if (it == g_sk.end() || !it->second.cnt) return -1;
+    cnt = it->second.cnt;
+  }
+  unsigned v = 0;
+  if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(&v, cnt + SK_MAX_TILES, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return -2;
+  }
+  return v ? 1 : 0;
+}
+
+// shape: 0 = 256 x 256, 1 = 256 x 128, 2 = 128 x 256, 3 = 256 x 256 with the last round split along K (-1 where that does not apply)
 int launch_gemm_v6(GemmParams& p, int shape, int nbatch, hipStream_t stream) {
+  if (shape == 3) return launch_v6<2, 2>(p, nbatch, stream, true);
   if (shape == 1) return launch_v6<2, 1>(p, nbatch, stream);
   if (shape == 2) return launch_v6<1, 2>(p, nbatch, stream);
   return launch_v6<2, 2>(p, nbatch, stream);

@@ -56,7 +56,14 @@ struct GemmParams {
   unsigned long long* stamps;
   // start-up stagger (gemm6.hip): workgroups of the launch's first round wait (blockIdx.x % 8) * stagger ticks of the 100 MHz clock
   int stagger;
+  // K split of the LAST, partly filled round of tiles over the CUs it would leave idle (gemm6.hip, 256 x 256 kernel, cfg 25): workgroup
+  // sk_full + s * roundup8(sk_rem) + j multiplies K slice s (of sk_s) of tile sk_full + j; slices 0 .. sk_s - 2 leave their f32 accumulators in sk_ws
+  // and count themselves in sk_cnt[j], slice sk_s - 1 (dispatched last) waits for that count, adds them and runs the epilogue. sk_s <= 1: off
+  int sk_full, sk_rem, sk_s;
+  float* sk_ws;
+  unsigned* sk_cnt;      // [sk_rem] arrival counts + one error word at [SK_MAX_TILES] (a bounded wait that gave up), zeroed per launch
 };
+constexpr int SK_MAX_TILES = 128;
 
 // row statistics of the folded LayerNorm (contraction length K is the normalised width)
 __device__ __forceinline__ void ln_row(const GemmParams& p, int m, float& mu, float& rs) {
@@ -736,10 +743,11 @@ inline void choose_tile_order(GemmParams& p, int BM, int BN, int wg_per_cu) {
 // v2 (LDS-DMA pipelined) launcher, defined in gemm2.hip. cfg: 0 = 256x128 tile, 1 = 128x256, 2 = 128x128.
 int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream);
 // v6 (256x256 tile, 8-phase schedule, NT, K % 64 == 0), defined in gemm6.hip.
-int launch_gemm_v6(GemmParams& p, int shape, int nbatch, hipStream_t stream);   // shape: 0 = 256x256, 1 = 256x128, 2 = 128x256
-// v8 (128x256 tile, compute / service wave teams, row-wise epilogue under the next tile's main loop), defined in gemm8.hip.
-// Returns -1 (nothing launched) when the problem is outside its contract: the caller picks another kernel.
-int launch_gemm_v8(GemmParams& p, int nbatch, hipStream_t stream);
+int launch_gemm_v6(GemmParams& p, int shape, int nbatch, hipStream_t stream);   // shape: 0 = 256x256, 1 = 256x128, 2 = 128x256,
+// 3 = 256x256 with the last round's tiles split along K (returns -1, nothing launched, where that does not apply)
+// host side of cfg 25 (gemm6.hip): the split plan, and the error word of the stream's workspace (-1: no split launch ever ran on it)
+int gemm_split_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem);
+int gemm_split_gave_up(hipStream_t stream);
 // v7 (256x128 tile, four waves, two workgroups per CU: a tile's epilogue runs under the co-resident workgroup's main loop), gemm7.hip.
 // Returns -1 (nothing launched) when the problem is outside its contract: the caller picks another kernel.
 int launch_gemm_v7(GemmParams& p, int nbatch, hipStream_t stream);

@@ -789,6 +789,22 @@ def skinny_linear_fp8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, re
 
 
 # ---------------------------------------------------------------------------------------------- benchmarking hook
+def gemm_split_plan(M: int, N: int, K: int, ncu: int = 256):
+    """(full, rem, slices) of the 256x256 kernel's last-round K split for an M x N x K product (host-only); slices == 0: no split."""
+    import ctypes as C
+    full, rem, sl = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    check(_lib.load().vq3_gemm_split_plan(M, N, K, ncu, C.addressof(full), C.addressof(rem), C.addressof(sl)), "vq3_gemm_split_plan")
+    return full.value, rem.value, sl.value
+
+
+def gemm_split_gave_up() -> bool:
+    """True if a bounded wait of a split GEMM launch on the current stream ever expired (synchronises the stream)."""
+    import ctypes as C
+    flag = C.c_int32(0)
+    check(_lib.load().vq3_gemm_split_status(_stream(), C.addressof(flag)), "vq3_gemm_split_status")
+    return bool(flag.value)
+
+
 def gemm_force_config(cfg: int = -3) -> None:
     """Force vq3_gemm_bf16_nt's tile configuration for NT shapes (-3 = automatic). Benchmarks and tests only."""
     check(_lib.load().vq3_gemm_force_config(cfg), "vq3_gemm_force_config")

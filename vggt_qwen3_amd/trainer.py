@@ -168,13 +168,15 @@ class Stage1Trainer:
     def set_schedule(self, *, text_group: Optional[int] = None, grad_accum: Optional[int] = None) -> None:
         """Change micro-batches per pass and / or per optimiser step between two accumulation windows (bench.py times the same job
         under several schedules); the deferred weight-gradient depth follows as in __init__."""
-        if self._merged_pending or self._opt_due or any(self.tm._wd_rows):
+        if self._merged_pending or self._opt_due or any(self.tm._wd_rows) or self.micro % self.grad_accum != 0:
             raise RuntimeError("set_schedule: only on an accumulation boundary (flush_pending() first)")
-        if grad_accum is not None:
+        if grad_accum is not None and max(1, int(grad_accum)) != self.grad_accum:
             self.grad_accum = max(1, int(grad_accum))
+            # the micro-batch counter (max_steps, step_N checkpoint names, the saved `micro`) is never rewound: it moves UP to the next
+            # multiple of the new window so that window boundaries and the counter stay in phase (ADVICE r3; bench.py resets it itself)
+            self.micro = (self.micro + self.grad_accum - 1) // self.grad_accum * self.grad_accum
         if text_group is not None:
             self.text_group = max(1, int(text_group))
-        self.micro = 0
         self.tm.enable_wgrad_deferral(min(max(1, self._wgrad_defer // self.text_group), max(1, self.grad_accum)))
 
     def resync_master_from_weights(self) -> None:
