@@ -430,6 +430,17 @@ int vq3_gemm_force_config(int32_t cfg);
 int vq3_gemm_tile_order(int32_t M, int32_t N, int32_t bm, int32_t bn, int32_t wg_per_cu, int32_t* xm_out, int32_t* band_out,
                         int32_t* order);
 
+/* Kernel-choice hygiene (gemm.hip: tuned_choice). The first call of a new (shape, layout, epilogue kind) times its candidate kernels
+ * unless a table entry answers. vq3_gemm_tune_table_load reads "M N K batch flags cfg" lines ('#' comments) into the table (the package
+ * ships one for the Stage-1 shapes; VQ3_GEMM_TUNE_FILE=<path> still adds / appends). vq3_gemm_tune_workspace hands the tuner caller-owned
+ * device memory for its trial output and cache-flush buffer (>= trial bytes + 320 MiB, 256-byte aligned; NULL, 0 detaches): with a
+ * workspace registered the library never allocates for tuning, and a shape that does not fit is not measured. vq3_gemm_autotune_hold(1)
+ * stops all measuring (table, then heuristic): multi-rank jobs - a measurement synchronises the device under in-flight collectives and
+ * ranks would disagree on near-ties. No counterpart in the reference (cuBLAS heuristics are internal). */
+int vq3_gemm_tune_table_load(const char* path, int32_t* entries_out);
+int vq3_gemm_tune_workspace(void* ptr, int64_t bytes);
+int vq3_gemm_autotune_hold(int32_t on);
+
 /* Last-round K split of the 256x256 GEMM kernel (cfg 25; chosen by measurement like every other configuration). An M x N output is
  * ceil(M/256) * ceil(N/256) tiles; when the last round of `ncu` CUs would be at most half full, its `rem` tiles are cut into `slices`
  * K ranges run by rem * slices workgroups: all but the last slice of a tile leave f32 partial tiles in a per-stream workspace (allocated on

@@ -151,7 +151,8 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     root = Path(__file__).resolve().parents[1]
     port = _free_port()
     base = dict(os.environ, VQ3_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
-                HSA_ENABLE_IPC_MODE_LEGACY="0")
+                HSA_ENABLE_IPC_MODE_LEGACY="0", VQ3_GEMM_AUTOTUNE_LOG="1", VQ3_GEMM_TUNE_WS_MB="0")
+    base.pop("VQ3_GEMM_TUNE_FILE", None)
     cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--layers", "2",
            "--no-trim-variant", "--no-cpu-baseline"]
     procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -175,6 +176,15 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     c = d["comm"]
     assert c and c["allreduce_ms_per_opt_step"] > 0 and c["allreduce_bytes_per_opt_step"] > 0 and c["bus_gb_per_s"] > 0
     assert d["accum1_variant"]["comm"]["collectives_per_opt_step"] >= 2 and d["text_group_1_variant"]["value"] > 0
+    # a multi-rank job measures no GEMM candidate - no device synchronisation under in-flight collectives, and both
+    # ranks make the SAME kernel choices (shipped table, then the heuristic): compared key by key from the two logs
+    choices = []
+    for r in range(2):
+        err = outs[r][1]
+        assert "[vq3 gemm autotune]" not in err, err[-1500:]
+        choices.append(dict(l.split("] ", 1)[1].split(" -> ") for l in err.splitlines() if l.startswith("[vq3 gemm choice]")))
+    common = set(choices[0]) & set(choices[1])      # (the ranks' batches differ: a few label-row-count buckets are seen by one rank only)
+    assert len(common) >= 10 and all(choices[0][k] == choices[1][k] for k in common)
 
 
 def test_bench_one_rank_over_rccl():

@@ -777,7 +777,7 @@ def test_gemm_tune_file_makes_the_choice_repeatable(tmp_path):
     code = ("import torch; from vggt_qwen3_amd import ops; x = torch.randn(512, 1024, device='cuda').to(torch.bfloat16); "
             "w = torch.randn(768, 1024, device='cuda').to(torch.bfloat16); y = ops.linear(x, w); torch.cuda.synchronize(); "
             "print('ok', float(y.float().abs().sum()) > 0)")
-    env = dict(os.environ, VQ3_GEMM_TUNE_FILE=str(tune), VQ3_GEMM_AUTOTUNE_LOG="1", PYTHONPATH=repo)
+    env = dict(os.environ, VQ3_GEMM_TUNE_FILE=str(tune), VQ3_GEMM_AUTOTUNE_LOG="1", PYTHONPATH=repo, VQ3_GEMM_TUNE_TABLE="0")
     first = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=repo)
     assert first.returncode == 0 and "ok True" in first.stdout, first.stderr[-2000:]
     assert "[vq3 gemm autotune] M=512 N=768 K=1024" in first.stderr
@@ -786,7 +786,47 @@ def test_gemm_tune_file_makes_the_choice_repeatable(tmp_path):
     second = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=repo)
     assert second.returncode == 0 and "ok True" in second.stdout, second.stderr[-2000:]
     assert "[vq3 gemm autotune]" not in second.stderr                      # nothing was measured: the table came from the file
+    assert "[vq3 gemm choice] M=512 N=768 K=1024" in second.stderr and "(table)" in second.stderr
     assert tune.read_text().count("512 768 1024 1 ") == 1
+    # the same file as a TABLE (what the package ships): read, never appended to; with measuring held (a multi-rank job) a shape the
+    # table does not know takes the heuristic, and says so
+    code2 = ("import torch; from vggt_qwen3_amd import ops, _lib; _lib.load().vq3_gemm_autotune_hold(1); "
+             "x = torch.randn(512, 1024, device='cuda').to(torch.bfloat16); w = torch.randn(768, 1024, device='cuda').to(torch.bfloat16); "
+             "w2 = torch.randn(640, 1024, device='cuda').to(torch.bfloat16); y = ops.linear(x, w); z = ops.linear(x, w2); "
+             "torch.cuda.synchronize(); print('ok', float((y.float().abs().sum() + z.float().abs().sum())) > 0)")
+    env3 = dict(os.environ, VQ3_GEMM_TUNE_TABLE=str(tune), VQ3_GEMM_AUTOTUNE_LOG="1", PYTHONPATH=repo)
+    env3.pop("VQ3_GEMM_TUNE_FILE", None)
+    before = tune.read_text()
+    third = subprocess.run([sys.executable, "-c", code2], env=env3, capture_output=True, text=True, timeout=300, cwd=repo)
+    assert third.returncode == 0 and "ok True" in third.stdout, third.stderr[-2000:]
+    assert "[vq3 gemm autotune]" not in third.stderr and tune.read_text() == before
+    assert "M=512 N=768 K=1024" in third.stderr and "(table)" in third.stderr
+    assert "M=512 N=640 K=1024" in third.stderr and "(heuristic)" in third.stderr
+
+
+def test_gemm_tuner_measures_in_the_callers_workspace(ops):
+    """trial output and cache-flush buffer of the kernel-choice measurements come from a torch-owned workspace
+    (ops.gemm_tune_setup: vq3_gemm_tune_workspace) - a first-sight shape allocates nothing through the HIP allocator; a shape whose trial
+    does not fit the workspace is not measured."""
+    from vggt_qwen3_amd import _lib
+    lib = _lib.load()
+    ops.gemm_tune_setup()
+    assert ops._TUNE_WS is not False and ops._TUNE_WS.numel() >= (512 << 20)
+    x = _rand((640, 1024), 1.0, seed=1); w = _rand((896, 1024), 0.05, seed=2)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    y = ops.linear(x, w)                                   # first sight of (640, 896, 1024): measured in the workspace
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (64 << 20)                      # (no 320 MiB flush buffer, no trial-output allocation appeared)
+    assert _relerr(y, x.float() @ w.float().t()) < 4e-3
+    small = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    try:
+        assert lib.vq3_gemm_tune_workspace(small.data_ptr(), small.numel()) == 0
+        y2 = ops.linear(_rand((704, 1024), 1.0, seed=3), w)          # trial would need 320 MiB + C: not measured, still correct
+        assert y2.shape == (704, 896)
+    finally:
+        assert lib.vq3_gemm_tune_workspace(ops._TUNE_WS.data_ptr(), ops._TUNE_WS.numel()) == 0
 
 
 # ------------------------------------------------------------------------------------------ fused Perceiver cross-attention

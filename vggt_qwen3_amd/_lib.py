@@ -11,6 +11,7 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libvq3hip.so"
+TUNE_TABLE = _PKG / "gemm_tune_gfx950.txt"
 
 c_p = C.c_void_p
 i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
@@ -111,6 +112,9 @@ SIGNATURES = {
     "vq3_gelu_bwd": [c_p, c_p, c_p, i64, c_p],
     "vq3_gelu_fwd": [c_p, c_p, i64, c_p],
     "vq3_gemm_tile_order": [i32, i32, i32, i32, i32, c_p, c_p, c_p],
+    "vq3_gemm_tune_table_load": [C.c_char_p, c_p],
+    "vq3_gemm_tune_workspace": [c_p, i64],
+    "vq3_gemm_autotune_hold": [i32],
     "vq3_gemm_split_plan": [i32, i32, i32, i32, c_p, c_p, c_p],
     "vq3_gemm_split_status": [c_p, c_p],
     "vq3_pack_tokens": [c_p, c_p, c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p, c_p],
@@ -145,6 +149,11 @@ def load() -> C.CDLL:
         fn.restype = _RESTYPES.get(name, C.c_int)
     if lib.vq3_abi_version() != 1:
         raise Vq3Error(f"ABI version mismatch: library {lib.vq3_abi_version()} != binding 1")
+    # the committed kernel-choice table of the Stage-1 shapes (tools/make_tune_table.sh); VQ3_GEMM_TUNE_TABLE=0 skips it, a path replaces it
+    table = os.environ.get("VQ3_GEMM_TUNE_TABLE", str(TUNE_TABLE))
+    if table != "0" and Path(table).exists():
+        if lib.vq3_gemm_tune_table_load(table.encode(), None) != 0:
+            raise Vq3Error(f"cannot read the GEMM tune table {table}")
     _lib = lib
     return lib
 

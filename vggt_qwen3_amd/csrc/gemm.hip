@@ -176,6 +176,9 @@ int choose_config(int M, int N, int K, int nbatch) {
   const double s12 = (shortk ? 0.85 : 0.95) * fill(t128, 256);
   const double s11 = (shortk ? 0.90 : 1.00) * fill(t256, 256) * ((double)M / (double)(((M + 255) / 256) * 256)) /
                      ((double)M / (double)(((M + 127) / 128) * 128));
+  // (the measured choice usually lands on the 256 x 256 8-phase kernel once its tile grid fills most of a round: this is what a launch
+  // gets when nothing may be measured - under graph capture, or in a multi-rank job without a table entry)
+  if ((long)((M + 255) / 256) * ((N + 255) / 256) * nbatch >= 192 && K >= 256) return 20;
   if (s11 >= s12 && s11 >= s7) return 11;
   return s12 >= s7 ? 13 : 7;
 }
@@ -214,6 +217,14 @@ size_t g_scratch_c_bytes = 0;
 void* g_flush = nullptr;
 constexpr size_t FLUSH_BYTES = 320u << 20;
 int g_autotune = -1;
+// vq3_gemm_tune_workspace: trial output + cache-flush buffer come from memory the CALLER owns (a torch tensor) - no hipMalloc / hipFree
+// from inside a GEMM call. A registered workspace that is too small for a shape means "do not measure this shape" (the table or the
+// heuristic answers), never a silent allocation.
+void* g_ws = nullptr;
+size_t g_ws_bytes = 0;
+// vq3_gemm_autotune_hold: nothing is measured while it is on (multi-rank jobs: a measurement synchronises the device under in-flight
+// collectives and every rank would rank near-ties on its own; the table and the heuristic are the same function on every rank)
+int g_hold = 0;
 
 bool autotune_on(hipStream_t s) {
   if (g_autotune < 0) {
@@ -287,17 +298,31 @@ int launch_candidate(GemmParams p, int cand, int transA, int transB, int nbatch,
 // returns the fastest candidate, or -1 when tuning could not run (allocation failure, ...)
 int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int transB, int nbatch, hipStream_t s) {
   GemmParams p = p0;
+  // tall products are measured on their first 65 536 rows (>= 4 rounds of 256 x 256 tiles for N >= 1024: the ranking no longer depends on
+  // M there, and config C4's 395 136-row tower GEMMs would otherwise need 3.2 GB of trial output and 30 ms per trial launch)
+  if (!transA && p.M > 65536 && p.epi != 2 && p.epi != 3) p.M = 65536;
   const size_t esz = p.out_f32 ? 4 : 2;
-  const size_t need = (size_t)p.M * p.N * esz * (size_t)nbatch + 256;
-  if (need > g_scratch_c_bytes) {
-    if (g_scratch_c) (void)hipFree(g_scratch_c);
-    g_scratch_c = nullptr; g_scratch_c_bytes = 0;
-    if (hipMalloc(&g_scratch_c, need) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    g_scratch_c_bytes = need;
+  const size_t need = ((size_t)p.M * p.N * esz * (size_t)nbatch + 256 + 255) & ~(size_t)255;
+  void* scratch_c = nullptr;
+  void* flush = nullptr;
+  if (g_ws) {
+    if (need + FLUSH_BYTES > g_ws_bytes) return -1;           // the caller's workspace decides what may be measured
+    scratch_c = g_ws;
+    flush = (char*)g_ws + need;
+  } else {
+    // no workspace registered (a plain C caller): the library's own buffers, allocated on first use
+    if (need > g_scratch_c_bytes) {
+      if (g_scratch_c) (void)hipFree(g_scratch_c);
+      g_scratch_c = nullptr; g_scratch_c_bytes = 0;
+      if (hipMalloc(&g_scratch_c, need) != hipSuccess) { (void)hipGetLastError(); return -1; }
+      g_scratch_c_bytes = need;
+    }
+    if (!g_flush && hipMalloc(&g_flush, FLUSH_BYTES) != hipSuccess) { (void)hipGetLastError(); g_flush = nullptr; return -1; }
+    scratch_c = g_scratch_c;
+    flush = g_flush;
   }
-  if (!g_flush && hipMalloc(&g_flush, FLUSH_BYTES) != hipSuccess) { (void)hipGetLastError(); g_flush = nullptr; return -1; }
   // trial output: dense scratch, no read-modify-write operands (an in-place residual or accumulate target must not be touched)
-  if (p.epi == 0) p.C = g_scratch_c;      // (epi == 1 writes Q / K / V, epi == 3 gate|up and act: idempotent, no read-modify-write)
+  if (p.epi == 0) p.C = scratch_c;      // (epi == 1 writes Q / K / V, epi == 3 gate|up and act: idempotent, no read-modify-write)
   if (p.epi != 3) {
     p.ldc = p.N;
     p.sC1 = (long)p.M * p.N * p.nb2; p.sC2 = (long)p.M * p.N;
@@ -316,7 +341,7 @@ int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int tr
     if (launch_candidate(p, cand, transA, transB, nbatch, s) != 0) continue;      // warm-up (attribute set-up, code load)
     float tmin = 1e30f;
     for (int r = 0; r < reps; ++r) {
-      (void)hipMemsetAsync(g_flush, r, FLUSH_BYTES, s);
+      (void)hipMemsetAsync(flush, r, FLUSH_BYTES, s);
       (void)hipEventRecord(e0, s);
       if (launch_candidate(p, cand, transA, transB, nbatch, s) != 0) { tmin = 1e30f; break; }
       (void)hipEventRecord(e1, s);
@@ -340,15 +365,23 @@ int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int tr
 // (same kernels, same summation order) without measuring. Without it the choice is timing-based and may differ from run to run and
 // from rank to rank (replicas still agree bit for bit: they apply the same all-reduced gradient); VQ3_GEMM_AUTOTUNE=0 turns measuring off.
 bool g_tune_file_read = false;
+int tune_table_read(const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int m, n, k, b, fl, cfg, cnt = 0;
+  char line[256];
+  while (fgets(line, sizeof line, f)) {
+    if (line[0] == '#') continue;
+    if (sscanf(line, "%d %d %d %d %d %d", &m, &n, &k, &b, &fl, &cfg) == 6) { g_tuned[TuneKey(m, n, k, b, fl)] = cfg; ++cnt; }
+  }
+  fclose(f);
+  return cnt;
+}
 void tune_file_read() {
   g_tune_file_read = true;
   const char* path = getenv("VQ3_GEMM_TUNE_FILE");
   if (!path || !*path) return;
-  FILE* f = fopen(path, "r");
-  if (!f) return;
-  int m, n, k, b, fl, cfg;
-  while (fscanf(f, "%d %d %d %d %d %d", &m, &n, &k, &b, &fl, &cfg) == 6) g_tuned[TuneKey(m, n, k, b, fl)] = cfg;
-  fclose(f);
+  (void)tune_table_read(path);
 }
 void tune_file_append(const TuneKey& key, int cfg) {
   const char* path = getenv("VQ3_GEMM_TUNE_FILE");
@@ -359,13 +392,14 @@ void tune_file_append(const TuneKey& key, int cfg) {
   fclose(f);
 }
 
-int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStream_t s, const std::vector<int>& cands, int fallback) {
+int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStream_t s, const std::vector<int>& cands, int fallback,
+                 bool v3_path = false) {
   // (the key carries what selects a code path inside the candidates: layout, epilogue kind, and whether the 4-wide / whole-row stores apply)
   const bool rows16 = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                       (!p.R || ((p.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.R) & 15) == 0)));
   const int flags = (transA ? 1 : 0) | (transB ? 2 : 0) | (p.out_f32 ? 4 : 0) | (p.accumulate ? 8 : 0) | (p.R ? 16 : 0) |
                     (p.bias ? 32 : 0) | (p.act << 6) | (p.colscale ? 256 : 0) | (p.epi << 9) | (p.ln_in ? 4096 : 0) | (p.st_out ? 8192 : 0) |
-                    (p.vec_ok ? 0 : 16384) | (rows16 ? 0 : 32768);
+                    (p.vec_ok ? 0 : 16384) | (rows16 ? 0 : 32768) | (v3_path ? 65536 : 0);
   // small extents are remembered per bucket (M < 256 in steps of 32, K < 512 in steps of 64): the labelled rows of a pass - the lm_head's M,
   // its weight gradient's K - change from pass to pass, and a measurement (a device synchronisation, ~10 ms of trial launches) for every new
   // count landed inside training steps: bench.py's instrumented window showed a 15.6 ms "launch" of the [149, 151 937, 2560] product
@@ -374,9 +408,23 @@ int tuned_choice(const GemmParams& p, int transA, int transB, int nbatch, hipStr
   const TuneKey key(mkey, p.N, kkey, nbatch, flags);
   std::lock_guard<std::mutex> lock(g_tune_mutex);
   if (!g_tune_file_read) tune_file_read();
+  static int log_on = -1;
+  if (log_on < 0) log_on = getenv("VQ3_GEMM_AUTOTUNE_LOG") ? 1 : 0;
   auto it = g_tuned.find(key);
-  if (it != g_tuned.end()) return it->second;
-  if (!autotune_on(s)) return fallback;                   // not remembered: a later, tunable call may still measure
+  // (an entry is only as good as the candidate list it was measured against: a table written by another build, or by the other
+  // dispatch path under the same key, may name a configuration this call cannot run - such an entry is measured again / falls back)
+  static std::map<TuneKey, int> said;      // (VQ3_GEMM_AUTOTUNE_LOG: every key's choice once, so that two ranks' logs can be compared)
+  if (it != g_tuned.end() && std::find(cands.begin(), cands.end(), it->second) != cands.end()) {
+    if (log_on && said.emplace(key, it->second).second)
+      fprintf(stderr, "[vq3 gemm choice] M=%d N=%d K=%d batch=%d flags=%d -> %d (table)\n", mkey, p.N, kkey, nbatch, flags, it->second);
+    return it->second;
+  }
+  if (!autotune_on(s) || g_hold) {
+    // not remembered: a later, tunable call may still measure
+    if (log_on && said.emplace(key, fallback).second)
+      fprintf(stderr, "[vq3 gemm choice] M=%d N=%d K=%d batch=%d flags=%d -> %d (heuristic)\n", mkey, p.N, kkey, nbatch, flags, fallback);
+    return fallback;
+  }
   int best = tune(p, cands, transA, transB, nbatch, s);
   if (best < 0) best = fallback;
   g_tuned[key] = best;
@@ -506,7 +554,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   if (d->transA || d->transB || d->K % BK != 0) {
     int nstage = choose_v3_stages(d->M, d->N, d->K, nbatch);
     if (!g_forced_v3 && getenv("VQ3_GEMM_V3_STAGES") == nullptr && (long)d->M * d->N * d->K >= (1L << 24))
-      nstage = tuned_choice(p, d->transA, d->transB, nbatch, s, {102, 103, 105}, 100 + nstage) - 100;
+      nstage = tuned_choice(p, d->transA, d->transB, nbatch, s, {102, 103, 105}, 100 + nstage, true) - 100;
     const int rc = launch_gemm_v3(p, d->transA, d->transB, nstage, nbatch, s);
     if (rc) return rc;
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3)");
@@ -540,6 +588,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     if ((long)((d->M + 127) / 128) * ((d->N + 255) / 256) * nbatch >= 64) cands.push_back(22);
     if (split_rows_main(p, nbatch)) cands.push_back(30);
     cands.push_back(25);          // (skipped by the tuner where the last-round split does not apply: the launcher returns -1)
+    if ((long)((d->M + 255) / 256) * ((d->N + 127) / 128) * nbatch >= 256) cands.push_back(24);     // two workgroups per CU (gemm7.hip)
     cfg = tuned_choice(p, 0, 0, nbatch, s, cands, cfg);
   }
   if (cfg == 24) {
@@ -667,6 +716,28 @@ extern "C" int vq3_gemm_split_status(void* stream, int32_t* gave_up) {
   const int r = gemm_split_gave_up((hipStream_t)stream);
   VQ3_CHECK_ARG(r != -2, "gemm_split_status: could not read the stream's workspace");
   *gave_up = r > 0 ? 1 : 0;
+  return 0;
+}
+
+extern "C" int vq3_gemm_tune_table_load(const char* path, int32_t* entries_out) {
+  VQ3_CHECK_ARG(path && *path, "gemm_tune_table_load: null path");
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  const int n = tune_table_read(path);
+  VQ3_CHECK_ARG(n >= 0, "gemm_tune_table_load: cannot read %s", path);
+  if (entries_out) *entries_out = n;
+  return 0;
+}
+
+extern "C" int vq3_gemm_tune_workspace(void* ptr, int64_t bytes) {
+  VQ3_CHECK_ARG((ptr == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)ptr % 256 == 0), "gemm_tune_workspace: bad workspace");
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  g_ws = ptr; g_ws_bytes = (size_t)bytes;
+  return 0;
+}
+
+extern "C" int vq3_gemm_autotune_hold(int32_t on) {
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  g_hold = on ? 1 : 0;
   return 0;
 }
 

@@ -50,6 +50,30 @@ def round_up(x: int, m: int) -> int:
 
 
 # ----------------------------------------------------------------------------------------------- GEMM
+_TUNE_WS = None      # None: not set up yet; False: no workspace; else the uint8 tensor the GEMM tuner measures in
+
+
+def gemm_tune_setup(force: bool = False) -> None:
+    """Once per process, before the first GEMM: hand the kernel-choice tuner a torch-owned workspace (VQ3_GEMM_TUNE_WS_MB, default
+    1024: trial output + 320 MiB cache flush; 0 = none, the library then allocates its own on first use) and, in a multi-rank job, stop
+    it from measuring at all (the shipped table, then the heuristic, answer - the same function on every rank; VQ3_GEMM_AUTOTUNE_DIST=1
+    lets every rank measure as a single process would). Stage1Trainer calls it again once torch.distributed is up."""
+    global _TUNE_WS
+    if _TUNE_WS is not None and not force:
+        return
+    import os
+    lib = _lib.load()
+    if _TUNE_WS is None:
+        _TUNE_WS = False
+        mb = int(os.environ.get("VQ3_GEMM_TUNE_WS_MB", "1024"))
+        if os.environ.get("VQ3_GEMM_AUTOTUNE", "1") != "0" and mb > 0 and torch.cuda.is_available():
+            _TUNE_WS = torch.empty(mb << 20, dtype=torch.uint8, device="cuda")
+            check(lib.vq3_gemm_tune_workspace(_TUNE_WS.data_ptr(), _TUNE_WS.numel()), "vq3_gemm_tune_workspace")
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    check(lib.vq3_gemm_autotune_hold(1 if (multi and os.environ.get("VQ3_GEMM_AUTOTUNE_DIST", "0") != "1") else 0), "vq3_gemm_autotune_hold")
+
+
 def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
              *, bias=None, colscale=None, R=None, ldr: int = 0, nb1: int = 1, nb2: int = 1, b2divB: int = 1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), act: int = 0, accumulate: bool = False, alpha: float = 1.0,
@@ -77,6 +101,8 @@ def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, 
     d.alpha = alpha
     d.transA = 1 if transA else 0; d.transB = 1 if transB else 0; d.ksplit = ksplit
     lib = _lib.load()
+    if _TUNE_WS is None:
+        gemm_tune_setup()
     launch = (lambda: check(lib.vq3_gemm_bf16_nt(d, _stream()), "vq3_gemm_bf16_nt")) if ln_fold is None else \
              (lambda: check(lib.vq3_gemm_bf16_nt_ln(d, ln_fold, _stream()), "vq3_gemm_bf16_nt_ln"))
     if GEMM_PROFILE is not None:
@@ -537,6 +563,8 @@ def gemm_swiglu_bwd(dY: torch.Tensor, W: torch.Tensor, gu: torch.Tensor, transB:
     d.nb1 = d.nb2 = d.b2divB = 1
     d.alpha = 1.0
     d.transA, d.transB = 0, 1 if transB else 0
+    if _TUNE_WS is None:
+        gemm_tune_setup()
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -571,6 +599,8 @@ def gemm_swiglu_fwd(x: torch.Tensor, w_gu: torch.Tensor, gu_out: Optional[torch.
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldr = M, N, K, x.stride(0), w_gu.stride(0), act.stride(0), 0
     d.nb1 = d.nb2 = d.b2divB = 1
     d.alpha = 1.0
+    if _TUNE_WS is None:
+        gemm_tune_setup()
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -609,6 +639,8 @@ def linear_vit_qkv(x: torch.Tensor, w: torch.Tensor, bias, N: int, NH: int, *, q
     e.N, e.NH, e.tokens_per_frame, e.patch_start, e.Wp = N, NH, tokens_per_frame, patch_start, Wp
     e.use_norm, e.use_rope, e.eps = int(use_norm), int(use_rope), eps
     lib = _lib.load()
+    if _TUNE_WS is None:
+        gemm_tune_setup()
     launch = (lambda: check(lib.vq3_gemm_vit_qkv(d, e, _stream()), "vq3_gemm_vit_qkv")) if ln_fold is None else \
              (lambda: check(lib.vq3_gemm_vit_qkv_ln(d, e, ln_fold, _stream()), "vq3_gemm_vit_qkv_ln"))
     if GEMM_PROFILE is not None:

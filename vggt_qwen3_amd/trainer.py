@@ -60,6 +60,7 @@ class Stage1Trainer:
         self.warmup = int(warmup_ratio * max_steps)
         self.pg = process_group
         self.dist_on = dist.is_available() and dist.is_initialized()
+        ops.gemm_tune_setup(force=True)      # multi-rank: no kernel-choice measurements (table, then heuristic: the same on every rank)
         self.world = dist.get_world_size(process_group) if self.dist_on else 1
         self.rank = dist.get_rank(process_group) if self.dist_on else 0
         # "allreduce" (default): SUM all-reduce of every bucket, replicated AdamW. "sharded" (opt-in, dp.py): reduce-scatter of every
