@@ -790,7 +790,7 @@ def test_gemm_tune_file_makes_the_choice_repeatable(tmp_path):
     assert tune.read_text().count("512 768 1024 1 ") == 1
     # the same file as a TABLE (what the package ships): read, never appended to; with measuring held (a multi-rank job) a shape the
     # table does not know takes the heuristic, and says so
-    code2 = ("import torch; from vggt_qwen3_amd import ops, _lib; _lib.load().vq3_gemm_autotune_hold(1); "
+    code2 = ("import torch; from vggt_qwen3_amd import ops, _lib; ops.gemm_tune_setup(); _lib.load().vq3_gemm_autotune_hold(1); "
              "x = torch.randn(512, 1024, device='cuda').to(torch.bfloat16); w = torch.randn(768, 1024, device='cuda').to(torch.bfloat16); "
              "w2 = torch.randn(640, 1024, device='cuda').to(torch.bfloat16); y = ops.linear(x, w); z = ops.linear(x, w2); "
              "torch.cuda.synchronize(); print('ok', float((y.float().abs().sum() + z.float().abs().sum())) > 0)")

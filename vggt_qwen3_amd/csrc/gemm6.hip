@@ -566,6 +566,9 @@ bool sk_workspace(hipStream_t s, float** ws, unsigned** cnt) {
 // CUs) tiles are cut into S = min(CUs / R, 4) K slices of at least 8 K tiles each. Returns S (0: does not apply).
 int sk_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem) {
   if (nbatch != 1 || p.out_f32 || p.epi != 0 || p.ln_in) return 0;
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("VQ3_GEMM_SPLIT"); off = (e && atoi(e) == 0) ? 1 : 0; }      // VQ3_GEMM_SPLIT=0: A/B runs
+  if (off) return 0;
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   const int r = tiles % ncu;
   if (r == 0 || r > ncu / 2 || r > SK_MAX_TILES) return 0;
