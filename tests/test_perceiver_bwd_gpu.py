@@ -182,3 +182,38 @@ def test_train_projector_flag_end_to_end():
     assert len(moved) == len(w0)
     l2 = tr_model(**kw)                                      # compute copies follow the updated fp32 parameters
     assert torch.isfinite(l2) and abs(l2.item() - loss_off.item()) > 1e-6
+
+
+def test_prefetch_in_train_projector_mode_caches_the_frozen_tokens_only():
+    """with train_projector on, prefetch_images() for a future batch must not run the (trainable, train-mode-dropout)
+    projector ahead of time: it caches the frozen tower's tokens, the training forward consumes exactly that cache (nothing stays parked),
+    the dropout counter advances as without the prefetch, and loss and projector gradients are those of the un-prefetched pass."""
+    from tests.golden_io import load, meta
+    from tests.test_parity_gpu import _build_vlm
+    z = load("vlm_tiny.npz")
+    mt = meta(z)
+    geom = {k: torch.from_numpy(z["geom:" + k]).cuda() for k in ("R", "t", "K", "depth_hist")}
+    kw = dict(images=torch.from_numpy(z["pixel_values"].astype(np.float32)).cuda(), geom_token=geom,
+              input_ids=torch.from_numpy(z["input_ids"]).cuda(), attention_mask=torch.from_numpy(z["attention_mask"]).cuda(),
+              labels=torch.from_numpy(z["labels"]).cuda())
+    runs = []
+    for prefetch in (False, True):
+        m = _build_vlm(z, mt).train()                        # projector in train mode: its dropout sites are live
+        m.train_projector = True
+        m.projector._drop_seed, m.projector._drop_offset = 1234, 0
+        if prefetch:
+            m.prefetch_images(kw["images"])
+            assert m._prefetched is not None and m._prefetched[2] == "tokens"
+            assert m.projector._drop_offset == 0             # the projector did not run
+        loss = m(**kw)
+        assert m._prefetched is None                         # consumed, not parked
+        loss.backward()
+        runs.append((loss.item(), m.projector._drop_offset, {n: p.grad.clone() for n, p in m.projector.named_parameters()}))
+    (l0, o0, g0), (l1, o1, g1) = runs
+    assert l0 == l1 and o0 == o1 and o0 > 0
+    assert all(torch.equal(g0[n], g1[n]) for n in g0)
+    # reference mode (train_projector off): the whole encode_images result is prefetched, as before
+    m = _build_vlm(z, mt).train()
+    m.prefetch_images(kw["images"])
+    assert m._prefetched[2] == "encoded"
+    assert torch.isfinite(m(**kw)) and m._prefetched is None

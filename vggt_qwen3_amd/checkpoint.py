@@ -159,6 +159,11 @@ def load_checkpoint_if_available(model, ckpt_dir: Optional[str], verbose: bool =
 def save_trainer_state(trainer, out_dir) -> Path:
     """fp32 master weights, Adam moments, counters. (The reference cannot resume - SURVEY.md appendix A - so this
     format is ours; the model weights next to it stay in the reference's layout.)"""
+    if getattr(trainer, "dp_mode", "allreduce") == "sharded" and not getattr(trainer, "_shards_gathered", True):
+        # (ADVICE r3) the fp32 master weights and moments of the other ranks' shards are stale here: written out, a resume would put
+        # the old weights back at the next AdamW step. Every rank has to call trainer.gather_sharded_state() first (a collective).
+        raise RuntimeError("save_trainer_state: dp_mode='sharded' and the optimiser state has not been gathered since the last "
+                           "optimiser step - call trainer.gather_sharded_state() on every rank first (Stage1Trainer._save does)")
     out = Path(out_dir)
     out.mkdir(parents=True, exist_ok=True)
     st = {"micro": trainer.micro, "opt_step": trainer.opt_step, "grad_accum": trainer.grad_accum,

@@ -68,7 +68,9 @@ class Stage1Trainer:
         self.dp_mode = dp_mode or os.environ.get("VQ3_DP_MODE", "allreduce")
         if self.dp_mode not in ("allreduce", "sharded"):
             raise ValueError(f"dp_mode must be 'allreduce' or 'sharded', got {self.dp_mode!r}")
-        if not self.dist_on or self.world == 1:
+        # (one rank: nothing to shard - unless VQ3_FORCE_DIST asks for the collectives themselves, the one-rank RCCL rehearsal of
+        # reduce_scatter_tensor / all_gather_into_tensor in their in-place forms: tests/test_dp_gpu.py)
+        if not self.dist_on or (self.world == 1 and not os.environ.get("VQ3_FORCE_DIST")):
             self.dp_mode = "allreduce"
         self.max_grad_norm = max_grad_norm
         # scheduler ticks per optimiser step: `world` under Accelerate's rule (the reference), 1 for a plain loop
@@ -150,6 +152,9 @@ class Stage1Trainer:
                     p_.grad = self.proj_g32[off:off + k].view_as(p_)
                     off += k
             model.projector._cc = None
+        # dp_mode "sharded": fp32 master / moments are current in this rank's shards only until gather_sharded_state() ran after the
+        # last optimiser step (checkpoint.save_trainer_state refuses a state that is not gathered)
+        self._shards_gathered = True
         self._works: List = []
         self.comm_profile: Optional[List] = None    # set to [] to collect (start event, end event, bytes) per gradient all-reduce
         self._fired: List[int] = []     # buckets all-reduced from inside the backward of the current boundary micro-batch
@@ -381,6 +386,7 @@ class Stage1Trainer:
         if sharded:                                                 # the updated bf16 weights of every shard reach every rank
             for lo, hi in list(self.buckets.values()) + [self.embed_span]:
                 dp.all_gather_span(tm.flat_w, lo, hi, self.rank, self.world, group=self.pg)
+            self._shards_gathered = self.world == 1
         if proj_g16 is not None:
             ops.adamw_step(self.proj_w32, self.proj_m, self.proj_v, proj_g16, self.proj_w16, self.proj_lr * mult, self.betas[0],
                            self.betas[1], self.eps, self.wd, self.opt_step, gscale, clip=clip)
@@ -454,6 +460,7 @@ class Stage1Trainer:
         for lo, hi in list(self.buckets.values()) + [self.embed_span]:
             for t in (self.master, self.m, self.v):
                 dp.all_gather_span(t, lo, hi, self.rank, self.world, group=self.pg)
+        self._shards_gathered = True
 
     def _save(self, path, rank: int, checkpoint) -> None:
         if self.dist_on:

@@ -282,17 +282,24 @@ class VGGTQwen3VLM(nn.Module):
         images = images.to(self.device_)
         self._vis_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._vis_stream):
-            vis = self.encode_images(images)
-        self._prefetched = (images, vis)
+            # "corrected" mode (train_projector): only the FROZEN tower's tokens may be computed ahead - the projector's weights change
+            # with every optimiser step and its train-mode dropout offsets belong to the pass that consumes them
+            if self.train_projector:
+                kind, vis = "tokens", self._vision_tokens(images)
+            else:
+                kind, vis = "encoded", self.encode_images(images)
+        self._prefetched = (images, vis, kind)
 
-    def _take_prefetched(self, images: torch.Tensor) -> Optional[torch.Tensor]:
+    def _take_prefetched(self, images: torch.Tensor):
+        """(kind, tensor) of a prefetch_images() result for this very tensor object - kind "encoded": projector output, "tokens": the
+        frozen tower's tokens - or None."""
         pf = self._prefetched
         if pf is None or pf[0] is not images:
             return None
         self._prefetched = None
         torch.cuda.current_stream().wait_stream(self._vis_stream)
         pf[1].record_stream(torch.cuda.current_stream())
-        return pf[1]
+        return pf[2], pf[1]
 
     def _geom_inputs(self, geom_token) -> Optional[torch.Tensor]:
         if not geom_token or self.geom_tokens == 0:
@@ -341,14 +348,19 @@ class VGGTQwen3VLM(nn.Module):
         images0 = images
         images = images.to(self.device_)
         pctx = None
+        pf = self._take_prefetched(images)
         if self.train_projector and need_grad:
             # "corrected" mode: the tower stays frozen (no_grad), the projector's forward keeps what its backward needs
             with torch.no_grad():
-                vis, pctx = self.projector.forward_train(self._vision_tokens(images, _orig=images0))
+                tok = pf[1] if (pf is not None and pf[0] == "tokens") else self._vision_tokens(images, _orig=images0)
+                vis, pctx = self.projector.forward_train(tok)
+        elif pf is not None and pf[0] == "encoded":
+            vis = pf[1]
+        elif pf is not None:
+            with torch.no_grad():
+                vis = self.projector(pf[1])
         else:
-            vis = self._take_prefetched(images)
-            if vis is None:
-                vis = self.encode_images(images, _orig=images0)                               # [B, Nv, H] fp32
+            vis = self.encode_images(images, _orig=images0)                               # [B, Nv, H] fp32
         gfeat = self._geom_inputs(geom_token)
         geom_ctx, gy = None, None
         if gfeat is not None:
