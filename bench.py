@@ -540,7 +540,7 @@ def main():
                                     "with each micro-batch's loss normalised by its own labelled rows" % (args.image_size, V, B, trainer.pass_size(accum))),
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": L, "views": V,
                        "grad_accum": accum, "optimizer_steps_timed": len(cycles), "micro_batches_per_pass": int(trainer.pass_size(accum)),
-                       "parallelism": f"dp{world}", "geom_tokens": 8 if args.geom else 0,
+                       "parallelism": f"dp{world}", "dp_mode": trainer.dp_mode, "geom_tokens": 8 if args.geom else 0,
                        "trim_padding": bool(args.trim_pad), "fp8_text_forward": bool(args.fp8),
                        "train_projector": bool(args.train_projector), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),

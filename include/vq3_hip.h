@@ -402,18 +402,6 @@ int vq3_qwen_flash_fwd(const void* Q, const void* K, const void* V, const void* 
 int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* keymask, const void* O, const void* dO,
                        const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t kv_parts, int32_t B, int32_t L,
                        int32_t Hq, int32_t Hkv, int32_t head_dim, int64_t ldo, int64_t lddo, float scale, void* stream);
-/* The same two entry points with a promise from the caller: no sample attends to keys in more than max_live_tiles of its 32-key tiles
- * (0 = unknown). For short sequences (L <= 256) with few attended tiles - the reference's collator masks everything but the 20-50 text
- * positions of a 200-column row - the forward and the dQ pass then run as ONE workgroup per (sample, kv head) that stages the attended
- * K / V tiles in LDS once for its four query heads and all its query blocks. Results do not depend on the promise (a sample that
- * breaks it takes the generic path inside the kernel); otherwise identical to vq3_qwen_flash_fwd / vq3_qwen_flash_bwd, bit for bit. */
-int vq3_qwen_flash_fwd_b(const void* Q, const void* K, const void* V, const void* keymask, void* O, float* LSE, int32_t B, int32_t L,
-                         int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, float scale, int32_t max_live_tiles, void* stream);
-int vq3_qwen_flash_bwd_b(const void* Q, const void* K, const void* V, const void* keymask, const void* O, const void* dO,
-                         const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t kv_parts, int32_t B, int32_t L,
-                         int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, int64_t lddo, float scale, int32_t max_live_tiles,
-                         void* stream);
-
 /* Benchmarking / test hook for vq3_gemm_bf16_nt's kernel choice on NT, K % 64 == 0 shapes: cfg = -3 restores the automatic
  * choice (the default), -1 the register-staged reference kernel, 0..14 a gemm2.hip tile configuration, 20 / 21 / 22 the
  * 8-phase kernels of gemm6.hip (256x256 / 256x128 / 128x256 tiles), 24 the two-workgroups-per-CU 256x128 kernel of gemm7.hip, 25 the

@@ -74,7 +74,15 @@ def _worker(rank, world, port, outdir, merge=False, mode="allreduce"):
         for i, b in enumerate(bs):
             # merge: the two micro-batches of a window run as one pass (micro_step(upcoming=...)); the hooks then fire in that pass
             losses.append(float(tr.micro_step(b, upcoming=bs[i + 1:] if merge else None).item()))
+        if mode == "sharded":               #  the public save refuses a state whose other shards are stale, on every rank
+            from vggt_qwen3_amd import checkpoint
+            assert not tr._shards_gathered
+            with pytest.raises(RuntimeError):
+                checkpoint.save_trainer_state(tr, os.path.join(outdir, f"stale{rank}"))
         tr.gather_sharded_state()           # (sharded mode: the fp32 state is current inside each rank's shards only)
+        if mode == "sharded":
+            assert tr._shards_gathered
+            checkpoint.save_trainer_state(tr, os.path.join(outdir, f"state{rank}"))
         torch.cuda.synchronize()
         torch.save({"master": tr.master.cpu(), "geom_master": tr.geom_master.cpu(), "flat_w": model.text_model.flat_w.cpu(),
                     "fired": fired, "spans": spans, "losses": losses, "opt_step": tr.opt_step,
@@ -211,3 +219,29 @@ def test_bench_one_rank_over_rccl():
     c = d["comm"]
     assert c and c["allreduce_ms_per_opt_step"] > 0 and c["allreduce_bytes_per_opt_step"] > 0 and c["collectives_per_opt_step"] >= 2
     assert d["accum1_variant"]["comm"]["collectives_per_opt_step"] >= 2
+
+
+def test_bench_one_rank_over_rccl_sharded_mode():
+    """dp_mode "sharded" through RCCL itself. With VQ3_FORCE_DIST=1 a single rank keeps the sharded mode (it used to
+    fall back to "allreduce" silently at world 1), so RCCL's reduce_scatter_tensor / all_gather_into_tensor run in the in-place forms
+    dp.py uses (output = a slice of the input / input = a slice of the output) on a GPU, on the communication stream, with HIP events
+    around them; the job must finish with a finite loss, matched collectives and the comm fields filled. One rank moves no bytes between
+    GPUs: plumbing, not bandwidth - no multi-GPU number exists."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, VQ3_FORCE_DIST="1", VQ3_DP_MODE="sharded", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1",
+               RANK="0", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VQ3_DIST_BACKEND", None)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--layers", "2",
+           "--no-trim-variant", "--no-cpu-baseline", "--no-variants"]
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(root), text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["dp_mode"] == "sharded" and d["loss"] == d["loss"]
+    c = d["comm"]
+    assert c and c["allreduce_ms_per_opt_step"] > 0 and c["allreduce_bytes_per_opt_step"] > 0 and c["collectives_per_opt_step"] >= 2

@@ -739,33 +739,6 @@ def test_qwen_flash_attention_fwd_bwd(ops, B, Hkv, L, pad, G):
     assert (lse[ok] - lse_ref[ok]).abs().max() < 2e-2
 
 
-@pytest.mark.parametrize("B,L,keep", [(3, 200, (30, 47, 64)), (2, 77, (77, 10)), (5, 256, (256, 33, 1, 129, 96)), (2, 40, (3, 40))])
-def test_qwen_flash_fat_kernels_equal_the_per_block_kernels(ops, B, L, keep):
-    """vq3_qwen_flash_fwd_b / _bwd_b with a bound on the attended key tiles run the forward and the dQ pass as one workgroup per
-    (sample, kv head) with the attended K / V tiles in LDS: bit-identical to the per-query-block kernels, for an exact bound, a loose one,
-    and a BROKEN promise (a sample with more attended tiles than promised takes the generic path inside the kernel)."""
-    torch.manual_seed(L + B)
-    Hq, Hkv, D = 32, 8, 128
-    Q = torch.randn(B, Hq, L, D, device="cuda").to(BF16)
-    K = torch.randn(B, Hkv, L, D, device="cuda").to(BF16)
-    V = torch.randn(B, Hkv, L, D, device="cuda").to(BF16)
-    dO = torch.randn(B * L, Hq * D, device="cuda").to(BF16)
-    mask = torch.zeros(B, L, dtype=torch.uint8, device="cuda")
-    for b in range(B):
-        mask[b, : keep[b]] = 1                                  # right padding, as the collator pads
-    mask[0, 5:9] = 0                                            # and a hole
-    scale = D ** -0.5
-    exact = max((k + 31) // 32 for k in keep)
-    O0, lse0 = ops.qwen_flash_fwd(Q, K, V, mask, B, L, Hq, Hkv, D, scale)
-    g0 = ops.qwen_flash_bwd(Q, K, V, mask, O0, dO, lse0, B, L, Hq, Hkv, D, scale, kv_parts=1)
-    for bound in (exact, min(8, exact + 2), 1):
-        O1, lse1 = ops.qwen_flash_fwd(Q, K, V, mask, B, L, Hq, Hkv, D, scale, max_live_tiles=bound)
-        assert torch.equal(O1, O0) and torch.equal(lse1, lse0), bound
-        g1 = ops.qwen_flash_bwd(Q, K, V, mask, O0, dO, lse0, B, L, Hq, Hkv, D, scale, kv_parts=1, max_live_tiles=bound)
-        for a, b_ in zip(g1, g0):
-            assert torch.equal(a, b_), bound
-
-
 def test_gemm_tune_file_makes_the_choice_repeatable(tmp_path):
     """VQ3_GEMM_TUNE_FILE: the measured kernel choices of one process are appended to the file; a second process reads them and measures
     nothing (same kernels, same summation order from run to run and on every rank that is pointed at the file)."""

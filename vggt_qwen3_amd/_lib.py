@@ -104,8 +104,6 @@ SIGNATURES = {
     "vq3_gemm_fp8_nt": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i64, i64, c_p],
     "vq3_qwen_flash_fwd": [c_p] * 6 + [i32, i32, i32, i32, i32, i64, f32, c_p],
     "vq3_qwen_flash_bwd": [c_p] * 11 + [i32, i32, i32, i32, i32, i32, i64, i64, f32, c_p],
-    "vq3_qwen_flash_fwd_b": [c_p] * 6 + [i32, i32, i32, i32, i32, i64, f32, i32, c_p],
-    "vq3_qwen_flash_bwd_b": [c_p] * 11 + [i32, i32, i32, i32, i32, i32, i64, i64, f32, i32, c_p],
     "vq3_gemm_force_config": [i32],
     "vq3_layernorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, f32, c_p],
     "vq3_colsum_f32": [c_p, i32, i32, c_p, i32, c_p],

@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R,
                                                         int C, int Rpad, long lds_, long ldd, int n1, int n2, long s0,
                                                         long s1, long s2, long d0, long d1, long d2, int vec) {
-  __shared__ bf16_t tile[64][72];
+  // row stride 66 elements = 33 dwords (odd): the store phase reads element (ch * 8 + j, cc) with ch = lane & 7, i.e. rows 8 apart - at the
+  // old stride of 72 elements (36 dwords, 8 rows = 288 dwords = 0 mod 32) all eight landed on ONE bank (8-way; LDS-conflict share 0.82 in
+  // profiles/r3_pmc_mfma_lds.csv), now on four banks twice (2-way), and the load phase's dword writes are 2-way as well
+  __shared__ bf16_t tile[64][66];
   const int bz = blockIdx.z;
   const int i2 = bz % n2, i1 = (bz / n2) % n1, i0 = bz / (n2 * n1);
   src += i0 * s0 + i1 * s1 + i2 * s2;
@@ -120,7 +123,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
           if (c + j < C) v[j] = (short)src[(long)r * lds_ + c + j];
       }
     }
-    *reinterpret_cast<bf16x8*>(&tile[rr][ch * 8]) = v;
+    {
+      const u32x4 u = __builtin_bit_cast(u32x4, v);
+      unsigned* tp = reinterpret_cast<unsigned*>(&tile[rr][ch * 8]);       // (4-byte aligned: 132 rr + 16 ch)
+      tp[0] = u[0]; tp[1] = u[1]; tp[2] = u[2]; tp[3] = u[3];
+    }
   }
   __syncthreads();
   // store: dst row = c (64 of them), 8 chunks of 8 consecutive r
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
                                                         const int32_t* __restrict__ srcmap,
                                                         const bf16_t* __restrict__ dout, bf16_t* __restrict__ dtable,
                                                         int T, int H) {
-  __shared__ float part[4][64][8];
+  __shared__ float part[4][8][64];      // [wave][j][lane]: consecutive lanes on consecutive banks (lane-major rows of 8 were 8-way)
   __shared__ int any_s[4];
   const int i = blockIdx.x;
   const int64_t id = sorted_ids[i];
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) part[wid][lane][j] = a[j];
+  for (int j = 0; j < 8; ++j) part[wid][j][lane] = a[j];
   if (lane == 0) any_s[wid] = any ? 1 : 0;      // `any` is wave-uniform (it depends on the rows, not on the lane)
   __syncthreads();
   if (wid != 0 || !cin || !(any_s[0] | any_s[1] | any_s[2] | any_s[3])) return;
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   bf16x8 r;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    r[j] = (short)f2bf(((part[0][lane][j] + part[1][lane][j]) + (part[2][lane][j] + part[3][lane][j])) + bf2f((bf16_t)o[j]));
+    r[j] = (short)f2bf(((part[0][j][lane] + part[1][j][lane]) + (part[2][j][lane] + part[3][j][lane])) + bf2f((bf16_t)o[j]));
   *reinterpret_cast<bf16x8*>(d) = r;
 }
 // dfeat_f32[b, s, :] += dout[b, l, :] where srcmap[b,l] == s

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* dres, bf16_t* dx, float* __restrict__ dw,
                                                           long rows, int cols, int rb_rows) {
-  extern __shared__ __attribute__((aligned(16))) float dw_s[];   // [4 waves][cols]
+  extern __shared__ __attribute__((aligned(16))) float dw_s[];   // [4 waves][NCH * 512]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float dwacc[NCH][8];
   bf16x8 wv[NCH];
@@ -122,14 +122,19 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
   for (int ch = 0; ch < NCH; ++ch) {
     const int c = lane * 8 + ch * 512;
     if (c < cols) {
-      *reinterpret_cast<f32x4*>(&dw_s[wid * cols + c]) = f32x4{dwacc[ch][0], dwacc[ch][1], dwacc[ch][2], dwacc[ch][3]};
-      *reinterpret_cast<f32x4*>(&dw_s[wid * cols + c + 4]) = f32x4{dwacc[ch][4], dwacc[ch][5], dwacc[ch][6], dwacc[ch][7]};
+      // LDS image [wave][chunk][half][lane][4]: a wave instruction writes 64 x 16 contiguous bytes (lane-major rows of 8 floats put
+      // lanes l and l + 4 on the same banks: conflict share 0.75 in profiles/r3_pmc_mfma_lds.csv)
+      float* base = dw_s + wid * (NCH * 512) + ch * 512 + lane * 4;
+      *reinterpret_cast<f32x4*>(base) = f32x4{dwacc[ch][0], dwacc[ch][1], dwacc[ch][2], dwacc[ch][3]};
+      *reinterpret_cast<f32x4*>(base + 256) = f32x4{dwacc[ch][4], dwacc[ch][5], dwacc[ch][6], dwacc[ch][7]};
     }
   }
   __syncthreads();
   float* out = dw + (long)blockIdx.x * cols;
-  for (int c = threadIdx.x; c < cols; c += 256)
-    out[c] = dw_s[c] + dw_s[cols + c] + dw_s[2 * cols + c] + dw_s[3 * cols + c];
+  for (int i = threadIdx.x; i < NCH * 512; i += 256) {          // image index -> column: chunk i / 512, half (i / 256) & 1, lane (i & 255) / 4
+    const int c = (i >> 9) * 512 + ((i & 255) >> 2) * 8 + ((i >> 8) & 1) * 4 + (i & 3);
+    if (c < cols) out[c] = dw_s[i] + dw_s[NCH * 512 + i] + dw_s[2 * NCH * 512 + i] + dw_s[3 * NCH * 512 + i];
+  }
 }
 
 // out_bf16[c] (+)= sum_r part[r][c]: 64 columns per block, 16 waves stride over the rows (4 independent loads in
@@ -490,11 +495,11 @@ static int rmsnorm_bwd_impl(const void* dy, const void* x, const void* w, const 
 #define VQ3_RB_LAUNCH(NCH)                                                                                           \
   do {                                                                                                              \
     if (rows_per_part == 4)                                                                                         \
-      hipLaunchKernelGGL((rmsnorm_bwd_kernel<NCH, 4>), dim3((unsigned)nblk), dim3(256), 4 * cols * sizeof(float),     \
+      hipLaunchKernelGGL((rmsnorm_bwd_kernel<NCH, 4>), dim3((unsigned)nblk), dim3(256), 4 * NCH * 512 * sizeof(float),     \
                          (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd,           \
                          (const bf16_t*)dres, (bf16_t*)dx, dw_f32, (long)rows, cols, 4);                            \
     else                                                                                                            \
-      hipLaunchKernelGGL((rmsnorm_bwd_kernel<NCH, 0>), dim3((unsigned)nblk), dim3(256), 4 * cols * sizeof(float),     \
+      hipLaunchKernelGGL((rmsnorm_bwd_kernel<NCH, 0>), dim3((unsigned)nblk), dim3(256), 4 * NCH * 512 * sizeof(float),     \
                          (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd,           \
                          (const bf16_t*)dres, (bf16_t*)dx, dw_f32, (long)rows, cols, (int)rows_per_part);           \
   } while (0)

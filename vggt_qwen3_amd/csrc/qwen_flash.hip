@@ -281,91 +281,6 @@ __global__ __launch_bounds__(256) void qwen_flash_fwd_kernel(const bf16_t* __res
   fwd_block<false>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, nullptr, ostage[g]);
 }
 
-// (the fat kernels' rare path - a sample with more attended tiles than LDS slots - as a real call: inlined beside the LDS path it costs
-// the common path 50 spilled registers)
-__device__ __attribute__((noinline)) void fwd_block_global(const bf16_t* Q, const bf16_t* K, const bf16_t* V, bf16_t* O, float* LSE, int L,
-                                                           int Hq, int Hkv, long ldo, float scale, int b, int hk, int hq, int qb,
-                                                           const unsigned* bits_g, const unsigned* list_g, int nlist, char* otile) {
-  fwd_block<false>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, bits_g, list_g, nlist, nullptr, otile);
-}
-
-// number of list entries (ascending tile indices) that a query block may attend to: tiles <= qb
-__device__ __forceinline__ int tiles_upto(const unsigned* list, int n, int qb) {
-  int c = 0;
-  for (int i = 0; i < n; ++i) c += ((int)list[i] <= qb) ? 1 : 0;
-  return c;
-}
-
-// One workgroup per (sample, kv head) for short sequences (L <= 32 * FAT_TILES) whose attended key tiles are few - what the
-// reference's collator produces: the mask covers the 20-50 text positions of a 200-column row. The per-query-block kernels above pay
-// their start-up (key bits, tile list, the first K / V round trip) 7 x 384 times per layer for one or two tile steps each; here the
-// sample's attended K / V tiles are staged into LDS ONCE (at most nt_lds of them: the caller's bound; all four query heads and all
-// query blocks read them from there) and a wave walks its head's query blocks with no global load inside a tile step. A sample with
-// more attended tiles than slots takes the global-operand path for all its blocks - same results, the bound is only about speed.
-constexpr int FAT_TILES = 8;
-__global__ __launch_bounds__(256, 2) void qwen_flash_fwd_fat_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
-                                                                bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Hq,
-                                                                int Hkv, long ldo, float scale, int nt_lds, int per_block) {
-  extern __shared__ __attribute__((aligned(16))) char fat_smem[];        // nt_lds slots of [K tile | V tile]
-  __shared__ unsigned sbits[4][FAT_TILES];
-  __shared__ unsigned slist[4][FAT_TILES];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int gu = __builtin_amdgcn_readfirstlane(g);
-  const int nqb = (L + 31) / 32;
-  // per_block: one workgroup per (sample, kv head, query block) - the grid of the per-block kernel, heaviest blocks first - that stages
-  // only the tiles ITS block attends to; otherwise one workgroup per (sample, kv head) walks all query blocks
-  const int nbh = per_block ? (int)gridDim.x / nqb : (int)gridDim.x;
-  const int qb_only = per_block ? nqb - 1 - (int)(blockIdx.x / nbh) : -1;
-  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
-  const int G = Hq / Hkv, hq = hk * G + g;
-  const int ntile = per_block ? qb_only + 1 : nqb;
-  key_bits_all(keymask + (long)b * L, ntile, L, sbits[g]);
-  const int nlive = compact_tiles(sbits[g], ntile, slist[g]);
-  const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
-  const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
-  const bool fits = nlive <= nt_lds;                              // workgroup-uniform (every wave computed the same list)
-  char* const otile = fat_smem + nt_lds * (2 * 32 * 256) + gu * (32 * 256);      // behind the K / V slots: one output tile per wave
-  if (fits) {
-    for (int li = gu; li < nlive; li += 4) {
-      const int kb = (int)slist[g][li];
-      char* slot = fat_smem + li * (2 * 32 * 256);
-      dma_tile(Kb, D, kb * 32, L - 1, slot, lane);
-      dma_tile(Vb, D, kb * 32, L - 1, slot + 32 * 256, lane);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  if (g >= G) return;
-  if (per_block) {
-    if (fits) fwd_block<true>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb_only, sbits[g], slist[g], nlive, fat_smem, otile);
-    else fwd_block_global(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb_only, sbits[g], slist[g], nlive, otile);
-    return;
-  }
-  if (!fits) {
-    for (int qb = nqb - 1; qb >= 0; --qb)
-      fwd_block_global(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], tiles_upto(slist[g], nlive, qb), otile);
-    return;
-  }
-  // the Q rows of query block qb - 1 are requested before block qb is multiplied: with K / V in LDS they are the only global loads
-  // left in a block, and their round trip would otherwise be paid once per block
-  const int r = lane & 31, h = lane >> 5;
-  auto qrows = [&](int qb, bf16x8 (&f)[8]) {
-    const int q = qb * 32 + r, qc = q < L ? q : L - 1;
-    const bf16_t* Qr = Q + (((long)b * Hq + hq) * L + qc) * D + 8 * h;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) f[s] = ld8(Qr + 16 * s);
-  };
-  bf16x8 qcur[8], qnext[8];
-  qrows(nqb - 1, qcur);
-  for (int qb = nqb - 1; qb >= 0; --qb) {
-    if (qb > 0) qrows(qb - 1, qnext);
-    fwd_block<true>(Q, K, V, O, LSE, L, Hq, Hkv, ldo, scale, b, hk, hq, qb, sbits[g], slist[g], tiles_upto(slist[g], nlive, qb), fat_smem, otile, qcur);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) qcur[s] = qnext[s];
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
 // One 32-row query block of one query head in the dQ pass (LDS_KV as in fwd_block: K / V tiles from global memory or from the
 // workgroup's LDS slots; same arithmetic either way).
@@ -477,60 +392,6 @@ __global__ __launch_bounds__(256) void qwen_flash_bwd_dq_kernel(const bf16_t* __
   key_bits_all(keymask + (long)b * L, qb + 1, L, sbits[g]);
   const int nlist = compact_tiles(sbits[g], qb + 1, slist[g]);
   dq_block<false>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, nullptr, ostage[g]);
-}
-
-__device__ __attribute__((noinline)) void dq_block_global(const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* O, const bf16_t* dO,
-                                                          const float* LSE, float* Delta, bf16_t* dQ, int L, int Hq, int Hkv, long ldo,
-                                                          long lddo, float scale, int b, int hk, int hq, int qb, const unsigned* bits_g,
-                                                          const unsigned* list_g, int nlist, char* otile) {
-  dq_block<false>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, bits_g, list_g, nlist, nullptr, otile);
-}
-
-// the dQ pass in the one-workgroup-per-(sample, kv head) form of qwen_flash_fwd_fat_kernel
-__global__ __launch_bounds__(256, 2) void qwen_flash_bwd_dq_fat_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                      const bf16_t* __restrict__ V, const uint8_t* __restrict__ keymask,
-                                                                      const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
-                                                                      const float* __restrict__ LSE, float* __restrict__ Delta,
-                                                                      bf16_t* __restrict__ dQ, int L, int Hq, int Hkv, long ldo,
-                                                                      long lddo, float scale, int nt_lds, int per_block) {
-  extern __shared__ __attribute__((aligned(16))) char fat_smem[];
-  __shared__ unsigned sbits[4][FAT_TILES];
-  __shared__ unsigned slist[4][FAT_TILES];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int gu = __builtin_amdgcn_readfirstlane(g);
-  const int nqb = (L + 31) / 32;
-  const int nbh = per_block ? (int)gridDim.x / nqb : (int)gridDim.x;
-  const int qb_only = per_block ? nqb - 1 - (int)(blockIdx.x / nbh) : -1;
-  const int hk = (blockIdx.x % nbh) % Hkv, b = (blockIdx.x % nbh) / Hkv;
-  const int G = Hq / Hkv, hq = hk * G + g;
-  const int ntile = per_block ? qb_only + 1 : nqb;
-  key_bits_all(keymask + (long)b * L, ntile, L, sbits[g]);
-  const int nlive = compact_tiles(sbits[g], ntile, slist[g]);
-  const bf16_t* Kb = K + ((long)b * Hkv + hk) * L * D;
-  const bf16_t* Vb = V + ((long)b * Hkv + hk) * L * D;
-  const bool fits = nlive <= nt_lds;
-  char* const otile = fat_smem + nt_lds * (2 * 32 * 256) + gu * (32 * 256);
-  if (fits) {
-    for (int li = gu; li < nlive; li += 4) {
-      const int kb = (int)slist[g][li];
-      char* slot = fat_smem + li * (2 * 32 * 256);
-      dma_tile(Kb, D, kb * 32, L - 1, slot, lane);
-      dma_tile(Vb, D, kb * 32, L - 1, slot + 32 * 256, lane);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  if (g >= G) return;
-  if (per_block) {
-    if (fits) dq_block<true>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb_only, sbits[g], slist[g], nlive, fat_smem, otile);
-    else dq_block_global(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb_only, sbits[g], slist[g], nlive, otile);
-    return;
-  }
-  for (int qb = nqb - 1; qb >= 0; --qb) {
-    const int nlist = tiles_upto(slist[g], nlive, qb);
-    if (fits) dq_block<true>(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, fat_smem, otile);
-    else dq_block_global(Q, K, V, O, dO, LSE, Delta, dQ, L, Hq, Hkv, ldo, lddo, scale, b, hk, hq, qb, sbits[g], slist[g], nlist, otile);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -859,71 +720,8 @@ extern "C" int vq3_qwen_flash_fwd(const void* Q, const void* K, const void* V, c
   return 0;
 }
 
-static int g_fat_per_block = 0;
-// LDS bytes of the fat kernels for a caller-supplied bound (0: the bound does not allow them)
-static int fat_slots(int L, int max_live_tiles) {
-  const int nqb = (L + 31) / 32;
-  if (max_live_tiles <= 0 || nqb > FAT_TILES) return 0;
-  static int fat_on = -1, fat_max = 4;
-  if (fat_on < 0) {
-    const char* e = getenv("VQ3_QWEN_FAT");
-    fat_on = e ? atoi(e) : 1;
-    const char* m = getenv("VQ3_QWEN_FAT_MAX");
-    if (m) fat_max = atoi(m);
-    if (fat_max > FAT_TILES - 1) fat_max = FAT_TILES - 1;        // 7 slots + 4 output tiles = 144 KiB (+ the key-bit words) of 160
-    if (fat_max < 1) fat_max = 1;
-    if (fat_on) {
-      const int bytes = fat_max * 2 * 32 * 256 + 4 * 32 * 256;
-      if (hipFuncSetAttribute((const void*)qwen_flash_fwd_fat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-          hipFuncSetAttribute((const void*)qwen_flash_bwd_dq_fat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        fat_on = 0;
-      }
-    }
-  }
-  if (!fat_on) return 0;
-  g_fat_per_block = fat_on == 2 ? 1 : 0;
-  const int nt = max_live_tiles < nqb ? max_live_tiles : nqb;
-  return nt <= fat_max ? nt : 0;              // more slots than that: one workgroup per CU, the per-block kernels do better
-}
-
-extern "C" int vq3_qwen_flash_fwd_b(const void* Q, const void* K, const void* V, const void* keymask, void* O, float* LSE,
-                                    int32_t B, int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, float scale,
-                                    int32_t max_live_tiles, void* stream) {
-  const int nt = fat_slots(L, max_live_tiles);
-  if (!nt) return vq3_qwen_flash_fwd(Q, K, V, keymask, O, LSE, B, L, Hq, Hkv, Dh, ldo, scale, stream);
-  VQ3_CHECK_ARG(Q && K && V && keymask && O && LSE, "qwen_flash_fwd: null pointer");
-  if (flash_check("qwen_flash_fwd", B, L, Hq, Hkv, Dh)) return 1;
-  VQ3_CHECK_ARG(ldo >= (long)Hq * D && ldo % 4 == 0, "qwen_flash_fwd: bad output row stride");
-  hipLaunchKernelGGL(qwen_flash_fwd_fat_kernel, dim3(B * Hkv * (g_fat_per_block ? (L + 31) / 32 : 1)), dim3(256), nt * 2 * 32 * 256 + 4 * 32 * 256,
-                     (hipStream_t)stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const uint8_t*)keymask, (bf16_t*)O, LSE, L, Hq, Hkv,
-                     (long)ldo, scale, nt, g_fat_per_block);
-  VQ3_CHECK_LAUNCH("qwen_flash_fwd(fat)");
-  return 0;
-}
-
 static int launch_dkv(const void* Q, const void* K, const void* V, const void* keymask, const void* dO, const float* LSE, float* Delta,
                       void* dK, void* dV, int kv_parts, int B, int L, int Hq, int Hkv, long lddo, float scale, hipStream_t s);
-
-extern "C" int vq3_qwen_flash_bwd_b(const void* Q, const void* K, const void* V, const void* keymask, const void* O,
-                                    const void* dO, const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t kv_parts,
-                                    int32_t B, int32_t L, int32_t Hq, int32_t Hkv, int32_t Dh, int64_t ldo, int64_t lddo,
-                                    float scale, int32_t max_live_tiles, void* stream) {
-  const int nt = fat_slots(L, max_live_tiles);
-  if (!nt) return vq3_qwen_flash_bwd(Q, K, V, keymask, O, dO, LSE, Delta, dQ, dK, dV, kv_parts, B, L, Hq, Hkv, Dh, ldo, lddo, scale, stream);
-  VQ3_CHECK_ARG(Q && K && V && keymask && O && dO && LSE && Delta && dQ && dK && dV, "qwen_flash_bwd: null pointer");
-  if (flash_check("qwen_flash_bwd", B, L, Hq, Hkv, Dh)) return 1;
-  VQ3_CHECK_ARG(ldo >= (long)Hq * D && lddo >= (long)Hq * D && ldo % 8 == 0 && lddo % 8 == 0, "qwen_flash_bwd: bad row strides");
-  VQ3_CHECK_ARG(kv_parts >= 1 && kv_parts <= 4, "qwen_flash_bwd: kv_parts must be 1..4");
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(qwen_flash_bwd_dq_fat_kernel, dim3(B * Hkv * (g_fat_per_block ? (L + 31) / 32 : 1)), dim3(256), nt * 2 * 32 * 256 + 4 * 32 * 256, s,
-                     (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const uint8_t*)keymask, (const bf16_t*)O, (const bf16_t*)dO, LSE, Delta,
-                     (bf16_t*)dQ, L, Hq, Hkv, (long)ldo, (long)lddo, scale, nt, g_fat_per_block);
-  const int rc = launch_dkv(Q, K, V, keymask, dO, LSE, Delta, dK, dV, kv_parts, B, L, Hq, Hkv, (long)lddo, scale, s);
-  if (rc) return rc;
-  VQ3_CHECK_LAUNCH("qwen_flash_bwd(fat dQ)");
-  return 0;
-}
 
 extern "C" int vq3_qwen_flash_bwd(const void* Q, const void* K, const void* V, const void* keymask, const void* O,
                                   const void* dO, const float* LSE, float* Delta, void* dQ, void* dK, void* dV, int32_t kv_parts,

@@ -768,22 +768,21 @@ def linear_fp8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, residual:
 
 
 # ---------------------------------------------------------------------------------------------- fused Qwen3 attention
-def qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, scale, out: Optional[torch.Tensor] = None, max_live_tiles: int = 0):
-    """-> (O bf16 [B*L, Hq*D] token-major, LSE f32 [B, Hq, L]). max_live_tiles: the caller's bound on the attended 32-key tiles of any
-    sample (0 = unknown): selects the one-workgroup-per-(sample, kv head) kernels where they pay; never changes the result."""
+def qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, scale, out: Optional[torch.Tensor] = None):
+    """-> (O bf16 [B*L, Hq*D] token-major, LSE f32 [B, Hq, L])."""
     for t in (Q, K, V):
         _req(t, BF16, "qwen_flash"); assert t.is_contiguous()
     _req(keymask, torch.uint8, "qwen_flash keymask")
     assert Q.shape == (B, Hq, L, D) and K.shape == (B, Hkv, L, D) and V.shape == K.shape and keymask.shape == (B, L)
     O = _out2d(out, B * L, Hq * D, Q, "qwen_flash_fwd")
     lse = torch.empty(B * Hq * L + 4, device=Q.device, dtype=F32)[: B * Hq * L].view(B, Hq, L)   # 16 B of slack
-    check(_lib.load().vq3_qwen_flash_fwd_b(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
-                                           lse.data_ptr(), B, L, Hq, Hkv, D, Hq * D, scale, int(max_live_tiles), _stream()),
-          "vq3_qwen_flash_fwd_b")
+    check(_lib.load().vq3_qwen_flash_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
+                                         lse.data_ptr(), B, L, Hq, Hkv, D, Hq * D, scale, _stream()),
+          "vq3_qwen_flash_fwd")
     return O, lse
 
 
-def qwen_flash_bwd(Q, K, V, keymask, O, dO, lse, B, L, Hq, Hkv, D, scale, kv_parts: Optional[int] = None, max_live_tiles: int = 0):
+def qwen_flash_bwd(Q, K, V, keymask, O, dO, lse, B, L, Hq, Hkv, D, scale, kv_parts: Optional[int] = None):
     """O, dO: bf16 [B*L, Hq*D] token-major. -> dQ [B,Hq,L,D]; dK, dV bf16 [kv_parts, B,Hkv,L,D] partial slabs (kv_parts = 1 gives
     plain [B,Hkv,L,D], the default); qwen_qkprep_bwd adds the slabs. Worth it when most key tiles are padding (Qwen3ForCausalLM.forward_hidden decides)."""
     _req(O, BF16, "flash_bwd O"); _req(dO, BF16, "flash_bwd dO"); _req(lse, F32, "flash_bwd lse")
@@ -796,10 +795,10 @@ def qwen_flash_bwd(Q, K, V, keymask, O, dO, lse, B, L, Hq, Hkv, D, scale, kv_par
     dK = torch.empty(kv_shape, device=dev, dtype=BF16)
     dV = torch.empty(kv_shape, device=dev, dtype=BF16)
     delta = torch.empty(B * Hq * L + 4, device=dev, dtype=F32)
-    check(_lib.load().vq3_qwen_flash_bwd_b(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
-                                           dO.data_ptr(), lse.data_ptr(), delta.data_ptr(), dQ.data_ptr(), dK.data_ptr(),
-                                           dV.data_ptr(), kv_parts, B, L, Hq, Hkv, D, O.stride(0), dO.stride(0), scale,
-                                           int(max_live_tiles), _stream()), "vq3_qwen_flash_bwd_b")
+    check(_lib.load().vq3_qwen_flash_bwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), keymask.data_ptr(), O.data_ptr(),
+                                         dO.data_ptr(), lse.data_ptr(), delta.data_ptr(), dQ.data_ptr(), dK.data_ptr(),
+                                         dV.data_ptr(), kv_parts, B, L, Hq, Hkv, D, O.stride(0), dO.stride(0), scale,
+                                         _stream()), "vq3_qwen_flash_bwd")
     return dQ, dK, dV
 
 

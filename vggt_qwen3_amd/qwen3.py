@@ -375,8 +375,7 @@ class Qwen3ForCausalLM(nn.Module):
                                               D, c.rms_norm_eps, want_rstd=ctx is not None)
         if self._flash:
             # fused causal GQA attention: scores stay in registers; LSE is all the backward needs
-            ao, lse = ops.qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, D ** -0.5, out=ao_out,
-                                         max_live_tiles=getattr(self, "_max_live", 0))
+            ao, lse = ops.qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, D ** -0.5, out=ao_out)
             if ctx is not None:
                 ctx.update(qkv=qkv, Q=Q, K=K, V=V, qr=qr, kr=kr, lse=lse, ao=ao)
             return ao
@@ -403,22 +402,6 @@ class Qwen3ForCausalLM(nn.Module):
             attention_mask = torch.cat([attention_mask, attention_mask.new_zeros((B, L - L0))], dim=1)
         keymask = (attention_mask != 0).to(torch.uint8).contiguous()
         kv_parts = 1
-        # Upper bound of the attended 32-key tiles of any sample: lets the attention entry points pick the one-workgroup-per-(sample, kv
-        # head) kernels (short rows, few attended tiles: what the reference's collator produces). OFF by default (VQ3_QWEN_FAT=1 turns
-        # them on): bit-identical and 20-30 % faster on cold operands (tools/bench_qwen_flash.py 48), but inside the step the forward and
-        # dQ launches take the same 52 / 86 us either way - DESIGN.md section 9.
-        max_live = 0
-        if self._flash and L <= 256 and os.environ.get("VQ3_QWEN_FAT", "0") != "0":
-            nkb_ = (L + 31) // 32
-            pad_ = nkb_ * 32 - L
-            km_ = torch.nn.functional.pad(keymask, (0, pad_)) if pad_ else keymask
-            count_ = lambda: int(km_.view(B, nkb_, 32).any(-1).sum(1).max().item())
-            if os.environ.get("VQ3_QWEN_FAT_HOSTREAD", "0") == "0":
-                max_live = min(4, nkb_)          # no host read: four LDS slots; a sample with more attended tiles takes the kernel's generic path
-            else:
-                max_live = PLAN.get(("max_live_key_tiles", L), plan_key, count_) if plan_key is not None else count_()
-                max_live = max(1, max_live)
-        self._max_live = max_live
         dkv_lds = os.environ.get("VQ3_QWEN_DKV_LDS", "1") != "0"
         if "VQ3_QWEN_KV_PARTS" in os.environ:
             kv_parts = int(os.environ["VQ3_QWEN_KV_PARTS"])
@@ -456,7 +439,7 @@ class Qwen3ForCausalLM(nn.Module):
                 ctx.update(h_in=h, r1=r1, xn1=xn1, h_mid=h_mid, r2=r2, xn2=xn2, gu=gu, act=act)
                 saved.append(ctx)
             h = h_out
-        out = {"layers": saved, "B": B, "L": L, "L0": L0, "keymask": keymask, "kv_parts": kv_parts, "max_live": max_live}
+        out = {"layers": saved, "B": B, "L": L, "L0": L0, "keymask": keymask, "kv_parts": kv_parts}
         if wd_off is not None:
             out["wd_off"], out["wd_ticket"] = wd_off, self._wd_ticket
         return h, out
@@ -718,8 +701,7 @@ class Qwen3ForCausalLM(nn.Module):
                 if wd_off is None:
                     self._wgrad(f"l{i}.o", dh_mid, ctx["ao"], accumulate)
                 dQ, dK, dV = ops.qwen_flash_bwd(ctx["Q"], ctx["K"], ctx["V"], saved["keymask"], ctx["ao"], d_ao, ctx["lse"],
-                                                B, L, self.Hq, self.Hkv, D, D ** -0.5, kv_parts=saved.get("kv_parts", 1),
-                                                max_live_tiles=saved.get("max_live", 0))
+                                                B, L, self.Hq, self.Hkv, D, D ** -0.5, kv_parts=saved.get("kv_parts", 1))
             else:
                 d_ao = torch.empty((B, self.Hq, L, D), device=dev, dtype=BF16)
                 ops.gemm_raw(dh_mid, Wo, d_ao, L, D, H, H, self.Hq * D, D, nb1=B, nb2=self.Hq, sA=(L * H, 0), sB=(0, D),
