@@ -464,7 +464,7 @@ def main():
                 dt8 = (time.perf_counter() - t0) / n8
                 assert not model._vis_group
                 variants[key] = {"value": round(B / dt8, 3), "unit": "samples/s", "ms_per_step": round(dt8 * 1e3, 2), "steps": n8,
-                                 "views": 8, "geom_tokens": 8, "fp8_text_forward": fp8, "batch_per_gpu": B, "loss": round(float(l8.item()), 4),
+                                 "views": 8, "geom_tokens": 8, "fp8_text_forward": fp8, "fp8_text_dgrad": bool(fp8 and model.text_model._fp8T is not None), "batch_per_gpu": B, "loss": round(float(l8.item()), 4),
                                  "executed_tflop_per_sample": round(tf8, 3),
                                  "executed_flops_utilisation_vs_bf16_peak": round(B / dt8 * tf8 / BF16_DENSE_PEAK_TFLOPS, 4),
                                  "workload": ("BASELINE config %s on 1 GPU: VGGT aggregator @%dpx x 8 views (8 232-token global attention) "
@@ -474,6 +474,16 @@ def main():
             model.text_model.enable_fp8_forward(args.fp8)
             model.geom_tokens, trainer.geom_on = (8 if args.geom else 0), bool(args.geom)
             trainer.geom_grad.zero_()
+            if not args.fp8:
+                # the e4m3 text model at ONE view (the headline's workload with C5's arithmetic): here the text model is most of the
+                # step, so this is where the e4m3 kernels' worth shows
+                model.text_model.enable_fp8_forward(True)
+                d5, l5 = timed_windows(cycles, [cycles[0]])
+                variants["c5_c2_variant"] = {"value": round(world * B * args.steps / d5, 3), "unit": "samples/s", "ms_per_step": round(d5 / args.steps * 1e3, 2),
+                                             "views": V, "fp8_text_forward": True, "fp8_text_dgrad": model.text_model._fp8T is not None,
+                                             "grad_accum": accum, "loss": round(float(l5.item()), 4),
+                                             "workload": "the headline's workload (config C2) with the Qwen3 projections' forward and input-gradient GEMMs in e4m3"}
+                model.text_model.enable_fp8_forward(False)
 
     # ---- live roofline of the dominant kernel (gemm_nt_kernel): one extra instrumented step, HIP events per launch
     roof = None

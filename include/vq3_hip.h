@@ -384,6 +384,28 @@ int vq3_quant_fp8_rows(const void* x_bf16, int64_t ldx, int64_t rows, int32_t K,
 int vq3_gemm_fp8_nt(const void* Xq, const float* x_scale, const void* Wq, const float* w_scale, void* C,
                     const void* residual, int32_t M, int32_t N, int32_t K, int64_t ldx, int64_t ldw, int64_t ldc,
                     int64_t ldr, void* stream);
+/* The same quantisation of x[r, k] * colmul[k] (colmul f32 [K], 16-byte aligned): the dgrad GEMMs dX = dY . W contract over W's output
+ * channels, so W's per-output-channel scales are folded into dY before its rows are quantised. */
+int vq3_quant_fp8_rows_scaled(const void* x_bf16, int64_t ldx, int64_t rows, int32_t K, const float* colmul, void* q, int64_t ldq,
+                              float* scale, void* stream);
+/* dst[c, r] = src[r, c] for BYTE matrices (e4m3 weights -> the W^T operand of the NT dgrad GEMMs). R, C, lds, ldd multiples of 16. */
+int vq3_transpose_u8(const void* src, void* dst, int32_t R, int32_t C, int64_t lds, int64_t ldd, void* stream);
+/* e4m3 GEMM with the bf16 path's fused epilogues, on the 256x256 8-phase kernel (gemm6.hip, F8 instantiations), the last round of tiles
+ * split along K where that pays. mode 0: C[M,N] = bf16(x_scale[m] w_scale[n] sum_k Xq[m,k] Wq[n,k]) (+ residual); mode 1 (SwiGLU forward,
+ * modeling_qwen3.py:81-83): Wq = the gate|up weight [N = 2 I, K], C = act [M, I] = bf16(bf16(silu(gate)) * up), gu (or NULL) = gate|up
+ * [M, 2 I]; mode 2 (SwiGLU backward): the product is d(act) [M, N] and is never stored - dgu [M, 2 N] leaves, from the saved gate|up gu.
+ * w_scale == NULL means 1 (scales already folded into Xq: vq3_quant_fp8_rows_scaled). No counterpart in the reference (it has no fp8). */
+typedef struct vq3_gemm_fp8_desc {
+  const void* Xq; const float* x_scale;
+  const void* Wq; const float* w_scale;
+  void* C; const void* residual;
+  int32_t M, N, K;
+  int64_t ldx, ldw, ldc, ldr;
+  int32_t mode;
+  void* gu;
+  void* dgu;
+} vq3_gemm_fp8_desc;
+int vq3_gemm_fp8_ex(const vq3_gemm_fp8_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused causal GQA attention for Qwen3, head_dim 128, 1..4 query heads per kv head (modeling_qwen3.py:185-207,254-280 + autograd):

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE - CPU statement of the fp8 forward contract of BASELINE config C5 ("Qwen3 linear
+"""TEST INFRASTRUCTURE - CPU statement of the fp8 contract (forward projections and, since round 4, their input-gradient GEMMs) of BASELINE config C5 ("Qwen3 linear
 weights in OCP fp8-e4m3 + per-output-channel fp32 scales; activations bf16 -> fp8 on the fly; fp32 accumulate").
 The reference contains no fp8 code, so there is nothing of its own to pin against: **parity unpinned** for this
 config; the fixed points are the OCP e4m3 encoding itself (torch.float8_e4m3fn, round-to-nearest-even) and the
@@ -32,6 +32,20 @@ def linear(x: torch.Tensor, w: torch.Tensor, residual: torch.Tensor = None) -> t
     if residual is not None:
         out = (out.float() + residual.float()).to(torch.bfloat16)
     return out
+
+
+def quant_rows_scaled(x: torch.Tensor, colmul: torch.Tensor):
+    """quant_rows of x * colmul[None, :] (fp32 product of the bf16 value and the fp32 multiplier): how dY enters the dgrad GEMMs."""
+    return quant_rows(x.float() * colmul.float()[None, :])
+
+
+def dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """dX = dY . W under the C5 contract (round 4): W [N, K] is the SAME e4m3 tensor the forward multiplies by (one fp32 scale per
+    output channel n); those scales run along this product's contraction, so they are folded into dY before its rows are quantised:
+    dX[m, k] = bf16( t[m] * sum_n q(dY[m, n] s[n]) q_w[n, k] ), fp32 accumulation."""
+    wq, ws = quant_rows(w)
+    dq, t = quant_rows_scaled(dy, ws)
+    return ((dq.float() @ wq.float()) * t[:, None]).to(torch.bfloat16)
 
 
 class fp8_projections:

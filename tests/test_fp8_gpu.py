@@ -76,6 +76,102 @@ def test_fp8_linear_vs_oracle_and_bf16(ops):
                      torch.zeros(4, 64, dtype=torch.uint8, device="cuda"), torch.ones(4, device="cuda"))
 
 
+def test_fp8_v6_kernel_exact_integers_and_epilogues(ops):
+    """The e4m3 instantiations of the 256 x 256 8-phase kernel (gemm6.hip F8; vq3_gemm_fp8_ex): operand lane map with exact small integers
+    (row-, column- and k-dependent), ragged M / N, an odd number of K tiles, row and column scales, residual; the last-round K split
+    (50 tiles x 4 slices at 1200 x 2560) gives the same integers; SwiGLU forward / backward epilogues equal the two-launch forms."""
+    torch.manual_seed(0)
+    for M, N, K in [(300, 520, 384), (1200, 2560, 2560), (257, 264, 128), (2000, 2560, 1152)]:
+        x = torch.randint(-3, 4, (M, K)).float()
+        w = torch.randint(-2, 3, (N, K)).float()
+        x[:, 0] = torch.arange(M).float() % 5
+        w[:, K - 1] = (torch.arange(N).float() % 3) - 1
+        x[0] = (torch.arange(K) % 4).float()
+        ref = x @ w.t()
+        xs = (torch.rand(M) + 0.5).cuda(); ws = (torch.rand(N) + 0.5).cuda()
+        out = ops.gemm_fp8_ex(_e4m3_bytes(x).cuda(), torch.ones(M, device="cuda"), _e4m3_bytes(w).cuda(), None)
+        assert torch.equal(out.float().cpu(), ref.to(BF16).float()), (M, N, K)
+        r = torch.randn(M, N).to(BF16)
+        out = ops.gemm_fp8_ex(_e4m3_bytes(x).cuda(), xs, _e4m3_bytes(w).cuda(), ws, residual=r.cuda()) if False else \
+            ops.gemm_fp8(_e4m3_bytes(x).cuda(), xs, _e4m3_bytes(w).cuda(), ws, residual=r.cuda())
+        want = ((ref * xs.cpu()[:, None] * ws.cpu()[None, :]).to(BF16).float() + r.float()).to(BF16)
+        assert ((out.float().cpu() - want.float()).norm() / want.float().norm()).item() < 4e-3, (M, N, K)
+    # fused SwiGLU epilogues against plain product + element-wise kernels
+    M, H, I = 1200, 2560, 1024
+    x = torch.randn(M, H, device="cuda").to(BF16)
+    wgu = (torch.randn(2 * I, H, device="cuda") * 0.03).to(BF16)
+    xq, xs = ops.quant_fp8_rows(x); wq, ws = ops.quant_fp8_rows(wgu)
+    gu_ref = ops.gemm_fp8_ex(xq, xs, wq, ws)
+    gu, act = ops.gemm_fp8_ex(xq, xs, wq, ws, mode=1)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, ops.silu_mul_fwd(gu_ref))
+    none, act2 = ops.gemm_fp8_ex(xq, xs, wq, ws, mode=1, keep_gu=False)
+    assert none is None and torch.equal(act2, act)
+    dy = torch.randn(M, H, device="cuda").to(BF16)
+    wdown = (torch.randn(H, I, device="cuda") * 0.03).to(BF16)             # down_proj weight [H, I]: d(act) = dY . W_down
+    wdq, wds = ops.quant_fp8_rows(wdown)
+    wdqT = ops.transpose_u8(wdq)
+    assert torch.equal(wdqT, wdq.t().contiguous())
+    q, t = ops.quant_fp8_rows_scaled(dy, wds)
+    dact = ops.gemm_fp8_ex(q, t, wdqT, None)
+    dgu = ops.gemm_fp8_ex(q, t, wdqT, None, mode=2, gu=gu_ref)
+    want = ops.silu_mul_bwd(dact, gu_ref)
+    assert ((dgu.float() - want.float()).norm() / want.float().norm()).item() < 1e-2
+
+
+def test_fp8_dgrad_vs_oracle_contract(ops):
+    """dX = dY . W with the forward's e4m3 weights (round 4, C5): scaled row quantisation bit-exact against oracle/fp8.py, the product
+    within accumulation-order tolerance of the oracle's dgrad, and what e4m3 costs against the unquantised product."""
+    from oracle import fp8 as ofp8
+    torch.manual_seed(3)
+    for M, N, K in [(1200, 6144, 2560), (333, 2560, 9728), (1200, 19456, 2560)]:
+        dy = (torch.randn(M, N) * torch.logspace(-2, 1, M)[:, None]).to(BF16)
+        w = (torch.randn(N, K) * 0.02).to(BF16)
+        wq, ws = ops.quant_fp8_rows(w.cuda())
+        q, t = ops.quant_fp8_rows_scaled(dy.cuda(), ws)
+        rq, rt = ofp8.quant_rows_scaled(dy, ws.cpu())
+        assert torch.equal(t.cpu(), rt) and torch.equal(q.cpu(), rq.view(torch.uint8))
+        dx = ops.gemm_fp8_ex(q, t, ops.transpose_u8(wq), None)
+        ref = ofp8.dgrad(dy, w)
+        e = ((dx.float().cpu() - ref.float()).norm() / ref.float().norm()).item()
+        assert e < 4e-3, (M, N, K, e)
+        full = dy.float() @ w.float()
+        e2 = ((dx.float().cpu() - full).norm() / full.norm()).item()
+        assert e2 < 6e-2, e2
+
+
+def test_qwen3_fp8_dgrad_gradients_vs_bf16_path():
+    """C5 with the e4m3 dgrad GEMMs on the tiny golden model: every weight gradient and d(inputs_embeds) against the bf16 backward of
+    the SAME fp8 forward (what the dgrad quantisation alone costs: stated tolerance 6e-2 relative L2 per tensor, measured 2-4e-2) and
+    against the bf16 golden gradients (forward + dgrad quantisation together, 1.5e-1)."""
+    from tests.golden_io import bf16
+    model, z, c = _tiny()
+    emb = bf16(z["inputs_embeds"]).cuda()
+    mask = torch.from_numpy(z["attention_mask"]).cuda()
+    labels = torch.from_numpy(z["labels"]).cuda()
+
+    def grads(dgrad):
+        model.enable_fp8_forward(True, dgrad=dgrad)
+        model.flat_g.zero_()
+        h, saved = model.forward_hidden(emb, mask, save=True)
+        loss, head = model.loss_head(h, labels, save=True, L=saved["L"])
+        dh = model.backward_loss_head(head, mask.shape[0] * saved["L"], 1.0, accumulate=False)
+        demb = model.backward_hidden(saved, dh, accumulate=False)
+        return loss.item(), model.flat_g.float().clone(), demb.float().clone()
+
+    l0, g0, d0 = grads(False)
+    l1, g1, d1 = grads(True)
+    assert l0 == l1                                              # the forward is the same e4m3 forward
+    assert model._fp8T, "the tiny model's projections qualify for the e4m3 dgrad"
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    assert rel(d1, d0) < 6e-2, rel(d1, d0)
+    for name, (off, shape) in model.table.items():
+        n = int(np.prod(shape))
+        a, b = g1[off:off + n], g0[off:off + n]
+        if b.norm() > 0:
+            assert rel(a, b) < 6e-2, (name, rel(a, b))
+    model.enable_fp8_forward(False)
+
+
 def _tiny():
     from tests.golden_io import load, meta, weights
     from tests.test_parity_gpu import _tiny_qcfg

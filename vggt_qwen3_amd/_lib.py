@@ -40,6 +40,12 @@ class GemmLnFold(C.Structure):
     _fields_ = [("stats_in", c_p), ("parts_in", i32), ("eps", f32), ("colsum", c_p), ("stats_out", c_p)]
 
 
+class GemmFp8Desc(C.Structure):
+    _fields_ = [("Xq", c_p), ("x_scale", c_p), ("Wq", c_p), ("w_scale", c_p), ("C", c_p), ("residual", c_p),
+                ("M", i32), ("N", i32), ("K", i32), ("ldx", i64), ("ldw", i64), ("ldc", i64), ("ldr", i64),
+                ("mode", i32), ("gu", c_p), ("dgu", c_p)]
+
+
 class ColsumJob(C.Structure):
     _fields_ = [("part", c_p), ("out_bf16", c_p), ("nrows", i32), ("cols", i32), ("accumulate", i32)]
 
@@ -102,6 +108,9 @@ SIGNATURES = {
     "vq3_decode_advance": [c_p, i32, c_p, c_p],
     "vq3_quant_fp8_rows": [c_p, i64, i64, i32, c_p, i64, c_p, c_p],
     "vq3_gemm_fp8_nt": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i64, i64, c_p],
+    "vq3_quant_fp8_rows_scaled": [c_p, i64, i64, i32, c_p, c_p, i64, c_p, c_p],
+    "vq3_transpose_u8": [c_p, c_p, i32, i32, i64, i64, c_p],
+    "vq3_gemm_fp8_ex": [c_p, c_p],
     "vq3_qwen_flash_fwd": [c_p] * 6 + [i32, i32, i32, i32, i32, i64, f32, c_p],
     "vq3_qwen_flash_bwd": [c_p] * 11 + [i32, i32, i32, i32, i32, i32, i64, i64, f32, c_p],
     "vq3_gemm_force_config": [i32],

@@ -470,7 +470,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   p.stamps = nullptr;
   p.nbw = 1;
   p.stagger = 0;
-  p.sk_full = p.sk_rem = p.sk_s = 0; p.sk_ws = nullptr; p.sk_cnt = nullptr;
+  p.sk_full = p.sk_rem = p.sk_s = 0; p.sk_ws = nullptr; p.sk_cnt = nullptr; p.f8_rs = p.f8_cs = nullptr;
   if (ve) {
     VQ3_CHECK_ARG(ve->Q && ve->K && ve->V, "gemm_vit_qkv: null output pointer");
     VQ3_CHECK_ARG(!d->transA && !d->transB && d->K % BK == 0 && !d->out_f32 && !d->accumulate && !d->R && !d->colscale && d->act == 0 &&

@@ -52,7 +52,12 @@ constexpr int HALF = 128 * 128;          // bytes per half-tile (128 rows x 64 k
 // SPLIT (256 x 256, plain epilogue only): the launch's last, partly filled round of tiles is cut along K over the CUs it would leave idle
 // (GemmParams: sk_*). 9600 x 2560 outputs - every o / down projection and two of the four dgrads of a pass of 8 micro-batches - are 380
 // tiles = 1.48 rounds of 256 CUs: 124 tiles x 2 K halves run as ONE half-length round instead of a full one.
-template <int AH, int BH, bool OUT_F32, int EK = 0, bool SPLIT = false>
+// F8 (256 x 256, EK 0 / 2 / 4; config C5): A and B are OCP e4m3 bytes, a K tile is 128 elements - the same 128-byte rows, the same DMA
+// image, the same number of LDS reads, and ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales, 32 cycles) where the bf16 kernel
+// issues two 16x16x32 MFMAs (16 cycles each) per K tile and 16 x 16 output: twice the FLOPs per K tile at the same cadence. The real
+// scales - one per A row (token), one per B row (output channel) - multiply the accumulators in the epilogue (p.f8_rs / p.f8_cs).
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+template <int AH, int BH, bool OUT_F32, int EK = 0, bool SPLIT = false, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   constexpr bool HAS_LN = (EK == 1 || EK == 3);
   constexpr int BM = 128 * AH, BN = 128 * BH;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
 #pragma unroll
       for (int h = 0; h < AH; ++h) {
         int ra = tm0 + h * 128 + r; ra = ra < p.M ? ra : p.M - 1;
-        offA[h][j] = (unsigned)(((long)ra * p.lda + kch * 8) * 2);
+        offA[h][j] = F8 ? (unsigned)((long)ra * p.lda + kch * 16) : (unsigned)(((long)ra * p.lda + kch * 8) * 2);
       }
 #pragma unroll
       for (int h = 0; h < BH; ++h) {
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
           rb = li < BN / 2 ? (tn0 >> 1) + li : (p.N >> 1) + (tn0 >> 1) + li - BN / 2;
         }
         rb = rb < p.N ? rb : p.N - 1;
-        offB[h][j] = (unsigned)(((long)rb * p.ldb + kch * 8) * 2);
+        offB[h][j] = F8 ? (unsigned)((long)rb * p.ldb + kch * 16) : (unsigned)(((long)rb * p.ldb + kch * 8) * 2);
       }
     }
   };
@@ -117,30 +122,44 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   f32x4 acc[AH * 4][BH * 2];
 
   const int fr = lane & 15, fq = lane >> 4;
-  const int a_base = (wr * 64 + fr) * 128 + ((fq ^ (fr & 7)) << 4);
-  const int b_base = (wc * 32 + fr) * 128 + ((fq ^ (fr & 7)) << 4);
+  // bf16: lane (fr, fq) holds k = 8 fq .. + 7 of half kh (16-byte chunk fq + 4 kh); e4m3: k = 32 fq .. + 31 (chunks 2 fq and 2 fq + 1,
+  // kept as the two halves [.][0], [.][1] of the operand)
+  const int a_base = (wr * 64 + fr) * 128 + (((F8 ? 2 * fq : fq) ^ (fr & 7)) << 4);
+  const int b_base = (wc * 32 + fr) * 128 + (((F8 ? 2 * fq : fq) ^ (fr & 7)) << 4);
+  constexpr int KHX = F8 ? 4 : 6;        // address bit that separates the two 16-byte pieces of a fragment
 
   bf16x8 xa[4][2], wb0[2][2], wb1[2][2];
   auto read_a = [&](const char* slot) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) xa[mt][kh] = *reinterpret_cast<const bf16x8*>(slot + ((a_base ^ (kh << 6)) + mt * 2048));
+      for (int kh = 0; kh < 2; ++kh) xa[mt][kh] = *reinterpret_cast<const bf16x8*>(slot + ((a_base ^ (kh << KHX)) + mt * 2048));
   };
   auto read_b = [&](const char* slot, bf16x8 (&wb)[2][2]) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) wb[nt][kh] = *reinterpret_cast<const bf16x8*>(slot + ((b_base ^ (kh << 6)) + nt * 2048));
+      for (int kh = 0; kh < 2; ++kh) wb[nt][kh] = *reinterpret_cast<const bf16x8*>(slot + ((b_base ^ (kh << KHX)) + nt * 2048));
+  };
+  auto cat8 = [](const bf16x8& lo, const bf16x8& hi) -> i32x8_t {
+    const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+    return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
   };
 #define V6_MMA(I, J, WB)                                                                                         \
   do {                                                                                                           \
     __builtin_amdgcn_s_setprio(1);                                                                               \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                             \
+    if constexpr (F8) {                                                                                          \
       _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                           \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
-          acc[(I) * 4 + mt][(J) * 2 + nt] =                                                                      \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[nt][kh], xa[mt][kh], acc[(I) * 4 + mt][(J) * 2 + nt], 0, 0, 0); \
+          acc[(I) * 4 + mt][(J) * 2 + nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                    \
+              cat8(WB[nt][0], WB[nt][1]), cat8(xa[mt][0], xa[mt][1]), acc[(I) * 4 + mt][(J) * 2 + nt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
+    } else {                                                                                                     \
+      _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                           \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                         \
+          _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                       \
+            acc[(I) * 4 + mt][(J) * 2 + nt] =                                                                    \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[nt][kh], xa[mt][kh], acc[(I) * 4 + mt][(J) * 2 + nt], 0, 0, 0); \
+    }                                                                                                            \
     __builtin_amdgcn_s_setprio(0);                                                                               \
   } while (0)
   // first barrier of a phase: this wave's LDS reads are retired, then everybody meets
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);  \
   } while (0)
 
-  int nt = p.K / BK6;
+  int nt = F8 ? p.K / 128 : p.K / BK6;          // K tiles of 128 bytes per row
   int sk_slice = -1, sk_j = 0;       // (SPLIT) this workgroup's K slice of tile sk_full + sk_j; -1: a whole tile
   // two-phase variants keep THREE K-tile buffers (3 x 48 KiB): tile t+2 is staged whole while tile t is multiplied, into the
   // buffer tile t-1 left a full tile ago. Slots: A0 A1 B (256 x 128) or A B0 B1 (128 x 256).
@@ -457,6 +476,25 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       if (nt > 1) stage_tile(1, smem + BUF);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // e4m3 operands: the per-token and per-output-channel scales of this lane's rows / column quads
+    float f8r[AH * 4];
+    f32x4 f8c[BH * 2];
+    if constexpr (F8) {
+#pragma unroll
+      for (int i = 0; i < AH * 4; ++i) {
+        int m = m0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fr;
+        m = m < p.M ? m : p.M - 1;
+        f8r[i] = p.f8_rs ? p.f8_rs[m] : 1.f;
+      }
+#pragma unroll
+      for (int q = 0; q < BH * 2; ++q) {
+        const int li = (q >> 1) * 128 + wc * 32 + (q & 1) * 16 + 4 * fq;
+        int n = n0 + li;
+        if constexpr (EK == 4) n = li < BN / 2 ? (n0 >> 1) + li : (p.N >> 1) + (n0 >> 1) + li - BN / 2;       // (the weight row a tile column multiplies)
+        n = n + 3 < p.N ? n : (p.N >= 4 ? p.N - 4 : 0);
+        f8c[q] = p.f8_cs ? *reinterpret_cast<const f32x4*>(p.f8_cs + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+      }
+    }
     auto stage_all = [&](auto act_tag, auto mode_tag, auto ln_tag) {
       constexpr int ACT = decltype(act_tag)::value, MODE = decltype(mode_tag)::value;
       constexpr bool LN = LN_FUSED && decltype(ln_tag)::value;
@@ -472,6 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
             for (int nt2 = 0; nt2 < 2; ++nt2) {
               f32x4 a = acc[i * 4 + mt][j * 2 + nt2];
               if (LN) a = ln_apply(a, lv.x, lv.y, cc[j * 2 + nt2]);
+              if constexpr (F8) a = a * f8r[i * 4 + mt] * f8c[j * 2 + nt2];
               stage_quad<BN, ACT, MODE>(p, smem_c, i * 128 + wr * 64 + mt * 16 + fr, j * 128 + wc * 32 + nt2 * 16 + 4 * fq, a, bias_r[j][nt2], cs_r[j][nt2]);
             }
           if (LN_FUSED) __builtin_amdgcn_sched_barrier(0);      // one 16-row group at a time (register pressure)
@@ -564,7 +603,7 @@ bool sk_workspace(hipStream_t s, float** ws, unsigned** cnt) {
 
 // The split applies when the tile grid leaves a last round at most half full: R = tiles % CUs (or all tiles, when there are fewer than
 // CUs) tiles are cut into S = min(CUs / R, 4) K slices of at least 8 K tiles each. Returns S (0: does not apply).
-int sk_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem) {
+int sk_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem, int ktile = BK6) {
   if (nbatch != 1 || p.out_f32 || p.epi != 0 || p.ln_in) return 0;
   static int off = -1;
   if (off < 0) { const char* e = getenv("VQ3_GEMM_SPLIT"); off = (e && atoi(e) == 0) ? 1 : 0; }      // VQ3_GEMM_SPLIT=0: A/B runs
@@ -574,7 +613,7 @@ int sk_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem) {
   if (r == 0 || r > ncu / 2 || r > SK_MAX_TILES) return 0;
   int sl = ncu / r;
   sl = sl > 4 ? 4 : sl;
-  const int nt = p.K / BK6;
+  const int nt = p.K / ktile;
   if (sl > nt / 8) sl = nt / 8;
   while (sl >= 2 && (long)r * (sl - 1) > 192) --sl;
   // every slice non-empty: per = ceil(nt / sl) slices cover nt with the last one holding nt - (sl - 1) per >= 1 K tiles
@@ -656,6 +695,52 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream, bool split = false)
 }
 
 }  // namespace
+
+// e4m3 operands on the 256 x 256 kernel (config C5): plain / SwiGLU-forward / SwiGLU-backward epilogues, last round split along K where
+// that applies. Returns -1 (nothing launched) outside the contract: the caller takes the loader-ring kernel of gemm_fp8.hip.
+int launch_gemm_v6_f8(GemmParams& p, hipStream_t stream) {
+  constexpr int SMEM = 2 * 4 * HALF + 2048;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_v6_kernel<2, 2, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_v6_kernel<2, 2, false, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_v6_kernel<2, 2, false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_v6_kernel<2, 2, false, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) {
+      vq3_set_error("gemm v6 (e4m3): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_done = true;
+  }
+  if (p.out_f32 || !host_staged_ok(p) || p.K % 128 != 0 || p.ln_in || p.st_out) return -1;
+  if (p.epi == 3 && (p.N >> 1) % 128 != 0) return -1;
+  if (p.epi == 1) return -1;
+  p.mtiles = (p.M + 255) / 256;
+  p.ntiles = (p.N + 255) / 256;
+  choose_tile_order(p, 256, 256, 1);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    (void)hipGetLastError();
+    ncu = n / 8 * 8;
+  }
+  p.stagger = 0;
+  const dim3 grid(p.mtiles * p.ntiles, 1, 1);
+  if (p.epi == 2) hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 2, false, true>), grid, dim3(512), SMEM, stream, p);
+  else if (p.epi == 3) hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 4, false, true>), grid, dim3(512), SMEM, stream, p);
+  else {
+    int full = 0, rem = 0;
+    const int sl = sk_plan(p, 1, ncu, &full, &rem, 128);
+    if (sl >= 2 && sk_workspace(stream, &p.sk_ws, &p.sk_cnt)) {
+      p.sk_full = full; p.sk_rem = rem; p.sk_s = sl;
+      hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 0, true, true>), dim3(full + ((rem + 7) & ~7) * sl, 1, 1), dim3(512), SMEM, stream, p);
+    } else {
+      hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 0, false, true>), grid, dim3(512), SMEM, stream, p);
+    }
+  }
+  return 0;
+}
 
 int gemm_split_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem) { return sk_plan(p, nbatch, ncu, full, rem); }
 int gemm_split_gave_up(hipStream_t stream) {

@@ -60,6 +60,9 @@ struct GemmParams {
   // sk_full + s * roundup8(sk_rem) + j multiplies K slice s (of sk_s) of tile sk_full + j; slices 0 .. sk_s - 2 leave their f32 accumulators in sk_ws
   // and count themselves in sk_cnt[j], slice sk_s - 1 (dispatched last) waits for that count, adds them and runs the epilogue. sk_s <= 1: off
   int sk_full, sk_rem, sk_s;
+  // e4m3 operands (gemm6.hip F8 instantiations): fp32 scale per A row (token) and per B row (output channel); null = 1
+  const float* f8_rs;
+  const float* f8_cs;
   float* sk_ws;
   unsigned* sk_cnt;      // [sk_rem] arrival counts + one error word at [SK_MAX_TILES] (a bounded wait that gave up), zeroed per launch
 };
@@ -745,6 +748,8 @@ int launch_gemm_v2(GemmParams& p, int cfg, int nbatch, hipStream_t stream);
 // v6 (256x256 tile, 8-phase schedule, NT, K % 64 == 0), defined in gemm6.hip.
 int launch_gemm_v6(GemmParams& p, int shape, int nbatch, hipStream_t stream);   // shape: 0 = 256x256, 1 = 256x128, 2 = 128x256,
 // 3 = 256x256 with the last round's tiles split along K (returns -1, nothing launched, where that does not apply)
+// e4m3 operands on the 256 x 256 8-phase kernel (gemm6.hip; p.f8_rs / p.f8_cs, p.epi 0 / 2 / 3): -1 = outside its contract, nothing launched
+int launch_gemm_v6_f8(GemmParams& p, hipStream_t stream);
 // host side of cfg 25 (gemm6.hip): the split plan, and the error word of the stream's workspace (-1: no split launch ever ran on it)
 int gemm_split_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem);
 int gemm_split_gave_up(hipStream_t stream);

@@ -172,18 +172,26 @@ int launch_fp8(GemmParams& p, const float* rs, const float* cs, hipStream_t stre
 
 // ---------------------------------------------------------------------------------------------------- quantisation
 // per-row e4m3 quantisation of a bf16 matrix: scale[r] = amax_r / 448 (1 for an all-zero row), q = rne_e4m3(x * (448/amax))
+// colmul (optional, [K] f32): x[r, k] * colmul[k] is what gets quantised - the dgrad GEMMs fold the weight's per-output-channel scale
+// (which runs along THEIR contraction) into dY this way: dX = t_m * sum_n q(dY[m,n] s_n)[m,n] Wq[n,k]
 __global__ __launch_bounds__(256) void quant_rows_kernel(const bf16_t* __restrict__ x, long ldx, int K, uint8_t* __restrict__ q,
-                                                        long ldq, float* __restrict__ scale) {
+                                                        long ldq, float* __restrict__ scale, const float* __restrict__ colmul) {
   __shared__ float red[4];
   const long r = blockIdx.x;
   const bf16_t* xr = x + r * ldx;
   float amax = 0.f;
   for (int k = threadIdx.x * 8; k < K; k += 2048) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(xr + k);
+    float cm[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (colmul) {
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(colmul + k), c1 = *reinterpret_cast<const f32x4*>(colmul + k + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { cm[j] = c0[j]; cm[4 + j] = c1[j]; }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      amax = fmaxf(amax, fabsf(__builtin_bit_cast(float, v[j] << 16)));
-      amax = fmaxf(amax, fabsf(__builtin_bit_cast(float, v[j] & 0xffff0000u)));
+      amax = fmaxf(amax, fabsf(__builtin_bit_cast(float, v[j] << 16) * cm[2 * j]));
+      amax = fmaxf(amax, fabsf(__builtin_bit_cast(float, v[j] & 0xffff0000u) * cm[2 * j + 1]));
     }
   }
   amax = block_max<4>(amax, red);
@@ -195,15 +203,49 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const bf16_t* __restric
     float f[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      f[2 * j] = __builtin_bit_cast(float, v[j] << 16) * inv;
-      f[2 * j + 1] = __builtin_bit_cast(float, v[j] & 0xffff0000u) * inv;
+      f[2 * j] = __builtin_bit_cast(float, v[j] << 16);
+      f[2 * j + 1] = __builtin_bit_cast(float, v[j] & 0xffff0000u);
     }
+    if (colmul) {
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(colmul + k), c1 = *reinterpret_cast<const f32x4*>(colmul + k + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { f[j] *= c0[j]; f[4 + j] *= c1[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= inv;
     int w0 = 0, w1 = 0;
     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
     w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
     w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
     *reinterpret_cast<u32x2*>(qr + k) = u32x2{(unsigned)w0, (unsigned)w1};
+  }
+}
+
+// dst[c, r] = src[r, c] for a matrix of BYTES (the e4m3 weights' W^T copies: the NT operand of the dgrad GEMMs): 64 x 64 tiles through
+// LDS, 16-byte global accesses on both sides (R, C, lds, ldd multiples of 16)
+__global__ __launch_bounds__(256) void transpose_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int R, int C,
+                                                           long lds_, long ldd) {
+  __shared__ uint8_t tile[64][68];                 // rows of 17 dwords: the column reads below are conflict-free
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int rr = threadIdx.x >> 2, ch = threadIdx.x & 3;            // 64 rows x 4 chunks of 16 bytes
+  if (r0 + rr < R && c0 + ch * 16 < C) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)(r0 + rr) * lds_ + c0 + ch * 16);
+    unsigned* tp = reinterpret_cast<unsigned*>(&tile[rr][ch * 16]);
+    tp[0] = v[0]; tp[1] = v[1]; tp[2] = v[2]; tp[3] = v[3];
+  }
+  __syncthreads();
+  const int cc = threadIdx.x >> 2;                                  // dst row = source column c0 + cc, 16 consecutive source rows
+  if (c0 + cc < C && r0 + ch * 16 < R) {
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned x = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) x |= (unsigned)tile[ch * 16 + k * 4 + b][cc] << (8 * b);
+      w[k] = x;
+    }
+    *reinterpret_cast<u32x4*>(dst + (long)(c0 + cc) * ldd + r0 + ch * 16) = u32x4{w[0], w[1], w[2], w[3]};
   }
 }
 
@@ -230,6 +272,20 @@ extern "C" int vq3_gemm_fp8_nt(const void* Xq, const float* x_scale, const void*
     const char* e = getenv("VQ3_FP8_TILE");
     force = e ? atoi(e) : 0;
   }
+  // the 256 x 256 8-phase kernel once its tile grid fills half the chip (VQ3_FP8_V6=0: the loader-ring kernels below, for A/B runs)
+  static int v6 = -1;
+  if (v6 < 0) { const char* e = getenv("VQ3_FP8_V6"); v6 = e ? atoi(e) : 1; }
+  if (v6 && !force && (long)((M + 255) / 256) * ((N + 255) / 256) >= 128) {
+    GemmParams q = p;
+    q.f8_rs = x_scale; q.f8_cs = w_scale;
+    q.sC1 = q.sC2 = q.sR1 = q.sR2 = 0;
+    const int rc6 = launch_gemm_v6_f8(q, (hipStream_t)stream);
+    if (rc6 > 0) return rc6;
+    if (rc6 == 0) {
+      VQ3_CHECK_LAUNCH("gemm_fp8(v6)");
+      return 0;
+    }
+  }
   const long tiles256 = (long)((M + 255) / 256) * ((N + 127) / 128);
   const bool big = force ? force == 256 : tiles256 >= 200;
   const int rc = big ? launch_fp8<256, 128, 4, 2, 3, 2>(p, x_scale, w_scale, (hipStream_t)stream)
@@ -239,14 +295,79 @@ extern "C" int vq3_gemm_fp8_nt(const void* Xq, const float* x_scale, const void*
   return 0;
 }
 
-extern "C" int vq3_quant_fp8_rows(const void* x_bf16, int64_t ldx, int64_t rows, int32_t K, void* q, int64_t ldq, float* scale,
-                                  void* stream) {
+static int quant_rows_impl(const void* x_bf16, int64_t ldx, int64_t rows, int32_t K, const float* colmul, void* q, int64_t ldq, float* scale,
+                           void* stream) {
   VQ3_CHECK_ARG(x_bf16 && q && scale, "quant_fp8_rows: null pointer");
   VQ3_CHECK_ARG(rows > 0 && K > 0 && K % 8 == 0 && ldx >= K && ldq >= K && ldx % 8 == 0 && ldq % 8 == 0,
                 "quant_fp8_rows: need K %% 8 == 0 and 8-aligned leading dimensions");
   VQ3_CHECK_ARG(rows < (1l << 31), "quant_fp8_rows: too many rows");
+  VQ3_CHECK_ARG(!colmul || (uintptr_t)colmul % 16 == 0, "quant_fp8_rows: colmul must be 16-byte aligned");
   hipLaunchKernelGGL(vq3gemm::quant_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x_bf16, (long)ldx, K, (uint8_t*)q, (long)ldq, scale);
+                     (const bf16_t*)x_bf16, (long)ldx, K, (uint8_t*)q, (long)ldq, scale, colmul);
   VQ3_CHECK_LAUNCH("quant_fp8_rows");
   return 0;
+}
+
+extern "C" int vq3_quant_fp8_rows(const void* x_bf16, int64_t ldx, int64_t rows, int32_t K, void* q, int64_t ldq, float* scale,
+                                  void* stream) {
+  return quant_rows_impl(x_bf16, ldx, rows, K, nullptr, q, ldq, scale, stream);
+}
+
+extern "C" int vq3_quant_fp8_rows_scaled(const void* x_bf16, int64_t ldx, int64_t rows, int32_t K, const float* colmul, void* q, int64_t ldq,
+                                         float* scale, void* stream) {
+  VQ3_CHECK_ARG(colmul != nullptr, "quant_fp8_rows_scaled: null column multipliers");
+  return quant_rows_impl(x_bf16, ldx, rows, K, colmul, q, ldq, scale, stream);
+}
+
+extern "C" int vq3_transpose_u8(const void* src, void* dst, int32_t R, int32_t C, int64_t lds, int64_t ldd, void* stream) {
+  VQ3_CHECK_ARG(src && dst && R > 0 && C > 0, "transpose_u8: bad arguments");
+  VQ3_CHECK_ARG(R % 16 == 0 && C % 16 == 0 && lds >= C && ldd >= R && lds % 16 == 0 && ldd % 16 == 0 && (uintptr_t)src % 16 == 0 &&
+                    (uintptr_t)dst % 16 == 0, "transpose_u8: extents, leading dimensions and pointers must be multiples of 16");
+  hipLaunchKernelGGL(vq3gemm::transpose_u8_kernel, dim3((R + 63) / 64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)src, (uint8_t*)dst, R, C, (long)lds, (long)ldd);
+  VQ3_CHECK_LAUNCH("transpose_u8");
+  return 0;
+}
+
+// e4m3 GEMM with the fused epilogues of the bf16 path (config C5: forward AND dgrad projections of the text model):
+//   mode 0: C = (xs ws) Xq Wq^T (+ residual)                      mode 1: SwiGLU forward  - Wq = gate|up weight [2 I, K], C = act [M, I], gu out
+//   mode 2: SwiGLU backward - the product is d(act) [M, N], never stored: dgu [M, 2 N] from the saved gate|up
+// w_scale may be NULL (= 1): the dgrad GEMMs fold the weight's per-output-channel scales into dY before quantising it.
+extern "C" int vq3_gemm_fp8_ex(const vq3_gemm_fp8_desc* d, void* stream) {
+  using namespace vq3gemm;
+  VQ3_CHECK_ARG(d && d->Xq && d->x_scale && d->Wq, "gemm_fp8_ex: null pointer");
+  VQ3_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->K % 128 == 0, "gemm_fp8_ex: need K %% 128 == 0");
+  VQ3_CHECK_ARG(d->ldx >= d->K && d->ldw >= d->K && d->ldx % 16 == 0 && d->ldw % 16 == 0, "gemm_fp8_ex: bad leading dimensions");
+  VQ3_CHECK_ARG((uintptr_t)d->Xq % 16 == 0 && (uintptr_t)d->Wq % 16 == 0, "gemm_fp8_ex: operands must be 16-byte aligned");
+  VQ3_CHECK_ARG(d->mode >= 0 && d->mode <= 2, "gemm_fp8_ex: mode 0..2");
+  if (d->mode == 0) {
+    VQ3_CHECK_ARG(d->C != nullptr, "gemm_fp8_ex: null output");
+    if (d->w_scale) return vq3_gemm_fp8_nt(d->Xq, d->x_scale, d->Wq, d->w_scale, d->C, d->residual, d->M, d->N, d->K, d->ldx, d->ldw, d->ldc, d->ldr, stream);
+  }
+  GemmParams p{};
+  p.A = (const bf16_t*)d->Xq; p.B = (const bf16_t*)d->Wq; p.C = d->C; p.R = d->residual;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.lda = (int)d->ldx; p.ldb = (int)d->ldw; p.ldc = (int)d->ldc; p.ldr = (int)d->ldr;
+  p.nb2 = 1; p.b2divB = 1; p.kper = d->K; p.nsplit = 1; p.alpha = 1.0f;
+  p.f8_rs = d->x_scale; p.f8_cs = d->w_scale;
+  if (d->mode == 1) {
+    VQ3_CHECK_ARG(d->C && d->N % 256 == 0 && d->ldc >= d->N / 2 && d->ldc % 8 == 0 && !d->residual, "gemm_fp8_ex: SwiGLU forward needs N = 2 I, I %% 128 == 0");
+    VQ3_CHECK_ARG(((uintptr_t)d->gu | (uintptr_t)d->C) % 16 == 0, "gemm_fp8_ex: gate|up / act must be 16-byte aligned");
+    p.epi = 3; p.sw_dgu = (bf16_t*)d->gu;
+  } else if (d->mode == 2) {
+    VQ3_CHECK_ARG(d->gu && d->dgu && d->N % 8 == 0 && !d->residual, "gemm_fp8_ex: SwiGLU backward needs the saved gate|up and an output");
+    VQ3_CHECK_ARG(((uintptr_t)d->gu | (uintptr_t)d->dgu) % 16 == 0, "gemm_fp8_ex: gu / dgu must be 16-byte aligned");
+    p.epi = 2; p.sw_gu = (const bf16_t*)d->gu; p.sw_dgu = (bf16_t*)d->dgu;
+    p.C = d->dgu; p.ldc = d->N;            // placeholders (alignment checks only)
+  }
+  p.vec_ok = (p.ldc % 4 == 0 && (uintptr_t)p.C % 8 == 0 && (!p.R || (p.ldr % 4 == 0 && (uintptr_t)p.R % 8 == 0))) ? 1 : 0;
+  const int rc = launch_gemm_v6_f8(p, (hipStream_t)stream);
+  if (rc > 0) return rc;
+  if (rc == 0) {
+    VQ3_CHECK_LAUNCH("gemm_fp8_ex(v6)");
+    return 0;
+  }
+  VQ3_CHECK_ARG(d->mode == 0, "gemm_fp8_ex: the fused SwiGLU epilogues need the 256 x 256 kernel's contract (16-byte aligned rows)");
+  // plain product without column scales on the loader-ring kernel: a vector of ones stands in
+  vq3_set_error("gemm_fp8_ex: mode 0 without w_scale needs 16-byte aligned bf16 rows");
+  return 1;
 }

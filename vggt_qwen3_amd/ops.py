@@ -767,6 +767,70 @@ def linear_fp8(x: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, *, residual:
     return gemm_fp8(xq, xs, wq, ws, residual=residual)
 
 
+def quant_fp8_rows_scaled(x: torch.Tensor, colmul: torch.Tensor):
+    """(q uint8 [rows, K], scale f32 [rows]) of x * colmul[None, :] (colmul f32 [K]): dY with the weight's per-output-channel scales folded in."""
+    _req(x, BF16, "quant_fp8 x"); _req(colmul, F32, "quant_fp8 colmul")
+    assert x.dim() == 2 and x.stride(1) == 1 and colmul.numel() == x.shape[1]
+    rows, K = x.shape
+    q = torch.empty((rows, K), device=x.device, dtype=torch.uint8)
+    s = torch.empty((rows,), device=x.device, dtype=F32)
+    check(_lib.load().vq3_quant_fp8_rows_scaled(x.data_ptr(), x.stride(0), rows, K, colmul.data_ptr(), q.data_ptr(), K, s.data_ptr(), _stream()),
+          "vq3_quant_fp8_rows_scaled")
+    return q, s
+
+
+def transpose_u8(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[R, C] uint8 -> [C, R] (the e4m3 W^T copies of the dgrad GEMMs)."""
+    _req(src, torch.uint8, "transpose_u8"); assert src.dim() == 2 and src.is_contiguous()
+    R, Cc = src.shape
+    if out is None:
+        out = torch.empty((Cc, R), device=src.device, dtype=torch.uint8)
+    check(_lib.load().vq3_transpose_u8(src.data_ptr(), out.data_ptr(), R, Cc, Cc, R, _stream()), "vq3_transpose_u8")
+    return out
+
+
+def gemm_fp8_ex(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: Optional[torch.Tensor], *, mode: int = 0,
+                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, gu: Optional[torch.Tensor] = None,
+                keep_gu: bool = True):
+    """vq3_gemm_fp8_ex. mode 0: out [M, N] (+ residual); mode 1 (SwiGLU forward): wq = gate|up weight [2 I, K] -> (gu [M, 2 I] or None, act
+    [M, I] = out); mode 2 (SwiGLU backward): gu = saved gate|up [M, 2 N] -> dgu [M, 2 N]. ws None: the column scales were folded into xq."""
+    _req(xq, torch.uint8, "gemm_fp8 xq"); _req(wq, torch.uint8, "gemm_fp8 wq"); _req(xs, F32, "xs")
+    assert xq.dim() == 2 and wq.dim() == 2 and xq.is_contiguous() and wq.is_contiguous() and xq.shape[1] == wq.shape[1]
+    M, K = xq.shape
+    N = wq.shape[0]
+    d = _lib.GemmFp8Desc()
+    d.Xq, d.x_scale, d.Wq, d.w_scale = xq.data_ptr(), xs.data_ptr(), wq.data_ptr(), _p(ws)
+    d.M, d.N, d.K, d.ldx, d.ldw, d.mode = M, N, K, K, K, mode
+    dev = xq.device
+    if mode == 0:
+        out = _out2d(out, M, N, xq, "gemm_fp8_ex")
+        d.C, d.ldc = out.data_ptr(), out.stride(0)
+        if residual is not None:
+            _req(residual, BF16, "gemm_fp8 residual"); assert residual.shape == (M, N) and residual.stride(1) == 1
+            d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+        ret = out
+    elif mode == 1:
+        inter = N // 2
+        if out is None:
+            out = torch.empty((M, inter), device=dev, dtype=BF16)
+        assert out.shape == (M, inter) and out.stride(1) == 1 and out.dtype == BF16
+        g = None
+        if keep_gu:
+            g = gu if gu is not None else torch.empty((M, N), device=dev, dtype=BF16)
+            assert g.shape == (M, N) and g.is_contiguous()
+        d.C, d.ldc, d.gu = out.data_ptr(), out.stride(0), _p(g)
+        ret = (g, out)
+    else:
+        _req(gu, BF16, "gemm_fp8 gu"); assert gu.shape == (M, 2 * N) and gu.is_contiguous()
+        dgu = out if out is not None else torch.empty((M, 2 * N), device=dev, dtype=BF16)
+        assert dgu.shape == (M, 2 * N) and dgu.is_contiguous()
+        d.gu, d.dgu = gu.data_ptr(), dgu.data_ptr()
+        ret = dgu
+    import ctypes as C
+    check(_lib.load().vq3_gemm_fp8_ex(C.byref(d), _stream()), "vq3_gemm_fp8_ex")
+    return ret
+
+
 # ---------------------------------------------------------------------------------------------- fused Qwen3 attention
 def qwen_flash_fwd(Q, K, V, keymask, B, L, Hq, Hkv, D, scale, out: Optional[torch.Tensor] = None):
     """-> (O bf16 [B*L, Hq*D] token-major, LSE f32 [B, Hq, L])."""

@@ -113,6 +113,7 @@ class Qwen3ForCausalLM(nn.Module):
         if self.device_.type == "cuda" and os.environ.get("VQ3_WGRAD_STREAM", "1") != "0":
             self._wgrad_stream = torch.cuda.Stream(device=self.device_)
         self._fp8 = None
+        self._fp8T = None
         self._wt = None
         # deferred weight-gradient GEMMs (enable_wgrad_deferral): operand slabs, rows pending, forward/backward pairing ticket
         self._wd_depth = 1
@@ -305,25 +306,37 @@ class Qwen3ForCausalLM(nn.Module):
         return self._rope_cache[L]
 
     # ------------------------------------------------------------------ fp8 forward (BASELINE config C5)
-    def enable_fp8_forward(self, on: bool = True) -> None:
-        """Forward projections (q|k|v, o, gate|up, down of every layer) through the e4m3 block-scaled-MFMA GEMM: weights
-        quantised per output channel (refresh with requantize_fp8() after every weight update), activations per token on
-        the fly, fp32 accumulation. Embedding / lm_head, norms, attention and the whole backward stay bf16 (the backward
-        reads the bf16 weights and the saved bf16 activations)."""
+    def enable_fp8_forward(self, on: bool = True, dgrad: Optional[bool] = None) -> None:
+        """BASELINE config C5 ("Qwen3-4B fp8 weights"): the projections (q|k|v, o, gate|up, down of every layer) through the e4m3
+        block-scaled-MFMA GEMMs: weights quantised per output channel (refresh with requantize_fp8() after every weight update),
+        activations per token on the fly, fp32 accumulation - in the forward AND (dgrad, default on; VQ3_FP8_DGRAD=0 / dgrad=False =
+        round 3's forward-only form) in the four input-gradient GEMMs dX = dY . W of every layer, which read the SAME e4m3 weights
+        through a byte-transposed copy: W's per-output-channel scales run along that contraction, so they are folded into dY before
+        its rows are quantised (vq3_quant_fp8_rows_scaled). Embedding / lm_head, norms, attention and the weight-gradient GEMMs stay
+        bf16 (they read the saved bf16 activations and bf16 dY)."""
         self._fp8 = {} if on else None
+        if dgrad is None:
+            dgrad = os.environ.get("VQ3_FP8_DGRAD", "1") != "0"
+        self._fp8T = {} if (on and dgrad) else None
         if on:
             self.requantize_fp8()
 
     def requantize_fp8(self) -> None:
         if getattr(self, "_fp8", None) is None:
             return
+        f8t = getattr(self, "_fp8T", None)
         for i in range(self.config.num_hidden_layers):
             for k in ("qkv", "o", "gu", "down"):
                 name = f"l{i}.{k}"
                 w = self._w[name]
                 if w.shape[1] % 128:
                     raise ops._lib.Vq3Error(f"fp8 forward needs in_features % 128 == 0, {name} has {w.shape[1]}")
-                self._fp8[name] = ops.quant_fp8_rows(w)
+                wq, ws = ops.quant_fp8_rows(w)
+                self._fp8[name] = (wq, ws)
+                # W^T in e4m3 for dX = dY . W (contraction = out_features: % 128; rows of 16 bytes: in_features % 16)
+                if f8t is not None and w.shape[0] % 128 == 0 and w.shape[1] % 16 == 0:
+                    prev = f8t.get(name)
+                    f8t[name] = (ops.transpose_u8(wq, out=prev[0] if prev is not None else None), ws)
 
     # ------------------------------------------------------------------ W^T copies for the dgrad GEMMs
     # measured cold at 1200 rows: NT beats the k-major form by 10-18 % on q|k|v, o, gate|up and loses on down_proj; at the 9600 rows
@@ -431,6 +444,10 @@ class Qwen3ForCausalLM(nn.Module):
             if getattr(self, "_fp8", None) is None and ops.swiglu_fwd_fusable(B * L, c.intermediate_size, H):
                 # gate|up projection with silu(gate) * up in its epilogue: act leaves with gu, no second pass over [rows, 2 I]
                 gu, act = ops.gemm_swiglu_fwd(xn2, self._w[f"l{i}.gu"], act_out=wv(i, "down.X"), keep_gu=save)   # (no backward: act only)
+            elif getattr(self, "_fp8", None) is not None and ops.swiglu_fwd_fusable(B * L, c.intermediate_size, H) and H % 128 == 0:
+                wq, ws = self._fp8[f"l{i}.gu"]                      # the same fusion on the e4m3 kernel
+                xq, xs = ops.quant_fp8_rows(xn2)
+                gu, act = ops.gemm_fp8_ex(xq, xs, wq, ws, mode=1, out=wv(i, "down.X"), keep_gu=save)
             else:
                 gu = self._proj(xn2, f"l{i}.gu")
                 act = ops.silu_mul_fwd(gu, out=wv(i, "down.X"))
@@ -619,6 +636,11 @@ class Qwen3ForCausalLM(nn.Module):
         """dX[M,K] = dY[M,N] . W[N,K]: W as stored is the k-major B operand (contraction = its rows)."""
         W = self._w[name]
         M, N = dY.shape
+        f8t = getattr(self, "_fp8T", None)
+        if f8t is not None and name in f8t and dY.is_contiguous():
+            wqt, ws = f8t[name]                                     # e4m3 W^T [K, N]; dY's columns carry W's per-channel scales
+            q, t = ops.quant_fp8_rows_scaled(dY, ws)
+            return ops.gemm_fp8_ex(q, t, wqt, None, mode=0)
         wt = getattr(self, "_wt", None)
         if wt is not None and name in wt and dY.is_contiguous():
             return ops.linear(dY, wt[name])                      # NT: B = W^T [K, N], contraction along its rows' columns
@@ -682,7 +704,13 @@ class Qwen3ForCausalLM(nn.Module):
             # down_proj
             # d(act) = dh . W_down with the SwiGLU backward in the GEMM epilogue: d(gate | up) leaves directly
             wt = getattr(self, "_wt", None)
-            if wt is not None and f"l{i}.down" in wt and dh.is_contiguous():
+            f8t = getattr(self, "_fp8T", None)
+            if f8t is not None and f"l{i}.down" in f8t and dh.is_contiguous() and ctx["gu"].is_contiguous() and \
+                    (wv(i, "gu.dY") is None or wv(i, "gu.dY").is_contiguous()):
+                wqt, ws = f8t[f"l{i}.down"]
+                q, t = ops.quant_fp8_rows_scaled(dh, ws)
+                dgu = ops.gemm_fp8_ex(q, t, wqt, None, mode=2, gu=ctx["gu"], out=wv(i, "gu.dY"))
+            elif wt is not None and f"l{i}.down" in wt and dh.is_contiguous():
                 dgu = ops.gemm_swiglu_bwd(dh, wt[f"l{i}.down"], ctx["gu"], transB=False, out=wv(i, "gu.dY"))
             else:
                 dgu = ops.gemm_swiglu_bwd(dh, self._w[f"l{i}.down"], ctx["gu"], transB=True, out=wv(i, "gu.dY"))
