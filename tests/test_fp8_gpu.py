@@ -92,8 +92,7 @@ def test_fp8_v6_kernel_exact_integers_and_epilogues(ops):
         out = ops.gemm_fp8_ex(_e4m3_bytes(x).cuda(), torch.ones(M, device="cuda"), _e4m3_bytes(w).cuda(), None)
         assert torch.equal(out.float().cpu(), ref.to(BF16).float()), (M, N, K)
         r = torch.randn(M, N).to(BF16)
-        out = ops.gemm_fp8_ex(_e4m3_bytes(x).cuda(), xs, _e4m3_bytes(w).cuda(), ws, residual=r.cuda()) if False else \
-            ops.gemm_fp8(_e4m3_bytes(x).cuda(), xs, _e4m3_bytes(w).cuda(), ws, residual=r.cuda())
+        out = ops.gemm_fp8(_e4m3_bytes(x).cuda(), xs, _e4m3_bytes(w).cuda(), ws, residual=r.cuda())
         want = ((ref * xs.cpu()[:, None] * ws.cpu()[None, :]).to(BF16).float() + r.float()).to(BF16)
         assert ((out.float().cpu() - want.float()).norm() / want.float().norm()).item() < 4e-3, (M, N, K)
     # fused SwiGLU epilogues against plain product + element-wise kernels
@@ -103,7 +102,8 @@ def test_fp8_v6_kernel_exact_integers_and_epilogues(ops):
     xq, xs = ops.quant_fp8_rows(x); wq, ws = ops.quant_fp8_rows(wgu)
     gu_ref = ops.gemm_fp8_ex(xq, xs, wq, ws)
     gu, act = ops.gemm_fp8_ex(xq, xs, wq, ws, mode=1)
-    assert torch.equal(gu, gu_ref) and torch.equal(act, ops.silu_mul_fwd(gu_ref))
+    # (the plain product of this shape - 40 tiles - splits its K range over four workgroups per tile: same sum, another f32 order)
+    assert ((gu.float() - gu_ref.float()).norm() / gu_ref.float().norm()).item() < 2e-3 and torch.equal(act, ops.silu_mul_fwd(gu))
     none, act2 = ops.gemm_fp8_ex(xq, xs, wq, ws, mode=1, keep_gu=False)
     assert none is None and torch.equal(act2, act)
     dy = torch.randn(M, H, device="cuda").to(BF16)
@@ -160,7 +160,7 @@ def test_qwen3_fp8_dgrad_gradients_vs_bf16_path():
 
     l0, g0, d0 = grads(False)
     l1, g1, d1 = grads(True)
-    assert l0 == l1                                              # the forward is the same e4m3 forward
+    assert abs(l0 - l1) < 1e-5 * abs(l0)                         # the forward is the same e4m3 forward
     assert model._fp8T, "the tiny model's projections qualify for the e4m3 dgrad"
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
     assert rel(d1, d0) < 6e-2, rel(d1, d0)

@@ -8,7 +8,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from vggt_qwen3_amd import ops  # noqa: E402
 
 SHAPES = [("qkv", 1200, 6144, 2560), ("o", 1200, 2560, 4096), ("gate_up", 1200, 19456, 2560), ("down", 1200, 2560, 9728),
+          ("qkv x8", 9600, 6144, 2560), ("o x8", 9600, 2560, 4096), ("gate_up x8", 9600, 19456, 2560), ("down x8", 9600, 2560, 9728),
+          ("dgrad qkv x8", 9600, 2560, 6144), ("dgrad gu x8", 9600, 2560, 19456), ("dgrad down x8", 9600, 9728, 2560),
           ("square4096", 4096, 4096, 4096), ("square8192", 8192, 8192, 8192)]
+if len(sys.argv) > 1:
+    SHAPES = [s_ for s_ in SHAPES if any(a in s_[0] for a in sys.argv[1:])]
 
 
 def timeit(fn, n):

@@ -757,8 +757,15 @@ def gemm_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Ten
         out = torch.empty((M, N), device=xq.device, dtype=BF16)
     if residual is not None:
         _req(residual, BF16, "gemm_fp8 residual"); assert residual.shape == (M, N) and residual.is_contiguous()
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.load().vq3_gemm_fp8_nt(xq.data_ptr(), xs.data_ptr(), wq.data_ptr(), ws.data_ptr(), out.data_ptr(),
                                       _p(residual), M, N, K, K, K, out.stride(0), N, _stream()), "vq3_gemm_fp8_nt")
+    if prof is not None:
+        e1.record()
+        prof.append((2.0 * M * N * K, 1.0 * M * K + 1.0 * N * K + 2.0 * M * N * (2 if residual is not None else 1), e0, e1, ("e4m3", M, N, K)))
     return out
 
 
@@ -827,7 +834,14 @@ def gemm_fp8_ex(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: Option
         d.gu, d.dgu = gu.data_ptr(), dgu.data_ptr()
         ret = dgu
     import ctypes as C
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.load().vq3_gemm_fp8_ex(C.byref(d), _stream()), "vq3_gemm_fp8_ex")
+    if prof is not None:
+        e1.record()
+        prof.append((2.0 * M * N * K, 1.0 * M * K + 1.0 * N * K + 2.0 * M * N, e0, e1, ("e4m3 mode %d" % mode, M, N, K)))
     return ret
 
 
