@@ -284,14 +284,19 @@ def test_colsum_multi_tall_slabs(ops):
             assert torch.equal(o, o2)
 
 
-@pytest.mark.parametrize("sched", [102, 103, 105])
+@pytest.mark.parametrize("sched", [102, 103, 105, 106])
 def test_gemm_kmajor_layouts_all_schedules(ops, sched):
     """The any-layout kernel (gemm3.hip) in each of its schedules - 128x128 two-stage, 128x128 loader ring, 256x128 loader ring -
     for every operand layout (NT, k-major B = dgrad, k-major A and B = wgrad), K not a multiple of 64 (tail zero-fill), M / N edges
     inside tiles, accumulate into bf16 (the wgrad form) and a residual."""
     try:
         ops.gemm_force_config(sched)
-        for (M, N, K) in ((1200, 520, 200), (304, 1032, 1208), (2560, 1024, 1200)):
+        # (106 = both operands k-major on the 256 x 256 8-phase kernel, gemm6.hip: the other layouts and f32 output fall back to 105 under it;
+        # its own shapes add a weight-gradient-sized product with a ragged last K tile and one without)
+        shapes = ((1200, 520, 200), (304, 1032, 1208), (2560, 1024, 1200))
+        if sched == 106:
+            shapes += ((6144, 2560, 2408), (2560, 4096, 1920))
+        for (M, N, K) in shapes:
             A = _rand((M, K), 0.5, seed=40); Bm = _rand((N, K), 0.5, seed=41)
             At, Bt = A.t().contiguous(), Bm.t().contiguous()              # k-major copies [K, M], [K, N]
             ref = A.float() @ Bm.float().t()

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
                                                         long s1, long s2, long d0, long d1, long d2, int vec) {
   // row stride 66 elements = 33 dwords (odd): the store phase reads element (ch * 8 + j, cc) with ch = lane & 7, i.e. rows 8 apart - at the
   // old stride of 72 elements (36 dwords, 8 rows = 288 dwords = 0 mod 32) all eight landed on ONE bank (8-way; LDS-conflict share 0.82 in
-  // profiles/r3_pmc_mfma_lds.csv), now on four banks twice (2-way), and the load phase's dword writes are 2-way as well
+  // profiles/r3_pmc_mfma_lds.csv); with the column swizzle of rows >= 32 (below) both phases are conflict-free
   __shared__ bf16_t tile[64][66];
   const int bz = blockIdx.z;
   const int i2 = bz % n2, i1 = (bz / n2) % n1, i0 = bz / (n2 * n1);
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     {
       const u32x4 u = __builtin_bit_cast(u32x4, v);
       unsigned* tp = reinterpret_cast<unsigned*>(&tile[rr][ch * 8]);       // (4-byte aligned: 132 rr + 16 ch)
-      tp[0] = u[0]; tp[1] = u[1]; tp[2] = u[2]; tp[3] = u[3];
+      const int sw = (rr >> 4) & 2;            // rows 32-63 keep the two 4-column halves of a chunk swapped (below)
+      tp[0 ^ sw] = u[0]; tp[1 ^ sw] = u[1]; tp[2 ^ sw] = u[2]; tp[3 ^ sw] = u[3];
     }
   }
   __syncthreads();
@@ -139,7 +140,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     if (c >= C || r >= Rpad) continue;
     bf16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (short)tile[ch * 8 + j][cc];
+    // bank of element (row, col) = (row + col / 2) mod 32 at the 33-dword row stride: the eight ch of a half-wave read rows 8 ch + j, i.e.
+    // banks 8 ch + j + cc / 2 - ch and ch + 4 would meet; columns of rows >= 32 are stored with bit 2 flipped, which moves them two banks on
+    for (int j = 0; j < 8; ++j) v[j] = (short)tile[ch * 8 + j][cc ^ ((ch >> 2) << 2)];
     if (vec && r + 8 <= Rpad) {
       *reinterpret_cast<bf16x8*>(dst + (long)c * ldd + r) = v;
     } else {

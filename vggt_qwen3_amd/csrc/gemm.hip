@@ -287,6 +287,7 @@ int launch_split_rows(GemmParams p, int nbatch, hipStream_t s) {
 
 // launches one candidate; cand < 100: NT config (v2 cfg id or 20 = v6); cand >= 100: v3 with (cand - 100) stages
 int launch_candidate(GemmParams p, int cand, int transA, int transB, int nbatch, hipStream_t s) {
+  if (cand == 106 || cand == 107) return (transA && transB) ? launch_gemm_v6_km(p, nbatch, s, cand == 107) : -1;
   if (cand >= 100) return launch_gemm_v3(p, transA, transB, cand - 100, nbatch, s);
   if (cand == 30) return launch_split_rows(p, nbatch, s);
   if (cand >= 20 && cand <= 22) return launch_gemm_v6(p, cand - 20, nbatch, s);
@@ -553,8 +554,21 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   }
   if (d->transA || d->transB || d->K % BK != 0) {
     int nstage = choose_v3_stages(d->M, d->N, d->K, nbatch);
-    if (!g_forced_v3 && getenv("VQ3_GEMM_V3_STAGES") == nullptr && (long)d->M * d->N * d->K >= (1L << 24))
-      nstage = tuned_choice(p, d->transA, d->transB, nbatch, s, {102, 103, 105}, 100 + nstage, true) - 100;
+    if (!g_forced_v3 && getenv("VQ3_GEMM_V3_STAGES") == nullptr && (long)d->M * d->N * d->K >= (1L << 24)) {
+      std::vector<int> cands = {102, 103, 105};
+      if (d->transA && d->transB && (long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 64) cands.push_back(106);
+      nstage = tuned_choice(p, d->transA, d->transB, nbatch, s, cands, 100 + nstage, true) - 100;
+    }
+    if ((nstage == 6 || nstage == 7) && !(d->transA && d->transB)) nstage = 5;
+    if (nstage == 6 || nstage == 7) {          // both operands k-major on the 256 x 256 8-phase kernel (gemm6.hip)
+      const int rc6 = launch_gemm_v6_km(p, nbatch, s, nstage == 7);
+      if (rc6 > 0) return rc6;
+      if (rc6 == 0) {
+        VQ3_CHECK_LAUNCH("gemm_bf16_nt(v6 k-major)");
+        return 0;
+      }
+      nstage = 5;
+    }
     const int rc = launch_gemm_v3(p, d->transA, d->transB, nstage, nbatch, s);
     if (rc) return rc;
     VQ3_CHECK_LAUNCH("gemm_bf16_nt(v3)");
@@ -742,7 +756,7 @@ extern "C" int vq3_gemm_autotune_hold(int32_t on) {
 }
 
 extern "C" int vq3_gemm_force_config(int32_t cfg) {
-  if (cfg == 102 || cfg == 103 || cfg == 105) {       // schedule of the any-layout kernel (gemm3.hip)
+  if (cfg == 102 || cfg == 103 || cfg == 105 || cfg == 106 || cfg == 107) {       // schedule of the any-layout kernels (gemm3.hip; 106 / 107: gemm6.hip k-major)
     g_forced_v3 = cfg - 100;
     return 0;
   }

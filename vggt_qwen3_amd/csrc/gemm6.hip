@@ -57,7 +57,19 @@ constexpr int HALF = 128 * 128;          // bytes per half-tile (128 rows x 64 k
 // issues two 16x16x32 MFMAs (16 cycles each) per K tile and 16 x 16 output: twice the FLOPs per K tile at the same cadence. The real
 // scales - one per A row (token), one per B row (output channel) - multiply the accumulators in the epilogue (p.f8_rs / p.f8_cs).
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
-template <int AH, int BH, bool OUT_F32, int EK = 0, bool SPLIT = false, bool F8 = false>
+// KM (256 x 256, plain epilogue; round 4): BOTH operands k-major - A[k * lda + m], B[k * ldb + n], the weight-gradient products
+// dW = dY^T . X with dY and X as the backward stores them (token-major). A half-tile is then a 64(k) x 128 image of 256-byte k rows
+// (gemm3.hip's sub-tile: 16 DMA pieces of 4 k rows, 32-byte segments XORed with (k & 3) | ((k >> 3) & 1) << 2 on the source side) and a
+// fragment is two ds_read_b64_tr_b16 instead of one ds_read_b128; buffers, phases, waits and barriers are the NT kernel's. K % 8 == 0:
+// the k rows past K of the last tile are read from a row of zeros (both operands), so nothing is zero-filled in LDS.
+__device__ __attribute__((aligned(256))) bf16_t g_v6_zero_row[256];
+template <int OFF>
+__device__ __forceinline__ u32x2 v6_ds_tr(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int AH, int BH, bool OUT_F32, int EK = 0, bool SPLIT = false, bool F8 = false, bool KM = false>
 __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   constexpr bool HAS_LN = (EK == 1 || EK == 3);
   constexpr int BM = 128 * AH, BN = 128 * BH;
@@ -91,6 +103,28 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   const int kch = (lane & 7) ^ prow;
   unsigned offA[AH][2], offB[BH][2];     // byte offsets from A / B, [half][piece]
   auto set_offsets = [&](int tm0, int tn0) {
+    if constexpr (KM) {
+      // piece po = wid + 8 j holds k rows 4 po .. 4 po + 3; lane: k row 4 po + (lane >> 4), 16-byte chunk (lane & 15) of its 256 bytes,
+      // source chunk = the segment-swizzled one (gemm3.hip: src_ptr)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int krow = (wid + 8 * j) * 4 + (lane >> 4);
+        const int pc = lane & 15;
+        const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+        const int lchunk = (((pc >> 1) ^ f) << 1) | (pc & 1);
+#pragma unroll
+        for (int h = 0; h < AH; ++h) {
+          int col = tm0 + h * 128 + lchunk * 8; col = col <= p.M - 8 ? col : p.M - 8;
+          offA[h][j] = (unsigned)(((long)krow * p.lda + col) * 2);
+        }
+#pragma unroll
+        for (int h = 0; h < BH; ++h) {
+          int col = tn0 + h * 128 + lchunk * 8; col = col <= p.N - 8 ? col : p.N - 8;
+          offB[h][j] = (unsigned)(((long)krow * p.ldb + col) * 2);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = (wid + 8 * j) * 8 + prow;
@@ -111,13 +145,21 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       }
     }
   };
-  auto stage = [&](const bf16_t* base, const unsigned (&off)[2], int tile, char* slot) {
-    const char* g = reinterpret_cast<const char*>(base) + (long)tile * (BK6 * 2);
+  int tail_tile = -1, krem = 0;          // (KM) K tile whose k rows >= krem lie past K: read from the row of zeros
+  auto stage_op = [&](const bf16_t* base, long ld, const unsigned (&off)[2], int tile, char* slot) {
+    const char* g = reinterpret_cast<const char*>(base) + (KM ? (long)tile * (BK6 * 2) * ld : (long)tile * (BK6 * 2));
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off[j]),
+    for (int j = 0; j < 2; ++j) {
+      const char* src = g + off[j];
+      if constexpr (KM) {
+        if (tile == tail_tile && (wid + 8 * j) * 4 + (lane >> 4) >= krem) src = reinterpret_cast<const char*>(g_v6_zero_row) + (lane & 15) * 16;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(slot + (wid + 8 * j) * 1024), 16, 0, 0);
+    }
   };
+  auto stageA = [&](const unsigned (&off)[2], int tile, char* slot) { stage_op(A, p.lda, off, tile, slot); };
+  auto stageB = [&](const unsigned (&off)[2], int tile, char* slot) { stage_op(B, p.ldb, off, tile, slot); };
 
   f32x4 acc[AH * 4][BH * 2];
 
@@ -128,14 +170,69 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   const int b_base = (wc * 32 + fr) * 128 + (((F8 ? 2 * fq : fq) ^ (fr & 7)) << 4);
   constexpr int KHX = F8 ? 4 : 6;        // address bit that separates the two 16-byte pieces of a fragment
 
+  // k-major fragments (gemm3.hip): lane (li = fr, fq) of k step ks takes columns li of two 4-row x 16-column blocks - k rows
+  // 32 ks + 8 fq + (li >> 2) and + 4 - of the 16-column group g: byte = k row * 256 + ((g ^ fl) << 5) + lane part
+  const int km_fl = (fr >> 2) | ((fq & 1) << 2);
+  const int km_base = (8 * fq + (fr >> 2)) * 256 + ((((fr >> 1) & 1) << 4) | ((fr & 1) << 3));
+  unsigned km_a[4], km_b[2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) km_a[mt] = (unsigned)(km_base + ((((wr * 4 + mt)) ^ km_fl) << 5));
+#pragma unroll
+  for (int n2 = 0; n2 < 2; ++n2) km_b[n2] = (unsigned)(km_base + ((((wc * 2 + n2)) ^ km_fl) << 5));
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto tr_join = [](const u32x2& lo, const u32x2& hi) -> bf16x8 {
+    const u32x4 t = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, t);
+  };
+
   bf16x8 xa[4][2], wb0[2][2], wb1[2][2];
+  // (KM) the transposed reads go through asm, invisible to hipcc's waitcnt pass: their destinations stay RAW (lo / hi halves) until the
+  // phase's own s_waitcnt lgkmcnt(0) has passed - km_fix_* pins them behind it (an empty volatile statement per register pair: volatile
+  // statements keep their order) and only then forms the MFMA operands (cdna guide 5.7 item 1; gemm3.hip does the same)
+  u32x2 ra_lo[4][2], ra_hi[4][2], rb_lo[2][2], rb_hi[2][2];
+  auto km_fix_a = [&]() {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        asm volatile("" : "+v"(ra_lo[mt][kh]), "+v"(ra_hi[mt][kh]));
+        xa[mt][kh] = tr_join(ra_lo[mt][kh], ra_hi[mt][kh]);
+      }
+  };
+  auto km_fix_b = [&](bf16x8 (&wb)[2][2]) {
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        asm volatile("" : "+v"(rb_lo[n2][kh]), "+v"(rb_hi[n2][kh]));
+        wb[n2][kh] = tr_join(rb_lo[n2][kh], rb_hi[n2][kh]);
+      }
+  };
   auto read_a = [&](const char* slot) {
+    if constexpr (KM) {
+      const unsigned sa = lds0 + (unsigned)(slot - smem);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        ra_lo[mt][0] = v6_ds_tr<0>(sa + km_a[mt]); ra_hi[mt][0] = v6_ds_tr<4 * 256>(sa + km_a[mt]);
+        ra_lo[mt][1] = v6_ds_tr<32 * 256>(sa + km_a[mt]); ra_hi[mt][1] = v6_ds_tr<36 * 256>(sa + km_a[mt]);
+      }
+      return;
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) xa[mt][kh] = *reinterpret_cast<const bf16x8*>(slot + ((a_base ^ (kh << KHX)) + mt * 2048));
   };
   auto read_b = [&](const char* slot, bf16x8 (&wb)[2][2]) {
+    if constexpr (KM) {
+      const unsigned sa = lds0 + (unsigned)(slot - smem);
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) {
+        rb_lo[n2][0] = v6_ds_tr<0>(sa + km_b[n2]); rb_hi[n2][0] = v6_ds_tr<4 * 256>(sa + km_b[n2]);
+        rb_lo[n2][1] = v6_ds_tr<32 * 256>(sa + km_b[n2]); rb_hi[n2][1] = v6_ds_tr<36 * 256>(sa + km_b[n2]);
+      }
+      return;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -178,19 +275,23 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);  \
   } while (0)
 
-  int nt = F8 ? p.K / 128 : p.K / BK6;          // K tiles of 128 bytes per row
+  int nt = F8 ? p.K / 128 : (p.K + BK6 - 1) / BK6;          // K tiles of 128 bytes per row (k-major: of 64 k rows, the last one ragged)
+  if constexpr (KM) {
+    krem = p.K & (BK6 - 1);
+    tail_tile = krem ? nt - 1 : -1;
+  }
   int sk_slice = -1, sk_j = 0;       // (SPLIT) this workgroup's K slice of tile sk_full + sk_j; -1: a whole tile
   // two-phase variants keep THREE K-tile buffers (3 x 48 KiB): tile t+2 is staged whole while tile t is multiplied, into the
   // buffer tile t-1 left a full tile ago. Slots: A0 A1 B (256 x 128) or A B0 B1 (128 x 256).
   auto stage_tile = [&](int t, char* buf) {
     if constexpr (AH == 2 && BH == 1) {
-      stage(A, offA[0], t, buf + 0 * HALF);
-      stage(B, offB[0], t, buf + 2 * HALF);
-      stage(A, offA[1], t, buf + 1 * HALF);
+      stageA(offA[0], t, buf + 0 * HALF);
+      stageB(offB[0], t, buf + 2 * HALF);
+      stageA(offA[1], t, buf + 1 * HALF);
     } else if constexpr (AH == 1 && BH == 2) {
-      stage(A, offA[0], t, buf + 0 * HALF);
-      stage(B, offB[0], t, buf + 1 * HALF);
-      stage(B, offB[1], t, buf + 2 * HALF);
+      stageA(offA[0], t, buf + 0 * HALF);
+      stageB(offB[0], t, buf + 1 * HALF);
+      stageB(offB[1], t, buf + 2 * HALF);
     }
   };
   bool prefetched = false;         // this tile's first K tiles were requested during the previous tile's epilogue (and have landed)
@@ -207,9 +308,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       tile = p.sk_full + sk_j;
       const int per = (nt + p.sk_s - 1) / p.sk_s;
       const int kt0 = sk_slice * per;
+      if constexpr (KM) tail_tile = krem ? nt - 1 - kt0 : -1;     // (relative to this slice; out of its range for all but the last slice)
       nt = nt - kt0 < per ? nt - kt0 : per;        // (the host keeps every slice non-empty)
-      A += (long)kt0 * BK6;
-      B += (long)kt0 * BK6;
+      A += KM ? (long)kt0 * BK6 * p.lda : (long)kt0 * BK6;
+      B += KM ? (long)kt0 * BK6 * p.ldb : (long)kt0 * BK6;
     }
   }
   // Start-up stagger: every tile of a launch costs the same, so the CUs run in lockstep and reach their epilogues - the C-tile stores, the
@@ -234,14 +336,14 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
   // ---- prologue: all of tile 0, then the half-tiles of tile 1 that the steady state stages ahead of a tile's last phase
   if (!prefetched) set_offsets(m0, n0);
   if constexpr (AH == 2 && BH == 2) {
-    stage(A, offA[0], 0, smem + 0 * HALF);
-    stage(B, offB[0], 0, smem + 2 * HALF);
-    stage(B, offB[1], 0, smem + 3 * HALF);
-    stage(A, offA[1], 0, smem + 1 * HALF);
+    stageA(offA[0], 0, smem + 0 * HALF);
+    stageB(offB[0], 0, smem + 2 * HALF);
+    stageB(offB[1], 0, smem + 3 * HALF);
+    stageA(offA[1], 0, smem + 1 * HALF);
     if (nt > 1) {
-      stage(A, offA[0], 1, smem + BUF + 0 * HALF);
-      stage(B, offB[0], 1, smem + BUF + 2 * HALF);
-      stage(B, offB[1], 1, smem + BUF + 3 * HALF);
+      stageA(offA[0], 1, smem + BUF + 0 * HALF);
+      stageB(offB[0], 1, smem + BUF + 2 * HALF);
+      stageB(offB[1], 1, smem + BUF + 3 * HALF);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -271,25 +373,28 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       // phase 1
       read_b(cur + 2 * HALF, wb0);
       read_a(cur + 0 * HALF);
-      if (s1) stage(A, offA[1], t + 1, nxt + 1 * HALF);
+      if (s1) stageA(offA[1], t + 1, nxt + 1 * HALF);
       V6_SYNC_A();
+      if constexpr (KM) { km_fix_b(wb0); km_fix_a(); __builtin_amdgcn_sched_barrier(0); }
       V6_MMA(0, 0, wb0);
       V6_SYNC_B();
       // phase 2
       read_b(cur + 3 * HALF, wb1);
-      if (s2) stage(A, offA[0], t + 2, cur + 0 * HALF);
+      if (s2) stageA(offA[0], t + 2, cur + 0 * HALF);
       V6_SYNC_A();
+      if constexpr (KM) { km_fix_b(wb1); __builtin_amdgcn_sched_barrier(0); }
       V6_MMA(0, 1, wb1);
       V6_SYNC_B();
       // phase 3
       read_a(cur + 1 * HALF);
-      if (s2) stage(B, offB[0], t + 2, cur + 2 * HALF);
+      if (s2) stageB(offB[0], t + 2, cur + 2 * HALF);
       V6_SYNC_A();
+      if constexpr (KM) { km_fix_a(); __builtin_amdgcn_sched_barrier(0); }
       V6_MMA(1, 1, wb1);
       V6_SYNC_B();
       // phase 4
       if (s2) {
-        stage(B, offB[1], t + 2, cur + 3 * HALF);
+        stageB(offB[1], t + 2, cur + 3 * HALF);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -303,15 +408,15 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       read_b(cur + 2 * HALF, wb0);
       read_a(cur + 0 * HALF);
       if (s2) {
-        stage(A, offA[0], t + 2, nxt + 0 * HALF);
-        stage(B, offB[0], t + 2, nxt + 2 * HALF);
+        stageA(offA[0], t + 2, nxt + 0 * HALF);
+        stageB(offB[0], t + 2, nxt + 2 * HALF);
       }
       V6_SYNC_A();
       V6_MMA(0, 0, wb0);
       V6_SYNC_B();
       read_a(cur + 1 * HALF);
       if (s2) {
-        stage(A, offA[1], t + 2, nxt + 1 * HALF);
+        stageA(offA[1], t + 2, nxt + 1 * HALF);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile t+1 (staged during tile t-1) has landed
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -324,15 +429,15 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
       read_b(cur + 1 * HALF, wb0);
       read_a(cur + 0 * HALF);
       if (s2) {
-        stage(A, offA[0], t + 2, nxt + 0 * HALF);
-        stage(B, offB[0], t + 2, nxt + 1 * HALF);
+        stageA(offA[0], t + 2, nxt + 0 * HALF);
+        stageB(offB[0], t + 2, nxt + 1 * HALF);
       }
       V6_SYNC_A();
       V6_MMA(0, 0, wb0);
       V6_SYNC_B();
       read_b(cur + 2 * HALF, wb1);
       if (s2) {
-        stage(B, offB[1], t + 2, nxt + 2 * HALF);
+        stageB(offB[1], t + 2, nxt + 2 * HALF);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -739,6 +844,41 @@ int launch_gemm_v6_f8(GemmParams& p, hipStream_t stream) {
       hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 0, false, true>), grid, dim3(512), SMEM, stream, p);
     }
   }
+  return 0;
+}
+
+// both operands k-major on the 256 x 256 kernel (the weight-gradient products; cfg 106, with the last round split: 107). -1 = outside
+// its contract (nothing launched): the caller keeps gemm3.hip's kernels.
+int launch_gemm_v6_km(GemmParams& p, int nbatch, hipStream_t stream, bool split) {
+  constexpr int SMEM = 2 * 4 * HALF + 2048;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_v6_kernel<2, 2, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) {
+      vq3_set_error("gemm v6 (k-major): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_done = true;
+  }
+  if (nbatch != 1 || p.out_f32 || p.epi != 0 || p.ln_in || p.nsplit != 1 || !host_staged_ok(p) || p.M % 8 || p.N % 8 || p.K % 8 || p.M < 8 || p.N < 8)
+    return -1;
+  // (byte offsets of a tile's k rows are 32-bit: 63 rows of either operand must stay below 4 GiB)
+  if ((long)64 * p.lda * 2 + (long)p.M * 2 >= (1l << 32) || (long)64 * p.ldb * 2 + (long)p.N * 2 >= (1l << 32)) return -1;
+  p.mtiles = (p.M + 255) / 256;
+  p.ntiles = (p.N + 255) / 256;
+  choose_tile_order(p, 256, 256, 1);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    (void)hipGetLastError();
+    ncu = n / 8 * 8;
+  }
+  p.stagger = 0;
+  // (the last-round K split is not offered here: with the k-major fragment addresses on top of the split's state the 256-register kernel
+  // spills 133 registers INSIDE its main loop)
+  if (split) return -1;
+  hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 0, false, false, true>), dim3(p.mtiles * p.ntiles, 1, 1), dim3(512), SMEM, stream, p);
   return 0;
 }
 

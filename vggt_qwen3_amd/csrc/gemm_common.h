@@ -750,6 +750,8 @@ int launch_gemm_v6(GemmParams& p, int shape, int nbatch, hipStream_t stream);   
 // 3 = 256x256 with the last round's tiles split along K (returns -1, nothing launched, where that does not apply)
 // e4m3 operands on the 256 x 256 8-phase kernel (gemm6.hip; p.f8_rs / p.f8_cs, p.epi 0 / 2 / 3): -1 = outside its contract, nothing launched
 int launch_gemm_v6_f8(GemmParams& p, hipStream_t stream);
+// both operands k-major on the 256 x 256 8-phase kernel (gemm6.hip KM instantiations; cfg 106 / 107 = with the last round split): -1 = outside
+int launch_gemm_v6_km(GemmParams& p, int nbatch, hipStream_t stream, bool split);
 // host side of cfg 25 (gemm6.hip): the split plan, and the error word of the stream's workspace (-1: no split launch ever ran on it)
 int gemm_split_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem);
 int gemm_split_gave_up(hipStream_t stream);
