@@ -12,7 +12,7 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/tune_bench2
 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-variants > gpurun_out/tune_bench8.json 2> gpurun_out/tune_bench8.err
 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-variants --train-projector > gpurun_out/tune_bench8p.json 2> gpurun_out/tune_bench8p.err
 {
-  echo "# vq3 GEMM kernel choices for gfx950 (MI355X): M N K batch flags cfg - measured by tools/make_tune_table.sh at commit $(git rev-parse --short HEAD 2>/dev/null || echo unknown)"
+  echo "# vq3 GEMM kernel choices for gfx950 (MI355X): M N K batch flags cfg - measured by tools/make_tune_table.sh ${1:+at commit $1}"
   echo "# keys: gemm.hip tuned_choice (M < 256 in steps of 32, K < 512 in steps of 64; flags = layout / epilogue kind / alignment bits)"
   sort -u $T | sort -n -k1,1 -k2,2 -k3,3 -k5,5
 } > gpurun_out/gemm_tune_gfx950.txt
