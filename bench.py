@@ -240,6 +240,10 @@ def main():
     # timed micro-batch belongs to a cycle that ends with its all-reduce + optimiser step inside the window
     cycles = [accum] * (args.steps // accum) + ([args.steps % accum] if args.steps % accum else [])
     trainer = Stage1Trainer(model, grad_accum=accum, max_steps=30000)
+    # as Stage1Trainer.fit() runs it: a window's optimiser step is enqueued on a side stream and the next window's first pass starts with
+    # the frozen vision tower beside it (nothing to overlap with in a timed region of ONE window, e.g. the driver's --steps 20: the
+    # barrier + synchronize in front of the clock waits for the warm-up window's step, the one behind it for the timed window's)
+    trainer.overlap_optimizer = os.environ.get("VQ3_OPT_OVERLAP", "1") != "0"
     B, V, L = args.batch, args.views, args.seq_len
     # >= 2 x text_group distinct micro-batches per rank (seeds 1234 + 1000 * rank + i), rotated as a data stream
     npool = max(2, 2 * trainer.text_group)
@@ -552,7 +556,7 @@ def main():
                        "grad_accum": accum, "optimizer_steps_timed": len(cycles), "micro_batches_per_pass": int(trainer.pass_size(accum)),
                        "parallelism": f"dp{world}", "dp_mode": trainer.dp_mode, "geom_tokens": 8 if args.geom else 0,
                        "trim_padding": bool(args.trim_pad), "fp8_text_forward": bool(args.fp8),
-                       "train_projector": bool(args.train_projector), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
+                       "train_projector": bool(args.train_projector), "optimizer_overlap": bool(trainer.overlap_optimizer), "vision_prefetch": bool(args.vision_prefetch), "qwen_layers": args.layers, "valid": args.layers == 36},
             "loss": round(float(loss.item()), 4),
             # utilisation counts EXECUTED FLOPs: the lm_head + CE run on the labelled rows only (same loss and gradients);
             # the reference's figure (logits for all L positions) is kept beside it, never used for a utilisation number

@@ -462,3 +462,37 @@ def test_set_schedule_never_rewinds_the_micro_batch_counter():
     tr.micro_step(dict(batch))
     with pytest.raises(RuntimeError):
         tr.set_schedule(grad_accum=2)                   # mid-window: refused
+
+
+def test_optimizer_step_beside_the_next_pass_equals_the_serial_schedule():
+    """Stage1Trainer.overlap_optimizer (on inside fit() and bench.py): the window's optimiser step runs on a side stream while the next
+    window's pass starts with the frozen vision tower; every reader of an updated tensor waits on model._weights_gate. Same arithmetic in
+    the same order per tensor, so three windows (merged passes, geometry tokens, clipping on) must leave bit-identical weights, optimiser
+    state and losses - and a direct look at the weights after sync_optimizer() sees the finished step."""
+    from vggt_qwen3_amd.trainer import Stage1Trainer
+    z, m, build, batch = _vlm()
+    mbs = [dict(batch) for _ in range(6)]
+    for i, b in enumerate(mbs):                               # different labels per micro-batch
+        lab = b["labels"].clone()
+        lab[i % lab.shape[0]] = -100
+        b["labels"] = lab
+    out = []
+    for overlap in (False, True):
+        model = build()
+        model.vision_model = _Tower(model.vision_model.agg)
+        tr = Stage1Trainer(model, lr=1e-3, proj_lr=1e-3, weight_decay=0.1, warmup_ratio=0.0, max_steps=100, grad_accum=2, text_group=2)
+        tr.overlap_optimizer = overlap
+        losses = []
+        for w in range(3):
+            pair = mbs[2 * w: 2 * w + 2]
+            losses.append(float(tr.micro_step(pair[0], upcoming=pair[1:]).item()))
+            losses.append(float(tr.micro_step(pair[1]).item()))
+            if overlap:
+                assert model._weights_gate is not None        # the step was left running for the next pass to wait on
+        tr.sync_optimizer()
+        assert model._weights_gate is None and tr.opt_step == 3
+        torch.cuda.synchronize()
+        out.append((losses, model.text_model.flat_w.clone(), tr.master.clone(), tr.m.clone(), tr.geom_master.clone()))
+    (l0, w0, ma0, m0, g0), (l1, w1, ma1, m1, g1) = out
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1))       # (the loss sums its rows by f32 atomics)
+    assert torch.equal(w0, w1) and torch.equal(ma0, ma1) and torch.equal(m0, m1) and torch.equal(g0, g1)

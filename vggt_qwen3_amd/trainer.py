@@ -155,6 +155,9 @@ class Stage1Trainer:
         # dp_mode "sharded": fp32 master / moments are current in this rank's shards only until gather_sharded_state() ran after the
         # last optimiser step (checkpoint.save_trainer_state refuses a state that is not gathered)
         self._shards_gathered = True
+        # the optimiser step beside the next pass's vision tower (see _optimizer_step): opt-in, on inside fit() and bench.py
+        self.overlap_optimizer = False
+        self._opt_stream = None
         self._works: List = []
         self.comm_profile: Optional[List] = None    # set to [] to collect (start event, end event, bytes) per gradient all-reduce
         self._fired: List[int] = []     # buckets all-reduced from inside the backward of the current boundary micro-batch
@@ -176,6 +179,7 @@ class Stage1Trainer:
         under several schedules); the deferred weight-gradient depth follows as in __init__."""
         if self._merged_pending or self._opt_due or any(self.tm._wd_rows) or self.micro % self.grad_accum != 0:
             raise RuntimeError("set_schedule: only on an accumulation boundary (flush_pending() first)")
+        self.sync_optimizer()
         if grad_accum is not None and max(1, int(grad_accum)) != self.grad_accum:
             self.grad_accum = max(1, int(grad_accum))
             # the micro-batch counter (max_steps, step_N checkpoint names, the saved `micro`) is never rewound: it moves UP to the next
@@ -188,6 +192,7 @@ class Stage1Trainer:
     def resync_master_from_weights(self) -> None:
         """The bf16 weights were replaced behind the trainer's back (a checkpoint load): re-derive the fp32 master copy, or
         the next AdamW step would write the old weights back. Adam moments are kept."""
+        self.sync_optimizer()
         self.master.copy_(ops.cast(self.tm.flat_w, F32))
         off = 0
         for p in self.geom_params:
@@ -330,6 +335,33 @@ class Stage1Trainer:
         return schedule_multiplier(opt_step, self.sched_ticks, self.warmup, self.max_steps)
 
     def _optimizer_step(self):
+        """The window's optimiser step. With `overlap_optimizer` on (fit() and bench.py turn it on; VQ3_OPT_OVERLAP=0 keeps it off) the
+        whole step - outstanding all-reduces, the norm, AdamW over 112 GB of state, the W^T / e4m3 refresh: HBM-bound, ~23 ms at Qwen3-4B -
+        is enqueued on a stream of its own behind everything the backward enqueued, and the caller's stream goes straight on: the NEXT
+        pass starts with the frozen vision tower (compute-bound, no trainable weight), which runs beside it. The first reader of an updated
+        tensor waits on the event left in model._weights_gate (vlm.forward_state: before the text model, geom_head and - when it trains -
+        the projector); anything else that looks at weights or optimiser state calls sync_optimizer() first."""
+        if not self.overlap_optimizer:
+            return self._optimizer_step_impl()
+        main = torch.cuda.current_stream()
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.tm.flat_w.device)
+        self.sync_optimizer()                                   # (a previous step nobody consumed yet)
+        self._opt_stream.wait_stream(main)
+        with torch.cuda.stream(self._opt_stream):
+            self._optimizer_step_impl()
+            ev = torch.cuda.Event()
+            ev.record(self._opt_stream)
+        self.model._weights_gate = ev
+
+    def sync_optimizer(self) -> None:
+        """Make the current stream wait for an optimiser step that is still running on the side stream (no-op otherwise)."""
+        ev = getattr(self.model, "_weights_gate", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self.model._weights_gate = None
+
+    def _optimizer_step_impl(self):
         tm = self.tm
         if self.dist_on:
             for g0 in sorted(self.buckets, reverse=True):     # buckets the backward did not reach (no hook fired)
@@ -415,6 +447,8 @@ class Stage1Trainer:
         from . import checkpoint
         rank = dist.get_rank(self.pg) if self.dist_on else 0
         records: List[dict] = []
+        overlap0 = self.overlap_optimizer
+        self.overlap_optimizer = os.environ.get("VQ3_OPT_OVERLAP", "1") != "0"      # the optimiser step beside the next pass's tower
         it = iter(batches)
         t0 = time.perf_counter()
         start = self.micro
@@ -447,6 +481,8 @@ class Stage1Trainer:
                     f"Speed: {rec['steps_per_s']:.2f} steps/s, {rec['samples_per_s']:.1f} samples/s")
             if save_every_steps and output_dir is not None and self.micro % save_every_steps == 0:
                 self._save(Path(output_dir) / f"step_{self.micro}", rank, checkpoint)
+        self.sync_optimizer()
+        self.overlap_optimizer = overlap0
         if output_dir is not None:
             self._save(Path(output_dir), rank, checkpoint)
         return records
@@ -454,6 +490,7 @@ class Stage1Trainer:
     def gather_sharded_state(self) -> None:
         """dp_mode "sharded": fp32 master weights and Adam moments are current only inside this rank's shards; all-gather them so
         that rank 0 can write a complete trainer state (a no-op in the replicated mode)."""
+        self.sync_optimizer()
         if self.dp_mode != "sharded":
             return
         torch.cuda.current_stream().synchronize()
@@ -463,6 +500,7 @@ class Stage1Trainer:
         self._shards_gathered = True
 
     def _save(self, path, rank: int, checkpoint) -> None:
+        self.sync_optimizer()
         if self.dist_on:
             dist.barrier(group=self.pg)
             if self.micro % self.grad_accum == 0:

@@ -172,6 +172,7 @@ class VGGTQwen3VLM(nn.Module):
         self._vis_stream = None
         self._vision_head = os.environ.get("VQ3_VISION_HEAD", "1") != "0"
         self._prefetched = None
+        self._weights_gate = None        # event of an optimiser step still running on Stage1Trainer's side stream (trainer.py)
         self._vis_group = []          # [(images tensor, aggregator tokens)]: precompute_vision() results waiting for their micro-batch
         self._text_param_names = [n for n, _ in self.text_model.named_parameters()]
 
@@ -290,6 +291,12 @@ class VGGTQwen3VLM(nn.Module):
                 kind, vis = "encoded", self.encode_images(images)
         self._prefetched = (images, vis, kind)
 
+    def _pass_weights_gate(self) -> None:
+        ev = getattr(self, "_weights_gate", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._weights_gate = None
+
     def _take_prefetched(self, images: torch.Tensor):
         """(kind, tensor) of a prefetch_images() result for this very tensor object - kind "encoded": projector output, "tokens": the
         frozen tower's tokens - or None."""
@@ -353,14 +360,25 @@ class VGGTQwen3VLM(nn.Module):
             # "corrected" mode: the tower stays frozen (no_grad), the projector's forward keeps what its backward needs
             with torch.no_grad():
                 tok = pf[1] if (pf is not None and pf[0] == "tokens") else self._vision_tokens(images, _orig=images0)
+                self._pass_weights_gate()               # the projector trains: its weights may still be in the optimiser's hands
                 vis, pctx = self.projector.forward_train(tok)
         elif pf is not None and pf[0] == "encoded":
             vis = pf[1]
         elif pf is not None:
             with torch.no_grad():
+                if self.train_projector:
+                    self._pass_weights_gate()
                 vis = self.projector(pf[1])
+        elif self.train_projector:
+            with torch.no_grad():
+                tok = self._vision_tokens(images, _orig=images0)
+                self._pass_weights_gate()
+                vis = self.projector(tok)
         else:
             vis = self.encode_images(images, _orig=images0)                               # [B, Nv, H] fp32
+        # everything below reads trainable tensors (geom_head, the embedding, the text model): an optimiser step that Stage1Trainer left
+        # running beside this pass's (frozen) vision tower has to be complete from here on
+        self._pass_weights_gate()
         gfeat = self._geom_inputs(geom_token)
         geom_ctx, gy = None, None
         if gfeat is not None:
