@@ -78,6 +78,7 @@ def _probe(model):
 
 
 def test_c2_c4_forward_properties(full):
+    from vggt_qwen3_amd import ops
     model, b = full
     base = _loss(model, b)["loss"].item()
     assert 11.0 < base < 14.0                                   # random init: about ln(vocab)
@@ -92,7 +93,15 @@ def test_c2_c4_forward_properties(full):
     ids = torch.cat([b["input_ids"], torch.full((6, 16), pad_id, device="cuda", dtype=torch.long)], 1)
     mask = torch.cat([b["attention_mask"], torch.zeros((6, 16), device="cuda", dtype=torch.long)], 1)
     lab = torch.cat([b["labels"], torch.full((6, 16), -100, device="cuda", dtype=torch.long)], 1)
-    assert abs(_loss(model, b, input_ids=ids, attention_mask=mask, labels=lab)["loss"].item() - base) < 2e-4 * base
+    # (the extra columns change M of every text GEMM and with it the tuner's kernel choice; a split last round adds the same f32 terms
+    # in another order, which 36 random-init layers amplify to ~1e-3 of the loss - the exact statement is made with one kernel forced)
+    assert abs(_loss(model, b, input_ids=ids, attention_mask=mask, labels=lab)["loss"].item() - base) < 3e-3 * base
+    ops.gemm_force_config(20)
+    try:
+        f0 = _loss(model, b)["loss"].item()
+        assert abs(_loss(model, b, input_ids=ids, attention_mask=mask, labels=lab)["loss"].item() - f0) < 2e-4 * f0
+    finally:
+        ops.gemm_force_config(-3)
     # without geometry tokens (C2) the path still runs and the loss moves only a little at random init
     c2 = _loss(model, b, geom_token=None)["loss"].item()
     assert 11.0 < c2 < 14.0
