@@ -370,6 +370,41 @@ int vq3_greedy_pick(const void* logits_bf16, int64_t ld_logits, float* work, int
 /* lens[b] += 1 for b < B (B <= 64), *step += 1 (either pointer may be NULL): the last launch of a decode step. */
 int vq3_decode_advance(int32_t* lens, int32_t B, int32_t* step, void* stream);
 
+/* All decoder layers of one decode step for ONE row (B = 1, the reference's callers) in one persistent launch: per layer
+ * q|k|v[+RMSNorm] -> q/k-norm + RoPE + cache append + attention -> o[+residual] -> gate|up[+RMSNorm] + SwiGLU -> down[+residual]
+ * (modeling_qwen3.py:49-83, 185-207, 237-330), the arithmetic of the five entry points above, with the weight stream running through
+ * the phase boundaries (256 workgroups, grid barriers in device memory; csrc/decode_layers.hip).
+ * `weights`: DEVICE array [layers][8] of device pointers, in the order qkv [(Hq+2Hkv)*128, hidden], o [hidden, Hq*128],
+ * gate|up [2*intermediate, hidden] (gate rows first), down [hidden, intermediate], input_layernorm, post_attention_layernorm, q_norm,
+ * k_norm - all bf16, rows contiguous. `h` [hidden] bf16 holds the stack's input row and receives its output. qkv / attn / h_mid / act:
+ * scratch rows of (Hq+2Hkv)*128, Hq*128, hidden, intermediate bf16. Kcache / Vcache: layer 0's [Hkv, Lmax, 128]; layer l's at
+ * + l * cache_layer_stride elements; the new row is appended at position lens[0] (lens is NOT advanced here).
+ * `barrier`: one uint32 that MUST be zero when the kernel starts (zero it on the same stream before every launch).
+ * `status`: one uint32 the kernel ORs into and never clears: 1 = a grid-barrier wait ran out (a workgroup was not co-resident;
+ * the outputs are garbage), 2 = cache full (lens[0] >= Lmax). The caller reads it when it next synchronises.
+ * vq3_qwen_decode_layers_supported: 1 when this shape runs here (Qwen3-4B's 2560 / 9728 / 32 / 8 x 128, Lmax <= 2048, >= 256 CUs),
+ * else 0 - the per-projection launches above cover every other case. */
+typedef struct vq3_decode_layers_desc {
+  const void* const* weights;
+  void* h;
+  void* qkv;
+  void* attn;
+  void* h_mid;
+  void* act;
+  const void* cos;
+  const void* sin;
+  const int32_t* lens;
+  void* Kcache;
+  void* Vcache;
+  int64_t cache_layer_stride;
+  uint32_t* barrier;
+  uint32_t* status;
+  int32_t layers, hidden, intermediate, Hq, Hkv, head_dim, Lmax;
+  float eps, scale;
+} vq3_decode_layers_desc;
+int vq3_qwen_decode_layers_supported(int32_t hidden, int32_t intermediate, int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t Lmax);
+int vq3_qwen_decode_layers(const vq3_decode_layers_desc* desc, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * FP8 forward GEMM (BASELINE config C5: Qwen3 linear weights in OCP e4m3, one fp32 scale per output channel;
  * activations quantised per token on the fly; fp32 accumulate). Replaces nn.Linear of modeling_qwen3.py:81-83,241-280.

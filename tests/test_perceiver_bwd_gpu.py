@@ -210,7 +210,7 @@ def test_prefetch_in_train_projector_mode_caches_the_frozen_tokens_only():
         loss.backward()
         runs.append((loss.item(), m.projector._drop_offset, {n: p.grad.clone() for n, p in m.projector.named_parameters()}))
     (l0, o0, g0), (l1, o1, g1) = runs
-    assert l0 == l1 and o0 == o1                                 # (same dropout counter: the prefetch drew nothing)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0) and o0 == o1          # (the CE row sums meet by f32 atomics; same dropout counter: the prefetch drew nothing)
     assert all(torch.equal(g0[n], g1[n]) for n in g0)
     # reference mode (train_projector off): the whole encode_images result is prefetched, as before
     m = _build_vlm(z, mt).train()

@@ -1,0 +1,482 @@
+// All decoder layers of one greedy-decoding step (one token, B = 1) in ONE persistent launch: vq3_qwen_decode_layers.
+// (the reference's inference callers decode one prompt at a time: src/inference/qa_inference.py:207-216, arkit_inference.py:274-284;
+// the layer being computed is transformers' Qwen3DecoderLayer, modeling_qwen3.py:49-83, 185-207, 237-330.)
+//
+// Why: with one launch per projection (decode.hip) a layer is six 8-29 us kernels whose 21-100 MB of weights stream in 3-17 us - every
+// kernel pays its launch, first-byte latency, reduction and drain, and the HBM pipe is idle in between (2.96 ms / token = 0.34 of the
+// 8 TB/s peak). Here the weight stream never stops:
+//
+//  * 256 workgroups (one per CU, made exclusive by their LDS request) x 12 waves. Waves 0-7 STREAM: a workgroup owns a fixed slab of
+//    rows of every projection (24 of q|k|v, 10 of o, 38 + 38 of gate | up, 10 of down - contiguous bytes, 16 per lane and step), and a
+//    thread's 97 16-byte pieces per layer form one sequence with RING = 20 of them in flight at any time (a ring of registers, static
+//    indices) - ACROSS the phases of a layer and across layers, because weight addresses depend on nothing the token computes. The
+//    phases' synchronisation therefore gates the FMAs, not the loads.
+//  * Waves 8-11 HELP: they wait at the grid barrier, prepare the phase's activation vector in LDS (RMSNorm in registers / the
+//    attention output / the SwiGLU product), and after the streamers' partial sums are in LDS add them per row in a fixed order, apply
+//    the epilogue (residual / SwiGLU) and publish the row values. They hold no weight loads, so the few KB they read do not queue
+//    behind 40 MB of weights. Attention for the new token (q/k RMSNorm + RoPE, cache append, softmax over the cached positions) is
+//    helper work of workgroups 0 .. Hq-1, one head each, in decode.hip's arithmetic order.
+//  * Five grid barriers per layer (q|k|v -> attention -> o -> gate|up -> down): one monotonically increasing counter, arrival =
+//    agent-scope release add by one thread per workgroup, wait = agent-scope polling by one thread + acquire fence in every reader.
+//    Every wait is BOUNDED: after 2^21 polls the waiter raises the status word, every later wait returns at once, the grid drains and
+//    the host reports the failure (the kernel cannot hang the device when a workgroup was not co-resident).
+//
+// Arithmetic is that of decode.hip (bf16 rounding points: normed row, projection outputs before the residual, SwiGLU product,
+// probabilities; fp32 sums), only the ORDER of a dot product's fp32 terms differs (16-lane groups per 1 KiB of a row instead of a wave
+// per row), as it does between any two GEMV kernels.
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "vq3_hip.h"
+
+namespace {
+
+// f(integral_constant<int, B>{}), ..., f(integral_constant<int, E - 1>{})
+template <int B, int E, class F>
+__device__ __forceinline__ void dl_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    dl_static_for<B + 1, E>(f);
+  }
+}
+
+constexpr int DL_G = 256;        // workgroups (= CUs of an MI355X)
+constexpr int DL_TS = 512;       // streaming threads per workgroup
+constexpr int DL_TH = 256;       // helper threads
+constexpr int DL_RING = 20;      // 16-byte weight loads in flight per streaming thread
+constexpr int DL_D = 128;        // head_dim
+constexpr int DL_LMAX = 2048;    // cache positions the score buffer holds
+constexpr unsigned DL_POLLS = 1u << 21;
+
+struct LayerW { const bf16_t *qkv, *o, *gu, *down, *ln1, *ln2, *qn, *kn; };
+
+struct Args {
+  const LayerW* w;               // [nl] (device)
+  bf16_t* h;                     // [H]: the layer stack's input row, overwritten by its output
+  bf16_t *qkv, *ao, *hmid, *act; // scratch rows: (Hq + 2 Hkv) 128, Hq 128, H, I
+  const bf16_t *cs, *sn;         // RoPE tables [>= Lmax, 128]
+  const int32_t* lens;           // [1]: cached positions = position of the new token
+  bf16_t *Kc, *Vc;               // layer 0's cache [Hkv, Lmax, 128]
+  long cache_stride;             // elements between two layers' caches
+  unsigned* bar;                 // [0] arrival counter (zero at launch)
+  unsigned* status;              // sticky: 1 = a barrier wait ran out, 2 = cache full
+  int nl, Lmax;
+  float eps, scale;
+};
+
+__device__ __forceinline__ void dl_unpack8(const u32x4 v, float* f) {
+  f[0] = __builtin_bit_cast(float, v.x << 16); f[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+  f[2] = __builtin_bit_cast(float, v.y << 16); f[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+  f[4] = __builtin_bit_cast(float, v.z << 16); f[5] = __builtin_bit_cast(float, v.z & 0xffff0000u);
+  f[6] = __builtin_bit_cast(float, v.w << 16); f[7] = __builtin_bit_cast(float, v.w & 0xffff0000u);
+}
+
+// sum over the 16 lanes of a DPP row, valid in the row's lane 15 (VALU only: no LDS round trip per step)
+__device__ __forceinline__ float dl_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
+  return v;
+}
+
+__device__ __forceinline__ void dl_grid_wait(unsigned* bar, unsigned* status, unsigned target) {
+  unsigned n = 0;
+  while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    ++n;
+    if ((n & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    if (n > DL_POLLS) {
+      __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+__device__ __forceinline__ void dl_grid_arrive(unsigned* bar) {
+  __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// H hidden, I intermediate, HQ / HKV heads (head_dim 128). Every projection's rows divide over the 256 workgroups and every K is a
+// multiple of 512 (a wave's 64 x 16 bytes stay inside one weight row).
+template <int H, int I, int HQ, int HKV>
+struct Geo {
+  static constexpr int NQKV = (HQ + 2 * HKV) * DL_D, KO = HQ * DL_D;
+  static_assert(NQKV % DL_G == 0 && H % DL_G == 0 && I % DL_G == 0, "rows divide over the workgroups");
+  static_assert(H % 512 == 0 && KO % 512 == 0 && I % 512 == 0, "a wave's 1 KiB stays inside one weight row");
+  static constexpr int R0 = NQKV / DL_G, R2 = H / DL_G, RG = I / DL_G, R4 = H / DL_G;
+  static constexpr int C0 = R0 * (H / 8), C2 = R2 * (KO / 8), C3H = RG * (H / 8), C3 = 2 * C3H, C4 = R4 * (I / 8);   // 16-byte pieces per workgroup
+  static_assert(C3H % 64 == 0, "the gate | up slab boundary is wave-aligned");
+  static constexpr int S0 = (C0 + DL_TS - 1) / DL_TS, S2 = (C2 + DL_TS - 1) / DL_TS, S3 = (C3 + DL_TS - 1) / DL_TS, S4 = (C4 + DL_TS - 1) / DL_TS;
+  static constexpr int B0 = 0, B2 = S0, B3 = S0 + S2, B4 = S0 + S2 + S3, NS = S0 + S2 + S3 + S4;
+  static constexpr int NSLOT = (NS + DL_RING - 1) / DL_RING * DL_RING;      // padded so that a slot's ring register is the same in every layer
+  static constexpr int KMAX = (I > KO ? (I > H ? I : H) : (KO > H ? KO : H));
+  static constexpr int UMAX = C3 / 64 > C4 / 64 ? C3 / 64 : C4 / 64;       // wave-sized pieces per phase and workgroup
+  static constexpr int PER_LAYER = 4 * DL_G + HQ;                            // barrier arrivals per layer
+  // LDS (bytes)
+  static constexpr int XLO = 0, XHI = KMAX / 8 * 16, PART = 2 * XHI, SC = PART + UMAX * 16 + 64, QS = SC + DL_LMAX * 4,
+                       RED = QS + 3 * DL_D * 4, OPART = RED + 64, LDS_USED = OPART + 4 * DL_D * 4;
+};
+
+template <int H, int I, int HQ, int HKV>
+__global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args a) {
+  using Gm = Geo<H, I, HQ, HKV>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  f32x4* const xlo = reinterpret_cast<f32x4*>(lds + Gm::XLO);     // x[8 c .. 8 c + 3]
+  f32x4* const xhi = reinterpret_cast<f32x4*>(lds + Gm::XHI);     // x[8 c + 4 .. 8 c + 7]
+  float* const part = reinterpret_cast<float*>(lds + Gm::PART);   // [wave piece u][16-lane group]
+  float* const sc = reinterpret_cast<float*>(lds + Gm::SC);
+  float* const qs = reinterpret_cast<float*>(lds + Gm::QS);       // q', k', v of the new token (fp32 values on the bf16 grid)
+  float* const red = reinterpret_cast<float*>(lds + Gm::RED);
+  float* const opart = reinterpret_cast<float*>(lds + Gm::OPART);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const bool streamer = wave < DL_TS / 64;
+  const int ht = tid - DL_TS, hw = wave - DL_TS / 64;             // helper thread / wave index (negative for streamers)
+  const bool lead = tid == DL_TS;
+
+  u32x4 ring[DL_RING];
+
+  // ---- weight address of slot S (compile time) for this thread
+  auto slot_ptr = [&](const LayerW& w, auto tag) -> const u32x4* {
+    constexpr int S = decltype(tag)::value;
+    if constexpr (S < Gm::B2) {
+      constexpr int j = S - Gm::B0;
+      return reinterpret_cast<const u32x4*>(w.qkv + (size_t)wg * Gm::R0 * H) + (tid + DL_TS * j);
+    } else if constexpr (S < Gm::B3) {
+      constexpr int j = S - Gm::B2;
+      return reinterpret_cast<const u32x4*>(w.o + (size_t)wg * Gm::R2 * Gm::KO) + (tid + DL_TS * j);
+    } else if constexpr (S < Gm::B4) {
+      constexpr int j = S - Gm::B3;
+      int c = tid + DL_TS * j;
+      if (j == Gm::S3 - 1 && c >= Gm::C3) c -= DL_TS;             // ragged last step: a duplicate of the previous piece (never summed)
+      const bf16_t* gate = w.gu + (size_t)wg * Gm::RG * H;
+      const bf16_t* up = w.gu + ((size_t)I + (size_t)wg * Gm::RG) * H;
+      return c < Gm::C3H ? reinterpret_cast<const u32x4*>(gate) + c : reinterpret_cast<const u32x4*>(up) + (c - Gm::C3H);
+    } else {
+      constexpr int j = S - Gm::B4;
+      int c = tid + DL_TS * j;
+      if (j == Gm::S4 - 1 && c >= Gm::C4) c -= DL_TS;
+      return reinterpret_cast<const u32x4*>(w.down + (size_t)wg * Gm::R4 * I) + c;
+    }
+  };
+  auto issue = [&](const LayerW& w, auto tag) {
+    constexpr int S = decltype(tag)::value;
+    if constexpr (S < Gm::NS) ring[S % DL_RING] = __builtin_nontemporal_load(slot_ptr(w, tag));
+  };
+  // ---- one piece: 8 weights x 8 activations, 16-lane sums into part[u][lane / 16]
+  auto consume = [&](auto tag) {
+    constexpr int S = decltype(tag)::value;
+    if constexpr (S < Gm::NS) {
+      constexpr int PH = S < Gm::B2 ? 0 : (S < Gm::B3 ? 2 : (S < Gm::B4 ? 3 : 4));
+      constexpr int j = S - (PH == 0 ? Gm::B0 : PH == 2 ? Gm::B2 : PH == 3 ? Gm::B3 : Gm::B4);
+      constexpr int K = PH == 2 ? Gm::KO : (PH == 4 ? I : H);
+      constexpr int WPR = K / 512;                                 // wave pieces per weight row
+      constexpr int UTOT = (PH == 0 ? Gm::C0 : PH == 2 ? Gm::C2 : PH == 3 ? Gm::C3 : Gm::C4) / 64;
+      const int u = wave + 8 * j;
+      const int kc = (u % WPR) * 64 + lane;
+      float wf[8];
+      dl_unpack8(ring[S % DL_RING], wf);
+      const f32x4 x0 = xlo[kc], x1 = xhi[kc];
+      float acc = wf[0] * x0[0];
+      acc = fmaf(wf[1], x0[1], acc); acc = fmaf(wf[2], x0[2], acc); acc = fmaf(wf[3], x0[3], acc);
+      acc = fmaf(wf[4], x1[0], acc); acc = fmaf(wf[5], x1[1], acc); acc = fmaf(wf[6], x1[2], acc); acc = fmaf(wf[7], x1[3], acc);
+      acc = dl_row16_sum(acc);
+      if ((lane & 15) == 15 && u < UTOT) part[u * 4 + (lane >> 4)] = acc;
+    }
+  };
+  // sum of a row's pieces in a fixed order
+  auto row_sum = [&](int r, int wpr) {
+    float s = 0.f;
+    for (int u = r * wpr; u < (r + 1) * wpr; ++u) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(part + u * 4);
+      s += (p[0] + p[1]) + (p[2] + p[3]);
+    }
+    return s;
+  };
+  // Qwen3RMSNorm of a K-element row into the x planes (helper wave 0: K / 512 pieces per lane, statistics by one wave_sum)
+  auto xprep_rms = [&](const bf16_t* row, const bf16_t* lnw) {
+    constexpr int NP = H / 512;
+    float f[NP][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      dl_unpack8(*reinterpret_cast<const u32x4*>(row + (lane + 64 * i) * 8), f[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = fmaf(f[i][e], f[i][e], ss);
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)H + a.eps);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      float lw[8];
+      dl_unpack8(*reinterpret_cast<const u32x4*>(lnw + (lane + 64 * i) * 8), lw);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[i][e] = rbf(lw[e] * rbf(f[i][e] * rstd));
+      xlo[lane + 64 * i] = f32x4{f[i][0], f[i][1], f[i][2], f[i][3]};
+      xhi[lane + 64 * i] = f32x4{f[i][4], f[i][5], f[i][6], f[i][7]};
+    }
+  };
+  // a bf16 row as it is (all helper threads)
+  auto xprep_copy = [&](const bf16_t* row, int K) {
+    for (int c = ht; c < K / 8; c += DL_TH) {
+      float f[8];
+      dl_unpack8(*reinterpret_cast<const u32x4*>(row + c * 8), f);
+      xlo[c] = f32x4{f[0], f[1], f[2], f[3]};
+      xhi[c] = f32x4{f[4], f[5], f[6], f[7]};
+    }
+  };
+
+  // the first RING pieces of layer 0 are requested before anything else
+  if (streamer) {
+    const LayerW w0 = a.w[0];
+    dl_static_for<0, DL_RING>([&](auto tag) { issue(w0, tag); });
+  }
+  const int pos = a.lens[0];
+  if (pos >= a.Lmax && lead) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool cache_ok = pos < a.Lmax;
+  const bool attn = !streamer && wg < HQ && cache_ok;
+  const int T = pos + 1;
+
+  for (int l = 0; l < a.nl; ++l) {
+    const LayerW w = a.w[l];
+    const LayerW wn = a.w[l + 1 < a.nl ? l + 1 : l];               // past the last layer: harmless re-reads of its first pieces
+    const unsigned base = (unsigned)l * Gm::PER_LAYER;
+    // one streaming phase: pieces [SB, SE) are multiplied, the pieces RING ahead are requested into the registers just freed
+    auto stream_phase = [&](auto sb, auto se) {
+      constexpr int SB = decltype(sb)::value, SE = decltype(se)::value;
+      dl_static_for<SB, SE>([&](auto tag) {
+        constexpr int S = decltype(tag)::value, SN = S + DL_RING;
+        consume(tag);
+        if constexpr (SN < Gm::NSLOT) issue(w, std::integral_constant<int, SN>{});
+        else issue(wn, std::integral_constant<int, SN - Gm::NSLOT>{});
+      });
+    };
+
+    // ================= phase 0: q|k|v = W_qkv . RMSNorm(h)
+    if (lead && l > 0) dl_grid_wait(a.bar, a.status, base);                       // every row of h (previous layer's phase 4)
+    __syncthreads();
+    if (!streamer) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (hw == 0) xprep_rms(a.h, w.ln1);
+    __syncthreads();
+    if (streamer) stream_phase(std::integral_constant<int, Gm::B0>{}, std::integral_constant<int, Gm::B2>{});
+    __syncthreads();
+    if (!streamer && ht < Gm::R0) a.qkv[wg * Gm::R0 + ht] = f2bf(row_sum(ht, H / 512));
+    __syncthreads();
+    if (lead) { dl_grid_arrive(a.bar); dl_grid_wait(a.bar, a.status, base + DL_G); }
+
+    // ================= phase 1: attention of head wg (helpers of workgroups 0 .. HQ - 1), decode.hip's order of operations
+    __syncthreads();
+    if (!streamer) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    bf16_t* const Kl = a.Kc + (long)l * a.cache_stride + (long)(wg / (HQ / HKV)) * a.Lmax * DL_D;
+    bf16_t* const Vl = a.Vc + (long)l * a.cache_stride + (long)(wg / (HQ / HKV)) * a.Lmax * DL_D;
+    if (attn && hw < 3) {
+      // wave 0: q' of head wg; wave 1: k' of its kv head; wave 2: v. Lane i holds elements i and i + 64 (the rotate_half pair).
+      const int hk = wg / (HQ / HKV);
+      const bf16_t* src = a.qkv + (hw == 0 ? wg * DL_D : (hw == 1 ? (HQ + hk) * DL_D : (HQ + HKV + hk) * DL_D));
+      const float x1 = bf2f(src[lane]), x2 = bf2f(src[lane + 64]);
+      float o1 = x1, o2 = x2;
+      if (hw < 2) {
+        const bf16_t* nw = hw == 0 ? w.qn : w.kn;
+        const float c1 = bf2f(a.cs[(long)pos * DL_D + lane]), c2 = bf2f(a.cs[(long)pos * DL_D + lane + 64]);
+        const float s1 = bf2f(a.sn[(long)pos * DL_D + lane]), s2 = bf2f(a.sn[(long)pos * DL_D + lane + 64]);
+        const float rs = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)DL_D + a.eps);
+        const float n1 = rbf(bf2f(nw[lane]) * rbf(x1 * rs));
+        const float n2 = rbf(bf2f(nw[lane + 64]) * rbf(x2 * rs));
+        o1 = rbf(rbf(n1 * c1) + rbf(-n2 * s1));
+        o2 = rbf(rbf(n2 * c2) + rbf(n1 * s2));
+      }
+      qs[hw * DL_D + lane] = o1;
+      qs[hw * DL_D + lane + 64] = o2;
+      if (hw > 0 && wg % (HQ / HKV) == 0) {                        // one workgroup per kv head appends the row to the cache
+        bf16_t* dst = (hw == 1 ? Kl : Vl) + (long)pos * DL_D;
+        dst[lane] = f2bf(o1);
+        dst[lane + 64] = f2bf(o2);
+      }
+    }
+    __syncthreads();
+    const int sub = lane >> 4, dl = (lane & 15) * 8;
+    float mx = -INFINITY;
+    if (attn) {
+      float qf[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[e] = qs[dl + e];
+      const int last = pos > 0 ? pos - 1 : 0;                       // cached rows only; the new row comes from LDS (its store is another workgroup's)
+      for (int l0 = hw * 4; l0 < T; l0 += 64) {
+        u32x4 kr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kr[i] = *reinterpret_cast<const u32x4*>(Kl + (long)min(l0 + 16 * i + sub, last) * DL_D + dl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int lk = l0 + 16 * i + sub;
+          float kf[8];
+          dl_unpack8(kr[i], kf);
+          if (lk == pos) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kf[e] = qs[DL_D + dl + e];
+          }
+          float s = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s = fmaf(qf[e], kf[e], s);
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+          s *= a.scale;
+          if (lk < T) {
+            if ((lane & 15) == 0) sc[lk] = s;
+            mx = fmaxf(mx, s);
+          }
+        }
+      }
+      mx = wave_max(mx);
+      if (lane == 0) red[hw] = mx;
+    }
+    __syncthreads();
+    float sum = 0.f;
+    if (attn) {
+      mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      for (int lk = ht; lk < T; lk += DL_TH) {
+        const float e = __expf(sc[lk] - mx);
+        sc[lk] = e;
+        sum += e;
+      }
+      sum = wave_sum(sum);
+      if (lane == 0) red[4 + hw] = sum;
+    }
+    __syncthreads();
+    if (attn) {
+      const float inv = 1.f / (((0.f + red[4]) + red[5]) + red[6] + red[7]);
+      const int last = pos > 0 ? pos - 1 : 0;
+      float of[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) of[e] = 0.f;
+      for (int l0 = hw * 4; l0 < T; l0 += 64) {
+        u32x4 vr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vr[i] = *reinterpret_cast<const u32x4*>(Vl + (long)min(l0 + 16 * i + sub, last) * DL_D + dl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int lk = l0 + 16 * i + sub;
+          const float p = lk < T ? rbf(sc[lk] * inv) : 0.f;
+          float vf[8];
+          dl_unpack8(vr[i], vf);
+          if (lk == pos) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vf[e] = qs[2 * DL_D + dl + e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) of[e] = fmaf(p, vf[e], of[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        of[e] += __shfl_xor(of[e], 16, 64);
+        of[e] += __shfl_xor(of[e], 32, 64);
+      }
+      if (sub == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) opart[hw * DL_D + dl + e] = of[e];
+      }
+    }
+    __syncthreads();
+    if (attn && ht < DL_D) a.ao[wg * DL_D + ht] = f2bf(opart[ht] + opart[DL_D + ht] + opart[2 * DL_D + ht] + opart[3 * DL_D + ht]);
+    __syncthreads();
+    if (lead) {
+      if (wg < HQ) dl_grid_arrive(a.bar);
+      dl_grid_wait(a.bar, a.status, base + DL_G + HQ);
+    }
+
+    // ================= phase 2: h_mid = h + W_o . attn
+    __syncthreads();
+    if (!streamer) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); xprep_copy(a.ao, Gm::KO); }
+    __syncthreads();
+    if (streamer) stream_phase(std::integral_constant<int, Gm::B2>{}, std::integral_constant<int, Gm::B3>{});
+    __syncthreads();
+    if (!streamer && ht < Gm::R2) {
+      const int n = wg * Gm::R2 + ht;
+      a.hmid[n] = f2bf(rbf(row_sum(ht, Gm::KO / 512)) + bf2f(a.h[n]));
+    }
+    __syncthreads();
+    if (lead) { dl_grid_arrive(a.bar); dl_grid_wait(a.bar, a.status, base + 2 * DL_G + HQ); }
+
+    // ================= phase 3: act = SwiGLU(W_gate|up . RMSNorm(h_mid)) - a workgroup owns gate AND up of its 38 features
+    __syncthreads();
+    if (!streamer) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (hw == 0) xprep_rms(a.hmid, w.ln2);
+    __syncthreads();
+    if (streamer) stream_phase(std::integral_constant<int, Gm::B3>{}, std::integral_constant<int, Gm::B4>{});
+    __syncthreads();
+    if (!streamer && ht < Gm::RG) {
+      const float g = rbf(row_sum(ht, H / 512)), up = rbf(row_sum(Gm::RG + ht, H / 512));
+      a.act[wg * Gm::RG + ht] = f2bf(rbf(silu_f(g)) * up);
+    }
+    __syncthreads();
+    if (lead) { dl_grid_arrive(a.bar); dl_grid_wait(a.bar, a.status, base + 3 * DL_G + HQ); }
+
+    // ================= phase 4: h = h_mid + W_down . act
+    __syncthreads();
+    if (!streamer) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); xprep_copy(a.act, I); }
+    __syncthreads();
+    if (streamer) stream_phase(std::integral_constant<int, Gm::B4>{}, std::integral_constant<int, Gm::NSLOT>{});
+    __syncthreads();
+    if (!streamer && ht < Gm::R4) {
+      const int n = wg * Gm::R4 + ht;
+      a.h[n] = f2bf(rbf(row_sum(ht, I / 512)) + bf2f(a.hmid[n]));
+    }
+    __syncthreads();
+    if (lead) dl_grid_arrive(a.bar);
+  }
+}
+
+using Qwen3_4B = Geo<2560, 9728, 32, 8>;
+constexpr int DL_LDS_BYTES = 96 * 1024;      // more than half a CU's 160 KiB: one workgroup per CU, whatever the register count
+static_assert(Qwen3_4B::LDS_USED <= DL_LDS_BYTES, "LDS layout fits the request");
+
+bool dl_device_ok() {
+  static int ok = -1;
+  if (ok < 0) {
+    int dev = 0, cus = 0;
+    ok = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= DL_G) {
+      auto k = decode_layers_kernel<2560, 9728, 32, 8>;
+      int nb = 0;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DL_LDS_BYTES) == hipSuccess &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, DL_TS + DL_TH, DL_LDS_BYTES) == hipSuccess && nb >= 1)
+        ok = 1;
+    }
+    (void)hipGetLastError();
+  }
+  return ok == 1;
+}
+
+}  // namespace
+
+extern "C" int vq3_qwen_decode_layers_supported(int32_t hidden, int32_t intermediate, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                                                int32_t Lmax) {
+  if (hidden != 2560 || intermediate != 9728 || Hq != 32 || Hkv != 8 || head_dim != DL_D) return 0;
+  if (Lmax < 1 || Lmax > DL_LMAX) return 0;
+  return dl_device_ok() ? 1 : 0;
+}
+
+extern "C" int vq3_qwen_decode_layers(const vq3_decode_layers_desc* d, void* stream) {
+  VQ3_CHECK_ARG(d, "decode_layers: null descriptor");
+  VQ3_CHECK_ARG(d->weights && d->h && d->qkv && d->attn && d->h_mid && d->act && d->cos && d->sin && d->lens && d->Kcache && d->Vcache &&
+                    d->barrier && d->status,
+                "decode_layers: null pointer");
+  VQ3_CHECK_ARG(d->layers >= 1, "decode_layers: layers must be >= 1, got %d", d->layers);
+  VQ3_CHECK_ARG(vq3_qwen_decode_layers_supported(d->hidden, d->intermediate, d->Hq, d->Hkv, d->head_dim, d->Lmax),
+                "decode_layers: unsupported shape / device (hidden %d, intermediate %d, heads %d / %d x %d, Lmax %d; needs Qwen3-4B's "
+                "2560 / 9728 / 32 / 8 x 128, Lmax <= %d and %d CUs) - use the per-projection launches",
+                d->hidden, d->intermediate, d->Hq, d->Hkv, d->head_dim, d->Lmax, DL_LMAX, DL_G);
+  VQ3_CHECK_ARG(d->cache_layer_stride >= (int64_t)d->Hkv * d->Lmax * DL_D, "decode_layers: cache_layer_stride smaller than one layer's cache");
+  Args a;
+  a.w = reinterpret_cast<const LayerW*>(d->weights);
+  a.h = (bf16_t*)d->h; a.qkv = (bf16_t*)d->qkv; a.ao = (bf16_t*)d->attn; a.hmid = (bf16_t*)d->h_mid; a.act = (bf16_t*)d->act;
+  a.cs = (const bf16_t*)d->cos; a.sn = (const bf16_t*)d->sin; a.lens = d->lens;
+  a.Kc = (bf16_t*)d->Kcache; a.Vc = (bf16_t*)d->Vcache; a.cache_stride = d->cache_layer_stride;
+  a.bar = (unsigned*)d->barrier; a.status = (unsigned*)d->status;
+  a.nl = d->layers; a.Lmax = d->Lmax; a.eps = d->eps; a.scale = d->scale;
+  hipLaunchKernelGGL((decode_layers_kernel<2560, 9728, 32, 8>), dim3(DL_G), dim3(DL_TS + DL_TH), DL_LDS_BYTES, (hipStream_t)stream, a);
+  VQ3_CHECK_LAUNCH("decode_layers");
+  return 0;
+}
