@@ -376,10 +376,11 @@ int vq3_decode_advance(int32_t* lens, int32_t B, int32_t* step, void* stream);
  * the phase boundaries (256 workgroups, grid barriers in device memory; csrc/decode_layers.hip).
  * `weights`: DEVICE array [layers][8] of device pointers, in the order qkv [(Hq+2Hkv)*128, hidden], o [hidden, Hq*128],
  * gate|up [2*intermediate, hidden] (gate rows first), down [hidden, intermediate], input_layernorm, post_attention_layernorm, q_norm,
- * k_norm - all bf16, rows contiguous. `h` [hidden] bf16 holds the stack's input row and receives its output. qkv / attn / h_mid / act:
- * scratch rows of (Hq+2Hkv)*128, Hq*128, hidden, intermediate bf16. Kcache / Vcache: layer 0's [Hkv, Lmax, 128]; layer l's at
- * + l * cache_layer_stride elements; the new row is appended at position lens[0] (lens is NOT advanced here).
- * `barrier`: one uint32 that MUST be zero when the kernel starts (zero it on the same stream before every launch).
+ * k_norm - all bf16, rows contiguous. `h` [hidden] bf16 holds the stack's input row and receives its output. `workspace`:
+ * vq3_qwen_decode_layers_workspace_bytes() of device memory (16-byte aligned; the rows that travel between workgroups). Kcache /
+ * Vcache: layer 0's [Hkv, Lmax, 128]; layer l's at + l * cache_layer_stride elements; the new row is appended at position lens[0]
+ * (lens is NOT advanced here).
+ * `barrier`: 4096 bytes (1024 uint32) that MUST be zero when the kernel starts (zero them on the same stream before every launch).
  * `status`: one uint32 the kernel ORs into and never clears: 1 = a grid-barrier wait ran out (a workgroup was not co-resident;
  * the outputs are garbage), 2 = cache full (lens[0] >= Lmax). The caller reads it when it next synchronises.
  * vq3_qwen_decode_layers_supported: 1 when this shape runs here (Qwen3-4B's 2560 / 9728 / 32 / 8 x 128, Lmax <= 2048, >= 256 CUs),
@@ -387,10 +388,7 @@ int vq3_decode_advance(int32_t* lens, int32_t B, int32_t* step, void* stream);
 typedef struct vq3_decode_layers_desc {
   const void* const* weights;
   void* h;
-  void* qkv;
-  void* attn;
-  void* h_mid;
-  void* act;
+  void* workspace;
   const void* cos;
   const void* sin;
   const int32_t* lens;
@@ -402,6 +400,7 @@ typedef struct vq3_decode_layers_desc {
   int32_t layers, hidden, intermediate, Hq, Hkv, head_dim, Lmax;
   float eps, scale;
 } vq3_decode_layers_desc;
+int64_t vq3_qwen_decode_layers_workspace_bytes(void);
 int vq3_qwen_decode_layers_supported(int32_t hidden, int32_t intermediate, int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t Lmax);
 int vq3_qwen_decode_layers(const vq3_decode_layers_desc* desc, void* stream);
 

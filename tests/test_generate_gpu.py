@@ -289,3 +289,136 @@ def test_inference_flow_like_the_reference_script():
     first = int(diff[0]) if diff.numel() else n
     assert first == n or trace[first] < TIE_TOL, (out.tolist(), ref.tolist(), trace)
     assert first >= 1
+
+
+def _qwen4b_dims(layers):
+    from vggt_qwen3_amd.qwen3 import Qwen3Config, Qwen3ForCausalLM
+    cfg = Qwen3Config.qwen3_4b()
+    cfg.num_hidden_layers = layers
+    return Qwen3ForCausalLM(cfg, device="cuda", seed=0), cfg
+
+
+def test_persistent_decode_layers_vs_one_launch_per_projection(ops, monkeypatch):
+    """vq3_qwen_decode_layers (all decoder layers of a B = 1 step in one persistent launch, Qwen3-4B's shape) against the per-projection
+    launches it replaces, from the same prefilled state: the hidden row that reaches lm_head and the appended cache rows agree within
+    bf16 rounding (the two differ only in the order of each dot product's fp32 terms), over three consecutive steps, and the status word
+    stays clear."""
+    from vggt_qwen3_amd import generate as G
+    if not ops.decode_layers_supported(2560, 9728, 32, 8, 128, 128):
+        pytest.skip("needs an MI355X (256 CUs)")
+    tm, cfg = _qwen4b_dims(3)
+    torch.manual_seed(5)
+    L0 = 37
+    emb = (torch.randn(1, L0, cfg.hidden_size) * 0.5).to(BF16).cuda()
+    spans = [(0, L0)]
+    states = []
+    for persistent in (False, True):
+        monkeypatch.setenv("VQ3_DECODE_PERSISTENT", "1" if persistent else "0")
+        st = G.DecodeState(tm, 1, 128, 8)
+        assert (st.persistent is not None) == persistent
+        cos, sin = tm.rope(128)
+        G._prefill(tm, st, emb, spans)
+        hs = []
+        for step in range(3):
+            st.next_ids.fill_(1000 + 17 * step)                     # the same token ids on both routes
+            if persistent:
+                ps = st.persistent
+                h = ops.gather_rows(tm._w["embed"], st.next_ids, 1, 1, out=ps["h"])
+                ops.decode_layers(ps["wtab"], h, ps["workspace"], cos, sin, st.lens, st.K, st.V, ps["barrier"], ps["status"], cfg.hidden_size,
+                                  cfg.intermediate_size, tm.Hq, tm.Hkv, cfg.rms_norm_eps, tm.D ** -0.5)
+                ops.decode_layers_status(ps["status"])
+                assert int(ps["barrier"].sum().item()) == 3 * (4 * 256 + 32)      # every arrival of every layer was counted
+            else:
+                h = ops.gather_rows(tm._w["embed"], st.next_ids, 1, 1)
+                for i in range(cfg.num_hidden_layers):
+                    qkv = ops.skinny_linear(h, tm._w[f"l{i}.qkv"], ln_w=tm._w[f"l{i}.ln1"], eps=cfg.rms_norm_eps)
+                    Q = ops.qwen_decode_qkprep(qkv, tm._w[f"l{i}.qn"], tm._w[f"l{i}.kn"], cos, sin, st.lens, st.K[i], st.V[i], 1, tm.Hq,
+                                               tm.Hkv, tm.D, st.Lmax, cfg.rms_norm_eps)
+                    ao = ops.qwen_decode_attn(Q, st.K[i], st.V[i], st.lens, 1, tm.Hq, tm.Hkv, tm.D, st.Lmax, tm.D ** -0.5)
+                    h_mid = ops.skinny_linear(ao, tm._w[f"l{i}.o"], residual=h)
+                    gu = ops.skinny_linear(h_mid, tm._w[f"l{i}.gu"], ln_w=tm._w[f"l{i}.ln2"], eps=cfg.rms_norm_eps)
+                    h = ops.skinny_linear(gu, tm._w[f"l{i}.down"], residual=h_mid, swiglu=True)
+            hs.append(h.float().clone())
+            ops.decode_advance(st.lens, 1, st.step)
+        states.append((hs, st.K[:, :, :, L0:L0 + 3].float().clone(), st.V[:, :, :, L0:L0 + 3].float().clone()))
+    (h0, k0, v0), (h1, k1, v1) = states
+    # (one bf16 ulp in a few of a projection's inputs moves every output of the next one by ~1e-3 relative, i.e. re-rounds a quarter of
+    # them: tools/diag/decode_layers_stages.py shows 2 of 6144 q|k|v values differing after the first GEMV, 44 % of the SwiGLU products
+    # by one ulp three projections later - the stage-by-stage statement is the test below, the end-to-end one the full-forward test)
+    for a, b in zip(h0, h1):
+        assert torch.isfinite(b).all()
+        assert (a - b).abs().max() <= 3e-2 * a.abs().max(), ((a - b).abs().max().item(), a.abs().max().item())
+        assert (a - b).norm() <= 2e-2 * a.norm()
+    assert (k0 - k1).abs().max() <= 2e-2 * k0.abs().max() and (v0 - v1).abs().max() <= 2e-2 * v0.abs().max()
+    assert k1.abs().max() > 0 and v1.abs().max() > 0
+
+
+def test_persistent_decode_layer_stage_by_stage(ops):
+    """One layer of the persistent kernel against the per-projection launches, intermediate by intermediate: the first GEMV (same inputs)
+    differs only where a sum lands on a rounding boundary; every later stage inherits and amplifies those ulps."""
+    from vggt_qwen3_amd import generate as G
+    if not ops.decode_layers_supported(2560, 9728, 32, 8, 128, 128):
+        pytest.skip("needs an MI355X (256 CUs)")
+    tm, cfg = _qwen4b_dims(1)
+    torch.manual_seed(5)
+    L0 = 37
+    emb = (torch.randn(1, L0, cfg.hidden_size) * 0.5).to(BF16).cuda()
+    cos, sin = tm.rope(128)
+    st = G.DecodeState(tm, 1, 128, 8)
+    G._prefill(tm, st, emb, [(0, L0)])
+    K0, V0 = st.K.clone(), st.V.clone()
+    st.next_ids.fill_(1000)
+    ps = st.persistent
+    h = ops.gather_rows(tm._w["embed"], st.next_ids, 1, 1, out=ps["h"])
+    h_in = h.clone()
+    ops.decode_layers(ps["wtab"], h, ps["workspace"], cos, sin, st.lens, st.K, st.V, ps["barrier"], ps["status"], cfg.hidden_size,
+                      cfg.intermediate_size, tm.Hq, tm.Hkv, cfg.rms_norm_eps, tm.D ** -0.5)
+    ws = ps["workspace"]
+    NQ, KO, Hd = (tm.Hq + 2 * tm.Hkv) * tm.D, tm.Hq * tm.D, cfg.hidden_size
+    w_qkv, w_attn, w_hmid, w_act = ws[:NQ], ws[NQ:NQ + KO], ws[NQ + KO:NQ + KO + Hd], ws[NQ + KO + Hd:NQ + KO + Hd + cfg.intermediate_size]
+    ops.decode_layers_status(ps["status"])
+    K1, V1 = st.K.clone(), st.V.clone()
+    st.K.copy_(K0); st.V.copy_(V0)
+    qkv = ops.skinny_linear(h_in, tm._w["l0.qkv"], ln_w=tm._w["l0.ln1"], eps=cfg.rms_norm_eps)
+    Q = ops.qwen_decode_qkprep(qkv, tm._w["l0.qn"], tm._w["l0.kn"], cos, sin, st.lens, st.K[0], st.V[0], 1, tm.Hq, tm.Hkv, tm.D, st.Lmax,
+                               cfg.rms_norm_eps)
+    ao = ops.qwen_decode_attn(Q, st.K[0], st.V[0], st.lens, 1, tm.Hq, tm.Hkv, tm.D, st.Lmax, tm.D ** -0.5)
+    h_mid = ops.skinny_linear(ao, tm._w["l0.o"], residual=h_in)
+    gu = ops.skinny_linear(h_mid, tm._w["l0.gu"], ln_w=tm._w["l0.ln2"], eps=cfg.rms_norm_eps)
+    I = cfg.intermediate_size
+    act = (torch.nn.functional.silu(gu[:, :I].float()).to(BF16).float() * gu[:, I:].float()).to(BF16)
+    h_out = ops.skinny_linear(gu, tm._w["l0.down"], residual=h_mid, swiglu=True)
+
+    def rel(a, b):
+        a, b = a.float().flatten(), b.float().flatten()
+        return ((a - b).norm() / b.norm()).item(), ((a - b).abs() > 0).float().mean().item()
+
+    r, frac = rel(w_qkv, qkv)
+    assert r <= 1e-4 and frac <= 5e-3, (r, frac)
+    assert torch.equal(K1[:, :, :, :L0], K0[:, :, :, :L0]) and torch.equal(V1[:, :, :, L0 + 1:], V0[:, :, :, L0 + 1:])      # only row L0 is written
+    assert rel(K1[:, :, :, L0], st.K[:, :, :, L0])[0] <= 2e-3 and rel(V1[:, :, :, L0], st.V[:, :, :, L0])[0] <= 2e-3
+    assert rel(w_attn, ao)[0] <= 2e-3
+    assert rel(w_hmid, h_mid)[0] <= 4e-3
+    assert rel(w_act, act)[0] <= 1.2e-2
+    assert rel(h, h_out)[0] <= 1.5e-2
+
+
+def test_persistent_decode_generate_matches_full_forward():
+    """generate() on the persistent route (B = 1, Qwen3-4B's shape, graph replay): the logits behind each greedy pick equal those of a
+    cache-free forward over prompt + generated tokens within the bf16 tie tolerance - the test the per-projection route passes above."""
+    from vggt_qwen3_amd import ops
+    if not ops.decode_layers_supported(2560, 9728, 32, 8, 128, 128):
+        pytest.skip("needs an MI355X (256 CUs)")
+    tm, cfg = _qwen4b_dims(2)
+    torch.manual_seed(7)
+    L = 21
+    emb = (torch.randn(1, L, cfg.hidden_size) * 0.5).to(BF16).cuda()
+    mask = torch.ones(1, L, dtype=torch.long).cuda()
+    out, stats = tm.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=9, use_graph=True, return_stats=True)
+    assert stats["persistent"] and stats["graph"] and out.shape == (1, 9)
+    full = torch.cat([emb, tm.get_input_embeddings()(out[:, :-1])], dim=1)
+    h, _ = tm.forward_hidden(full, torch.ones(1, full.shape[1], dtype=torch.long).cuda(), save=False)
+    logits = tm.logits_all(h).view(1, h.shape[0], -1).float()
+    for t in range(9):
+        row = logits[:, L - 1 + t]
+        assert ((row.max(-1).values - row.gather(1, out[:, t][:, None]).squeeze(1)) < TIE_TOL).all(), t

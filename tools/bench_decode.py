@@ -31,11 +31,11 @@ def main():
     tm.generate(max_new_tokens=4, **kw)                       # warm-up (library load, allocator)
     torch.cuda.synchronize()
     t0 = time.perf_counter(); tm.generate(max_new_tokens=2, **kw); torch.cuda.synchronize(); t_short = time.perf_counter() - t0
-    t0 = time.perf_counter(); out = tm.generate(max_new_tokens=a.new, **kw); torch.cuda.synchronize(); t_long = time.perf_counter() - t0
+    t0 = time.perf_counter(); out, stats = tm.generate(max_new_tokens=a.new, return_stats=True, **kw); torch.cuda.synchronize(); t_long = time.perf_counter() - t0
     per_tok = (t_long - t_short) / (a.new - 2)
     wbytes = 2 * sum(p.numel() for n, p in tm.named_parameters() if n != "lm_head.weight")   # every weight once (embedding = lm_head)
     print(json.dumps({"batch": a.batch, "prompt": a.prompt, "new_tokens": int(out.shape[1]), "graph": not a.no_graph,
-                      "ms_per_token": per_tok * 1e3, "tokens_per_s": a.batch / per_tok,
+                      "persistent_layers_kernel": stats["persistent"], "ms_per_token": per_tok * 1e3, "tokens_per_s": a.batch / per_tok,
                       "prefill_plus_2_ms": t_short * 1e3, "weight_GB_per_token": wbytes / 1e9,
                       "weight_stream_GBps": wbytes / per_tok / 1e9, "hbm_peak_GBps": 8000,
                       "frac_of_peak": wbytes / per_tok / 8e12}))

@@ -46,6 +46,13 @@ class GemmFp8Desc(C.Structure):
                 ("mode", i32), ("gu", c_p), ("dgu", c_p)]
 
 
+class DecodeLayersDesc(C.Structure):
+    _fields_ = [("weights", c_p), ("h", c_p), ("workspace", c_p), ("cos", c_p), ("sin", c_p),
+                ("lens", c_p), ("Kcache", c_p), ("Vcache", c_p), ("cache_layer_stride", i64), ("barrier", c_p), ("status", c_p),
+                ("layers", i32), ("hidden", i32), ("intermediate", i32), ("Hq", i32), ("Hkv", i32), ("head_dim", i32), ("Lmax", i32),
+                ("eps", f32), ("scale", f32)]
+
+
 class ColsumJob(C.Structure):
     _fields_ = [("part", c_p), ("out_bf16", c_p), ("nrows", i32), ("cols", i32), ("accumulate", i32)]
 
@@ -106,6 +113,9 @@ SIGNATURES = {
     "vq3_qwen_decode_attn": [c_p] * 5 + [i32, i32, i32, i32, i32, f32, c_p],
     "vq3_greedy_pick": [c_p, i64, c_p, i32, i32, c_p, i32, c_p, c_p, f32, i32, c_p, i32, i64, c_p, c_p],
     "vq3_decode_advance": [c_p, i32, c_p, c_p],
+    "vq3_qwen_decode_layers_supported": [i32] * 6,
+    "vq3_qwen_decode_layers_workspace_bytes": [],
+    "vq3_qwen_decode_layers": [C.POINTER(DecodeLayersDesc), c_p],
     "vq3_quant_fp8_rows": [c_p, i64, i64, i32, c_p, i64, c_p, c_p],
     "vq3_gemm_fp8_nt": [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i64, i64, c_p],
     "vq3_quant_fp8_rows_scaled": [c_p, i64, i64, i32, c_p, c_p, i64, c_p, c_p],
@@ -126,7 +136,7 @@ SIGNATURES = {
     "vq3_gemm_split_status": [c_p, c_p],
     "vq3_pack_tokens": [c_p, c_p, c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p, c_p],
 }
-_RESTYPES = {"vq3_last_error": C.c_char_p, "vq3_target_arch": C.c_char_p}
+_RESTYPES = {"vq3_last_error": C.c_char_p, "vq3_target_arch": C.c_char_p, "vq3_qwen_decode_layers_workspace_bytes": i64}
 
 _lib = None
 

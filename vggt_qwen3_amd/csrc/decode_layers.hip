@@ -30,6 +30,22 @@
 #include "common.h"
 #include "vq3_hip.h"
 
+// (diagnostic build: make EXTRA=-DVQ3_DL_STAMPS, then tools/diag/decode_layers_stamps.py prints where a layer's microseconds go)
+#ifdef VQ3_DL_STAMPS
+__device__ unsigned long long dl_stamps[2][32];
+__device__ unsigned long long dl_layer_end[64];     // [0] kernel start, [1 + l] end of layer l (workgroup 0)
+#define DL_STAMP(i)                                                                        \
+  do {                                                                                     \
+    if (l == 1 && (wg == 0 || wg == 37) && lead) dl_stamps[wg == 0 ? 0 : 1][i] = wall_clock64(); \
+  } while (0)
+extern "C" int vq3_debug_decode_stamps(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dl_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return 1;
+  return (int)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(dl_layer_end), sizeof(unsigned long long) * 64);
+}
+#else
+#define DL_STAMP(i)
+#endif
+
 namespace {
 
 // f(integral_constant<int, B>{}), ..., f(integral_constant<int, E - 1>{})
@@ -44,22 +60,30 @@ __device__ __forceinline__ void dl_static_for(F&& f) {
 constexpr int DL_G = 256;        // workgroups (= CUs of an MI355X)
 constexpr int DL_TS = 512;       // streaming threads per workgroup
 constexpr int DL_TH = 256;       // helper threads
-constexpr int DL_RING = 20;      // 16-byte weight loads in flight per streaming thread
+#ifndef VQ3_DL_RING
+#define VQ3_DL_RING 20
+#endif
+constexpr int DL_RING = VQ3_DL_RING;      // 16-byte weight loads in flight per streaming thread
 constexpr int DL_D = 128;        // head_dim
 constexpr int DL_LMAX = 2048;    // cache positions the score buffer holds
 constexpr unsigned DL_POLLS = 1u << 21;
 
-struct LayerW { const bf16_t *qkv, *o, *gu, *down, *ln1, *ln2, *qn, *kn; };
+// (pointers read from device memory are generic to the compiler: typed as global here, so the weight stream is global_load with a
+// scalar base + one per-thread offset, not flat_load - which would also count against the LDS counter)
+typedef const __attribute__((address_space(1))) bf16_t* dl_gbf;
+typedef const __attribute__((address_space(1))) char* dl_gchar;
+typedef const __attribute__((address_space(1))) u32x4* dl_gvec;
+struct LayerW { dl_gbf qkv, o, gu, down, ln1, ln2, qn, kn; };
 
 struct Args {
   const LayerW* w;               // [nl] (device)
   bf16_t* h;                     // [H]: the layer stack's input row, overwritten by its output
-  bf16_t *qkv, *ao, *hmid, *act; // scratch rows: (Hq + 2 Hkv) 128, Hq 128, H, I
+  float *qkv, *ao, *hmid, *act, *hx;   // workspace rows (fp32 values on the bf16 grid): (Hq + 2 Hkv) 128, Hq 128, H, I, H
   const bf16_t *cs, *sn;         // RoPE tables [>= Lmax, 128]
   const int32_t* lens;           // [1]: cached positions = position of the new token
   bf16_t *Kc, *Vc;               // layer 0's cache [Hkv, Lmax, 128]
   long cache_stride;             // elements between two layers' caches
-  unsigned* bar;                 // [0] arrival counter (zero at launch)
+  unsigned* bar;                 // DL_NBAR arrival counters, DL_BAR_STRIDE words apart (zero at launch)
   unsigned* status;              // sticky: 1 = a barrier wait ran out, 2 = cache full
   int nl, Lmax;
   float eps, scale;
@@ -81,21 +105,49 @@ __device__ __forceinline__ float dl_row16_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ void dl_grid_wait(unsigned* bar, unsigned* status, unsigned target) {
+// The arrival counter is DL_NBAR words 256 bytes apart (workgroup g adds to word g % DL_NBAR; the waiting wave reads all of them in one
+// round trip and adds): 256 agent-scope adds on ONE address serialise at the memory side - 6-8 us per barrier measured, against ~1 us so.
+constexpr int DL_NBAR = 16, DL_BAR_STRIDE = 64;
+// called by a whole wave (helper wave 0); returns when the sum of the counters has reached target (or the status word is raised)
+__device__ __forceinline__ void dl_grid_wait(unsigned* bar, unsigned* status, unsigned target, int lane) {
   unsigned n = 0;
-  while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(2);
+  for (;;) {
+    unsigned v = lane < DL_NBAR ? __hip_atomic_load(bar + lane * DL_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
+    __builtin_amdgcn_s_sleep(1);
     ++n;
     if ((n & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
     if (n > DL_POLLS) {
-      __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
   }
 }
-__device__ __forceinline__ void dl_grid_arrive(unsigned* bar) {
-  __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void dl_grid_arrive(unsigned* bar, int wg) {
+  __hip_atomic_fetch_add(bar + (wg % DL_NBAR) * DL_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Rows that cross workgroups (and XCDs, whose L2s are not coherent with each other) move through agent-scope accesses: the store is
+// written through, the load bypasses the non-coherent levels. The first version published with a release fence and read behind an
+// acquire fence instead - buffer_wbl2 / buffer_inv sc1 from 1024 helper waves five times per layer: 8-10 us per phase
+// (tools/diag/decode_layers_stamps.py), whatever the depth of the weight ring.
+__device__ __forceinline__ float dl_ld1(const float* p) {
+  return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<unsigned*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ f32x2_t dl_ld2(const float* p) {
+  const unsigned long long v =
+      __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return f32x2_t{__builtin_bit_cast(float, (unsigned)v), __builtin_bit_cast(float, (unsigned)(v >> 32))};
+}
+__device__ __forceinline__ void dl_st1(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the wave's stores have been acknowledged (CDNA4 counts stores in vmcnt): what a workgroup's arrival at the grid barrier promises.
+// (Tried instead: a 16-bit epoch in the low half of every workspace word, checked and re-read by the consumer, so that a producer arrives
+// without waiting for the acknowledgement - the store's visibility latency is on the critical path either way, the readers' retries add
+// traffic, and the 36-layer step got slower: 2.85 -> 4.65 ms / token.)
+__device__ __forceinline__ void dl_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // H hidden, I intermediate, HQ / HKV heads (head_dim 128). Every projection's rows divide over the 256 workgroups and every K is a
 // multiple of 512 (a wave's 64 x 16 bytes stay inside one weight row).
@@ -130,41 +182,49 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
   float* const red = reinterpret_cast<float*>(lds + Gm::RED);
   float* const opart = reinterpret_cast<float*>(lds + Gm::OPART);
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
+  int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
   const bool streamer = wave < DL_TS / 64;
-  const int ht = tid - DL_TS, hw = wave - DL_TS / 64;             // helper thread / wave index (negative for streamers)
+  int ht = tid - DL_TS;                                           // helper thread / wave index (negative for streamers)
+  const int hw = wave - DL_TS / 64;
   const bool lead = tid == DL_TS;
 
   u32x4 ring[DL_RING];
 
-  // ---- weight address of slot S (compile time) for this thread
-  auto slot_ptr = [&](const LayerW& w, auto tag) -> const u32x4* {
-    constexpr int S = decltype(tag)::value;
-    if constexpr (S < Gm::B2) {
-      constexpr int j = S - Gm::B0;
-      return reinterpret_cast<const u32x4*>(w.qkv + (size_t)wg * Gm::R0 * H) + (tid + DL_TS * j);
-    } else if constexpr (S < Gm::B3) {
-      constexpr int j = S - Gm::B2;
-      return reinterpret_cast<const u32x4*>(w.o + (size_t)wg * Gm::R2 * Gm::KO) + (tid + DL_TS * j);
-    } else if constexpr (S < Gm::B4) {
-      constexpr int j = S - Gm::B3;
-      int c = tid + DL_TS * j;
-      if (j == Gm::S3 - 1 && c >= Gm::C3) c -= DL_TS;             // ragged last step: a duplicate of the previous piece (never summed)
-      const bf16_t* gate = w.gu + (size_t)wg * Gm::RG * H;
-      const bf16_t* up = w.gu + ((size_t)I + (size_t)wg * Gm::RG) * H;
-      return c < Gm::C3H ? reinterpret_cast<const u32x4*>(gate) + c : reinterpret_cast<const u32x4*>(up) + (c - Gm::C3H);
-    } else {
-      constexpr int j = S - Gm::B4;
-      int c = tid + DL_TS * j;
-      if (j == Gm::S4 - 1 && c >= Gm::C4) c -= DL_TS;
-      return reinterpret_cast<const u32x4*>(w.down + (size_t)wg * Gm::R4 * I) + c;
-    }
-  };
+  // ---- weight piece of slot S (compile time) for this thread: uniform base (scalar registers) + per-thread byte offset
+  const unsigned voff = (unsigned)tid * 16u;
   auto issue = [&](const LayerW& w, auto tag) {
     constexpr int S = decltype(tag)::value;
-    if constexpr (S < Gm::NS) ring[S % DL_RING] = __builtin_nontemporal_load(slot_ptr(w, tag));
+    if constexpr (S < Gm::NS) {
+      dl_gchar base;
+      unsigned off = voff;
+      if constexpr (S < Gm::B2) {
+        constexpr int j = S - Gm::B0;
+        base = (dl_gchar)w.qkv + ((size_t)wg * Gm::R0 * H * 2 + (size_t)j * DL_TS * 16);
+      } else if constexpr (S < Gm::B3) {
+        constexpr int j = S - Gm::B2;
+        base = (dl_gchar)w.o + ((size_t)wg * Gm::R2 * Gm::KO * 2 + (size_t)j * DL_TS * 16);
+      } else if constexpr (S < Gm::B4) {
+        constexpr int j = S - Gm::B3;
+        constexpr int CB = DL_TS * j;                                // first piece of the step
+        const dl_gchar gate = (dl_gchar)w.gu + (size_t)wg * Gm::RG * H * 2;
+        const dl_gchar up = (dl_gchar)w.gu + ((size_t)I + (size_t)wg * Gm::RG) * H * 2;
+        if constexpr (CB + DL_TS <= Gm::C3H) base = gate + (size_t)CB * 16;
+        else if constexpr (CB >= Gm::C3H) {
+          base = up + (size_t)(CB - Gm::C3H) * 16;
+          if (j == Gm::S3 - 1 && CB + tid >= Gm::C3) off = 0;               // ragged last step: lanes past the slab re-read its first piece of the step (never summed)
+        } else {
+          base = (CB + tid < Gm::C3H) ? gate + (long)CB * 16 : up + ((long)CB - Gm::C3H) * 16;   // the slab boundary falls inside this step (wave-aligned)
+        }
+      } else {
+        constexpr int j = S - Gm::B4;
+        base = (dl_gchar)w.down + ((size_t)wg * Gm::R4 * I * 2 + (size_t)j * DL_TS * 16);
+        if (j == Gm::S4 - 1 && DL_TS * j + tid >= Gm::C4) off = 0;
+      }
+      ring[S % DL_RING] = __builtin_nontemporal_load((dl_gvec)(base + off));
+    }
   };
   // ---- one piece: 8 weights x 8 activations, 16-lane sums into part[u][lane / 16]
   auto consume = [&](auto tag) {
@@ -175,7 +235,11 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       constexpr int K = PH == 2 ? Gm::KO : (PH == 4 ? I : H);
       constexpr int WPR = K / 512;                                 // wave pieces per weight row
       constexpr int UTOT = (PH == 0 ? Gm::C0 : PH == 2 ? Gm::C2 : PH == 3 ? Gm::C3 : Gm::C4) / 64;
-      const int u = wave + 8 * j;
+      // (the wave index is laundered per piece: left visible, the compiler hoists all 97 pieces' loop-invariant LDS addresses - two
+      // registers each - out of the layer loop and spills the ring)
+      int wv = wave;
+      asm volatile("" : "+s"(wv));
+      const int u = wv + 8 * j;
       const int kc = (u % WPR) * 64 + lane;
       float wf[8];
       dl_unpack8(ring[S % DL_RING], wf);
@@ -188,43 +252,55 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
     }
   };
   // sum of a row's pieces in a fixed order
-  auto row_sum = [&](int r, int wpr) {
+  auto row_sum = [&](int r, auto wpr_tag) {
+    constexpr int WPR = decltype(wpr_tag)::value;
+    f32x4 p[WPR];
+#pragma unroll
+    for (int u = 0; u < WPR; ++u) p[u] = *reinterpret_cast<const f32x4*>(part + (r * WPR + u) * 4);      // all reads in flight, then the adds
     float s = 0.f;
-    for (int u = r * wpr; u < (r + 1) * wpr; ++u) {
-      const f32x4 p = *reinterpret_cast<const f32x4*>(part + u * 4);
-      s += (p[0] + p[1]) + (p[2] + p[3]);
-    }
+#pragma unroll
+    for (int u = 0; u < WPR; ++u) s += (p[u][0] + p[u][1]) + (p[u][2] + p[u][3]);
     return s;
   };
-  // Qwen3RMSNorm of a K-element row into the x planes (helper wave 0: K / 512 pieces per lane, statistics by one wave_sum)
-  auto xprep_rms = [&](const bf16_t* row, const bf16_t* lnw) {
+  // Qwen3RMSNorm of an H-element row into the x planes (helper wave 0: H / 512 pieces per lane, statistics by one wave_sum). The row is
+  // the bf16 input of the stack (layer 0) or a workspace row.
+  auto xprep_rms = [&](const bf16_t* row16, const float* row32, const u32x4 (&lnv)[H / 512]) {
     constexpr int NP = H / 512;
     float f[NP][8];
     float ss = 0.f;
+    if (row16) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      dl_unpack8(*reinterpret_cast<const u32x4*>(row + (lane + 64 * i) * 8), f[i]);
+      for (int i = 0; i < NP; ++i) dl_unpack8(*reinterpret_cast<const u32x4*>(row16 + (lane + 64 * i) * 8), f[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x2_t v = dl_ld2(row32 + (lane + 64 * i) * 8 + 2 * q);
+          f[i][2 * q] = v[0]; f[i][2 * q + 1] = v[1];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e) ss = fmaf(f[i][e], f[i][e], ss);
-    }
     const float rstd = rsqrtf(wave_sum(ss) / (float)H + a.eps);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       float lw[8];
-      dl_unpack8(*reinterpret_cast<const u32x4*>(lnw + (lane + 64 * i) * 8), lw);
+      dl_unpack8(lnv[i], lw);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[i][e] = rbf(lw[e] * rbf(f[i][e] * rstd));
       xlo[lane + 64 * i] = f32x4{f[i][0], f[i][1], f[i][2], f[i][3]};
       xhi[lane + 64 * i] = f32x4{f[i][4], f[i][5], f[i][6], f[i][7]};
     }
   };
-  // a bf16 row as it is (all helper threads)
-  auto xprep_copy = [&](const bf16_t* row, int K) {
+  // a workspace row as it is (all helper threads)
+  auto xprep_copy = [&](const float* row, int K) {
     for (int c = ht; c < K / 8; c += DL_TH) {
-      float f[8];
-      dl_unpack8(*reinterpret_cast<const u32x4*>(row + c * 8), f);
-      xlo[c] = f32x4{f[0], f[1], f[2], f[3]};
-      xhi[c] = f32x4{f[4], f[5], f[6], f[7]};
+      const f32x2_t v0 = dl_ld2(row + c * 8), v1 = dl_ld2(row + c * 8 + 2), v2 = dl_ld2(row + c * 8 + 4), v3 = dl_ld2(row + c * 8 + 6);
+      xlo[c] = f32x4{v0[0], v0[1], v1[0], v1[1]};
+      xhi[c] = f32x4{v2[0], v2[1], v3[0], v3[1]};
     }
   };
 
@@ -233,199 +309,291 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
     const LayerW w0 = a.w[0];
     dl_static_for<0, DL_RING>([&](auto tag) { issue(w0, tag); });
   }
+#ifdef VQ3_DL_STAMPS
+  if (wg == 0 && lead) dl_layer_end[0] = wall_clock64();
+#endif
   const int pos = a.lens[0];
   if (pos >= a.Lmax && lead) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const bool cache_ok = pos < a.Lmax;
   const bool attn = !streamer && wg < HQ && cache_ok;
   const int T = pos + 1;
+  // the residual stream's rows this helper thread owns (h[n], h_mid[n] for n = wg * H / 256 + ht): produced and consumed by the same
+  // thread, so they never travel
+  float h_own = 0.f, hmid_own = 0.f;
+  if (!streamer && ht < Gm::R2) h_own = bf2f(a.h[wg * Gm::R2 + ht]);
 
-  for (int l = 0; l < a.nl; ++l) {
-    const LayerW w = a.w[l];
-    const LayerW wn = a.w[l + 1 < a.nl ? l + 1 : l];               // past the last layer: harmless re-reads of its first pieces
-    const unsigned base = (unsigned)l * Gm::PER_LAYER;
-    // one streaming phase: pieces [SB, SE) are multiplied, the pieces RING ahead are requested into the registers just freed
-    auto stream_phase = [&](auto sb, auto se) {
-      constexpr int SB = decltype(sb)::value, SE = decltype(se)::value;
-      dl_static_for<SB, SE>([&](auto tag) {
-        constexpr int S = decltype(tag)::value, SN = S + DL_RING;
-        consume(tag);
-        if constexpr (SN < Gm::NSLOT) issue(w, std::integral_constant<int, SN>{});
-        else issue(wn, std::integral_constant<int, SN - Gm::NSLOT>{});
-      });
-    };
-
-    // ================= phase 0: q|k|v = W_qkv . RMSNorm(h)
-    if (lead && l > 0) dl_grid_wait(a.bar, a.status, base);                       // every row of h (previous layer's phase 4)
-    __syncthreads();
-    if (!streamer) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (hw == 0) xprep_rms(a.h, w.ln1);
-    __syncthreads();
-    if (streamer) stream_phase(std::integral_constant<int, Gm::B0>{}, std::integral_constant<int, Gm::B2>{});
-    __syncthreads();
-    if (!streamer && ht < Gm::R0) a.qkv[wg * Gm::R0 + ht] = f2bf(row_sum(ht, H / 512));
-    __syncthreads();
-    if (lead) { dl_grid_arrive(a.bar); dl_grid_wait(a.bar, a.status, base + DL_G); }
-
-    // ================= phase 1: attention of head wg (helpers of workgroups 0 .. HQ - 1), decode.hip's order of operations
-    __syncthreads();
-    if (!streamer) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    bf16_t* const Kl = a.Kc + (long)l * a.cache_stride + (long)(wg / (HQ / HKV)) * a.Lmax * DL_D;
-    bf16_t* const Vl = a.Vc + (long)l * a.cache_stride + (long)(wg / (HQ / HKV)) * a.Lmax * DL_D;
-    if (attn && hw < 3) {
-      // wave 0: q' of head wg; wave 1: k' of its kv head; wave 2: v. Lane i holds elements i and i + 64 (the rotate_half pair).
-      const int hk = wg / (HQ / HKV);
-      const bf16_t* src = a.qkv + (hw == 0 ? wg * DL_D : (hw == 1 ? (HQ + hk) * DL_D : (HQ + HKV + hk) * DL_D));
-      const float x1 = bf2f(src[lane]), x2 = bf2f(src[lane + 64]);
-      float o1 = x1, o2 = x2;
-      if (hw < 2) {
-        const bf16_t* nw = hw == 0 ? w.qn : w.kn;
-        const float c1 = bf2f(a.cs[(long)pos * DL_D + lane]), c2 = bf2f(a.cs[(long)pos * DL_D + lane + 64]);
-        const float s1 = bf2f(a.sn[(long)pos * DL_D + lane]), s2 = bf2f(a.sn[(long)pos * DL_D + lane + 64]);
-        const float rs = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)DL_D + a.eps);
-        const float n1 = rbf(bf2f(nw[lane]) * rbf(x1 * rs));
-        const float n2 = rbf(bf2f(nw[lane + 64]) * rbf(x2 * rs));
-        o1 = rbf(rbf(n1 * c1) + rbf(-n2 * s1));
-        o2 = rbf(rbf(n2 * c2) + rbf(n1 * s2));
+  // Two instantiations of the layer loop, one per role, with the same sequence of workgroup barriers: in one body the register allocator
+  // sees a helper's prefetched cache rows live across the streamers' ring (it cannot know the branch is never taken by that wave) and
+  // spills both.
+  auto run = [&](auto role) {
+    constexpr bool STREAM = decltype(role)::value;
+    for (int l = 0; l < a.nl; ++l) {
+      const LayerW w = a.w[l];
+      const LayerW wn = a.w[l + 1 < a.nl ? l + 1 : l];               // past the last layer: harmless re-reads of its first pieces
+      const unsigned base = (unsigned)l * Gm::PER_LAYER;
+      // (helpers: the thread indices are laundered once per layer - visible as loop invariants they make the compiler hoist every
+      // per-thread address of the layer out of the loop and spill them around the attention's row buffers)
+      if constexpr (!STREAM) asm volatile("" : "+v"(lane), "+v"(ht));
+      // the two norm weights of the layer: requested now (helper wave 0), used after the barriers
+      u32x4 ln1v[H / 512], ln2v[H / 512];
+      if constexpr (!STREAM) if (hw == 0) {
+#pragma unroll
+        for (int i = 0; i < H / 512; ++i) ln1v[i] = *(dl_gvec)(w.ln1 + (lane + 64 * i) * 8);
       }
-      qs[hw * DL_D + lane] = o1;
-      qs[hw * DL_D + lane + 64] = o2;
-      if (hw > 0 && wg % (HQ / HKV) == 0) {                        // one workgroup per kv head appends the row to the cache
-        bf16_t* dst = (hw == 1 ? Kl : Vl) + (long)pos * DL_D;
-        dst[lane] = f2bf(o1);
-        dst[lane + 64] = f2bf(o2);
-      }
-    }
-    __syncthreads();
-    const int sub = lane >> 4, dl = (lane & 15) * 8;
-    float mx = -INFINITY;
-    if (attn) {
-      float qf[8];
+      // attention operands that do not depend on this token: the head's cache, RoPE row and q / k norm weights
+      bf16_t* const Kl = a.Kc + (long)l * a.cache_stride + (long)(wg / (HQ / HKV)) * a.Lmax * DL_D;
+      bf16_t* const Vl = a.Vc + (long)l * a.cache_stride + (long)(wg / (HQ / HKV)) * a.Lmax * DL_D;
+      const int sub = lane >> 4, dl = (lane & 15) * 8;
+      const int last = pos > 0 ? pos - 1 : 0;                         // cached rows only; the new row comes from LDS (its store is another workgroup's)
+      // rows c0 + 4 hw + 64 (it / 4) + 16 (it % 4) + sub, 8 elements from dl: decode.hip's key -> lane map, 128 keys per call
+      auto load_rows = [&](const bf16_t* base_rows, int c0, u32x4 (&r)[8]) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qf[e] = qs[dl + e];
-      const int last = pos > 0 ? pos - 1 : 0;                       // cached rows only; the new row comes from LDS (its store is another workgroup's)
-      for (int l0 = hw * 4; l0 < T; l0 += 64) {
-        u32x4 kr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) kr[i] = *reinterpret_cast<const u32x4*>(Kl + (long)min(l0 + 16 * i + sub, last) * DL_D + dl);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int lk = l0 + 16 * i + sub;
-          float kf[8];
-          dl_unpack8(kr[i], kf);
-          if (lk == pos) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) kf[e] = qs[DL_D + dl + e];
-          }
-          float s = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) s = fmaf(qf[e], kf[e], s);
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-          s *= a.scale;
-          if (lk < T) {
-            if ((lane & 15) == 0) sc[lk] = s;
-            mx = fmaxf(mx, s);
-          }
+        for (int it = 0; it < 8; ++it)
+          r[it] = *reinterpret_cast<const u32x4*>(base_rows + (long)min(c0 + hw * 4 + 64 * (it >> 2) + 16 * (it & 3) + sub, last) * DL_D + dl);
+      };
+      u32x4 kpre[2][8];                                               // two chunks of key rows, then of value rows, in flight (registers: 64)
+      float rc1 = 0.f, rc2 = 0.f, rs1 = 0.f, rs2 = 0.f, nw1 = 0.f, nw2 = 0.f;
+      if constexpr (!STREAM) if (attn) {
+        load_rows(Kl, 0, kpre[0]);
+        if (hw < 2) {
+          const dl_gbf nw = hw == 0 ? w.qn : w.kn;
+          rc1 = bf2f(a.cs[(long)pos * DL_D + lane]); rc2 = bf2f(a.cs[(long)pos * DL_D + lane + 64]);
+          rs1 = bf2f(a.sn[(long)pos * DL_D + lane]); rs2 = bf2f(a.sn[(long)pos * DL_D + lane + 64]);
+          nw1 = bf2f(nw[lane]); nw2 = bf2f(nw[lane + 64]);
         }
       }
-      mx = wave_max(mx);
-      if (lane == 0) red[hw] = mx;
-    }
-    __syncthreads();
-    float sum = 0.f;
-    if (attn) {
-      mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-      for (int lk = ht; lk < T; lk += DL_TH) {
-        const float e = __expf(sc[lk] - mx);
-        sc[lk] = e;
-        sum += e;
-      }
-      sum = wave_sum(sum);
-      if (lane == 0) red[4 + hw] = sum;
-    }
-    __syncthreads();
-    if (attn) {
-      const float inv = 1.f / (((0.f + red[4]) + red[5]) + red[6] + red[7]);
-      const int last = pos > 0 ? pos - 1 : 0;
-      float of[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) of[e] = 0.f;
-      for (int l0 = hw * 4; l0 < T; l0 += 64) {
-        u32x4 vr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vr[i] = *reinterpret_cast<const u32x4*>(Vl + (long)min(l0 + 16 * i + sub, last) * DL_D + dl);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int lk = l0 + 16 * i + sub;
-          const float p = lk < T ? rbf(sc[lk] * inv) : 0.f;
-          float vf[8];
-          dl_unpack8(vr[i], vf);
-          if (lk == pos) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) vf[e] = qs[2 * DL_D + dl + e];
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) of[e] = fmaf(p, vf[e], of[e]);
+      // one streaming phase: pieces [SB, SE) are multiplied, the pieces RING ahead are requested into the registers just freed
+      auto stream_phase = [&](auto sb, auto se) {
+        constexpr int SB = decltype(sb)::value, SE = decltype(se)::value;
+        dl_static_for<SB, SE>([&](auto tag) {
+          constexpr int S = decltype(tag)::value, SN = S + DL_RING;
+          consume(tag);
+          if constexpr (SN < Gm::NSLOT) issue(w, std::integral_constant<int, SN>{});
+          else issue(wn, std::integral_constant<int, SN - Gm::NSLOT>{});
+        });
+      };
+
+      // ================= phase 0: q|k|v = W_qkv . RMSNorm(h)
+      DL_STAMP(0);
+      if constexpr (!STREAM) if (hw == 0 && l > 0) dl_grid_wait(a.bar, a.status, base, lane);             // every row of h (previous layer's phase 4)
+      DL_STAMP(1);
+      __syncthreads();
+      if constexpr (!STREAM) if (hw == 0) xprep_rms(l == 0 ? a.h : nullptr, a.hx, ln1v);
+      __syncthreads();
+      DL_STAMP(2);
+      if constexpr (STREAM) stream_phase(std::integral_constant<int, Gm::B0>{}, std::integral_constant<int, Gm::B2>{});
+      __syncthreads();
+      DL_STAMP(3);
+      if constexpr (!STREAM) if (ht < Gm::R0) { dl_st1(a.qkv + wg * Gm::R0 + ht, rbf(row_sum(ht, std::integral_constant<int, H / 512>{}))); dl_stores_done(); }
+      __syncthreads();
+      DL_STAMP(4);
+      if constexpr (!STREAM) if (lead) dl_grid_arrive(a.bar, wg);
+      if constexpr (!STREAM) if (hw == 0) dl_grid_wait(a.bar, a.status, base + DL_G, lane);
+      DL_STAMP(5);
+
+      // ================= phase 1: attention of head wg (helpers of workgroups 0 .. HQ - 1), decode.hip's order of operations
+      __syncthreads();
+      DL_STAMP(20);
+      if constexpr (!STREAM) if (attn && T > 128) load_rows(Kl, 128, kpre[1]);      // the second chunk of key rows: under the q / k / v preparation
+      if constexpr (!STREAM) if (attn && hw < 3) {
+        // wave 0: q' of head wg; wave 1: k' of its kv head; wave 2: v. Lane i holds elements i and i + 64 (the rotate_half pair).
+        const int hk = wg / (HQ / HKV);
+        const float* src = a.qkv + (hw == 0 ? wg * DL_D : (hw == 1 ? (HQ + hk) * DL_D : (HQ + HKV + hk) * DL_D));
+        const float x1 = dl_ld1(src + lane), x2 = dl_ld1(src + lane + 64);
+        float o1 = x1, o2 = x2;
+        if (hw < 2) {
+          const float rs = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)DL_D + a.eps);
+          const float n1 = rbf(nw1 * rbf(x1 * rs));
+          const float n2 = rbf(nw2 * rbf(x2 * rs));
+          o1 = rbf(rbf(n1 * rc1) + rbf(-n2 * rs1));
+          o2 = rbf(rbf(n2 * rc2) + rbf(n1 * rs2));
+        }
+        qs[hw * DL_D + lane] = o1;
+        qs[hw * DL_D + lane + 64] = o2;
+        if (hw > 0 && wg % (HQ / HKV) == 0) {                        // one workgroup per kv head appends the row to the cache
+          bf16_t* dst = (hw == 1 ? Kl : Vl) + (long)pos * DL_D;
+          dst[lane] = f2bf(o1);
+          dst[lane + 64] = f2bf(o2);
         }
       }
+      __syncthreads();
+      DL_STAMP(21);
+      float mx = -INFINITY;
+      if constexpr (!STREAM) if (attn) {
+        float qf[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        of[e] += __shfl_xor(of[e], 16, 64);
-        of[e] += __shfl_xor(of[e], 32, 64);
-      }
-      if (sub == 0) {
+        for (int e = 0; e < 8; ++e) qf[e] = qs[dl + e];
+        // 128 keys per chunk and workgroup (8 row loads per lane), the next chunk requested before this one is multiplied; chunk 0 was
+        // requested during phase 0
+        auto scores = [&](int c0, const u32x4 (&kr)[8]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) opart[hw * DL_D + dl + e] = of[e];
+          for (int it = 0; it < 8; ++it) {
+            const int lk = c0 + hw * 4 + 64 * (it >> 2) + 16 * (it & 3) + sub;
+            float kf[8];
+            dl_unpack8(kr[it], kf);
+            if (lk == pos) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) kf[e] = qs[DL_D + dl + e];
+            }
+            float sv = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sv = fmaf(qf[e], kf[e], sv);
+            sv = dl_row16_sum(sv) * a.scale;                             // the key's 16 lanes -> its lane 15 (DPP; a shuffle is an LDS round trip)
+            if (lk < T && (lane & 15) == 15) {
+              sc[lk] = sv;
+              mx = fmaxf(mx, sv);
+            }
+          }
+        };
+        for (int c0 = 0; c0 < T; c0 += 256) {
+          if (c0 > 0 && c0 + 128 < T) load_rows(Kl, c0 + 128, kpre[1]);
+          scores(c0, kpre[0]);
+          if (c0 + 256 < T) load_rows(Kl, c0 + 256, kpre[0]);
+          if (c0 + 128 < T) scores(c0 + 128, kpre[1]);
+        }
+        asm volatile("" ::: "memory");                                // (the same registers: no value row is requested before the last key row was multiplied)
+        load_rows(Vl, 0, kpre[0]);                                    // land under the two softmax steps
+        if (T > 128) load_rows(Vl, 128, kpre[1]);
+        mx = wave_max(mx);
+        if (lane == 0) red[hw] = mx;
       }
-    }
-    __syncthreads();
-    if (attn && ht < DL_D) a.ao[wg * DL_D + ht] = f2bf(opart[ht] + opart[DL_D + ht] + opart[2 * DL_D + ht] + opart[3 * DL_D + ht]);
-    __syncthreads();
-    if (lead) {
-      if (wg < HQ) dl_grid_arrive(a.bar);
-      dl_grid_wait(a.bar, a.status, base + DL_G + HQ);
-    }
+      __syncthreads();
+      DL_STAMP(22);
+      float sum = 0.f;
+      if constexpr (!STREAM) if (attn) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        for (int lk = ht; lk < T; lk += DL_TH) {
+          const float e = __expf(sc[lk] - mx);
+          sc[lk] = e;
+          sum += e;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) red[4 + hw] = sum;
+      }
+      __syncthreads();
+      DL_STAMP(23);
+      if constexpr (!STREAM) if (attn) {
+        const float inv = 1.f / (((0.f + red[4]) + red[5]) + red[6] + red[7]);
+        float of[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) of[e] = 0.f;
+        auto pv = [&](int c0, const u32x4 (&vr)[8]) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int lk = c0 + hw * 4 + 64 * (it >> 2) + 16 * (it & 3) + sub;
+            const float p = lk < T ? rbf(sc[lk] * inv) : 0.f;
+            float vf[8];
+            dl_unpack8(vr[it], vf);
+            if (lk == pos) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) vf[e] = qs[2 * DL_D + dl + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) of[e] = fmaf(p, vf[e], of[e]);
+          }
+        };
+        for (int c0 = 0; c0 < T; c0 += 256) {
+          if (c0 > 0 && c0 + 128 < T) load_rows(Vl, c0 + 128, kpre[1]);
+          pv(c0, kpre[0]);
+          if (c0 + 256 < T) load_rows(Vl, c0 + 256, kpre[0]);
+          if (c0 + 128 < T) pv(c0 + 128, kpre[1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          of[e] += __shfl_xor(of[e], 16, 64);
+          of[e] += __shfl_xor(of[e], 32, 64);
+        }
+        if (sub == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) opart[hw * DL_D + dl + e] = of[e];
+        }
+      }
+      __syncthreads();
+      DL_STAMP(24);
+      if constexpr (!STREAM) if (attn && ht < DL_D) {
+        dl_st1(a.ao + wg * DL_D + ht, rbf(opart[ht] + opart[DL_D + ht] + opart[2 * DL_D + ht] + opart[3 * DL_D + ht]));
+        dl_stores_done();
+       
+      }
+      if constexpr (!STREAM) if (hw == 0) {                                                  // the second norm weight: requested now, used two barriers later
+#pragma unroll
+        for (int i = 0; i < H / 512; ++i) ln2v[i] = *(dl_gvec)(w.ln2 + (lane + 64 * i) * 8);
+      }
+      __syncthreads();
+      DL_STAMP(25);
+      DL_STAMP(6);
+      if constexpr (!STREAM) if (lead && wg < HQ) dl_grid_arrive(a.bar, wg);
+      if constexpr (!STREAM) if (hw == 0) dl_grid_wait(a.bar, a.status, base + DL_G + HQ, lane);
+      DL_STAMP(7);
 
-    // ================= phase 2: h_mid = h + W_o . attn
-    __syncthreads();
-    if (!streamer) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); xprep_copy(a.ao, Gm::KO); }
-    __syncthreads();
-    if (streamer) stream_phase(std::integral_constant<int, Gm::B2>{}, std::integral_constant<int, Gm::B3>{});
-    __syncthreads();
-    if (!streamer && ht < Gm::R2) {
-      const int n = wg * Gm::R2 + ht;
-      a.hmid[n] = f2bf(rbf(row_sum(ht, Gm::KO / 512)) + bf2f(a.h[n]));
-    }
-    __syncthreads();
-    if (lead) { dl_grid_arrive(a.bar); dl_grid_wait(a.bar, a.status, base + 2 * DL_G + HQ); }
+      // ================= phase 2: h_mid = h + W_o . attn
+      __syncthreads();
+      if constexpr (!STREAM) xprep_copy(a.ao, Gm::KO);
+      __syncthreads();
+      DL_STAMP(8);
+      if constexpr (STREAM) stream_phase(std::integral_constant<int, Gm::B2>{}, std::integral_constant<int, Gm::B3>{});
+      __syncthreads();
+      DL_STAMP(9);
+      if constexpr (!STREAM) if (ht < Gm::R2) {
+        const int n = wg * Gm::R2 + ht;
+        hmid_own = rbf(rbf(row_sum(ht, std::integral_constant<int, Gm::KO / 512>{})) + h_own);
+        dl_st1(a.hmid + n, hmid_own);
+        dl_stores_done();
+       
+      }
+      __syncthreads();
+      DL_STAMP(10);
+      if constexpr (!STREAM) if (lead) dl_grid_arrive(a.bar, wg);
+      if constexpr (!STREAM) if (hw == 0) dl_grid_wait(a.bar, a.status, base + 2 * DL_G + HQ, lane);
+      DL_STAMP(11);
 
-    // ================= phase 3: act = SwiGLU(W_gate|up . RMSNorm(h_mid)) - a workgroup owns gate AND up of its 38 features
-    __syncthreads();
-    if (!streamer) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (hw == 0) xprep_rms(a.hmid, w.ln2);
-    __syncthreads();
-    if (streamer) stream_phase(std::integral_constant<int, Gm::B3>{}, std::integral_constant<int, Gm::B4>{});
-    __syncthreads();
-    if (!streamer && ht < Gm::RG) {
-      const float g = rbf(row_sum(ht, H / 512)), up = rbf(row_sum(Gm::RG + ht, H / 512));
-      a.act[wg * Gm::RG + ht] = f2bf(rbf(silu_f(g)) * up);
-    }
-    __syncthreads();
-    if (lead) { dl_grid_arrive(a.bar); dl_grid_wait(a.bar, a.status, base + 3 * DL_G + HQ); }
+      // ================= phase 3: act = SwiGLU(W_gate|up . RMSNorm(h_mid)) - a workgroup owns gate AND up of its 38 features
+      __syncthreads();
+      if constexpr (!STREAM) if (hw == 0) xprep_rms(nullptr, a.hmid, ln2v);
+      __syncthreads();
+      DL_STAMP(12);
+      if constexpr (STREAM) stream_phase(std::integral_constant<int, Gm::B3>{}, std::integral_constant<int, Gm::B4>{});
+      __syncthreads();
+      DL_STAMP(13);
+      if constexpr (!STREAM) if (ht < Gm::RG) {
+        const float g = rbf(row_sum(ht, std::integral_constant<int, H / 512>{})), up = rbf(row_sum(Gm::RG + ht, std::integral_constant<int, H / 512>{}));
+        dl_st1(a.act + wg * Gm::RG + ht, rbf(rbf(silu_f(g)) * up));
+        dl_stores_done();
+       
+      }
+      __syncthreads();
+      DL_STAMP(14);
+      if constexpr (!STREAM) if (lead) dl_grid_arrive(a.bar, wg);
+      if constexpr (!STREAM) if (hw == 0) dl_grid_wait(a.bar, a.status, base + 3 * DL_G + HQ, lane);
+      DL_STAMP(15);
 
-    // ================= phase 4: h = h_mid + W_down . act
-    __syncthreads();
-    if (!streamer) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); xprep_copy(a.act, I); }
-    __syncthreads();
-    if (streamer) stream_phase(std::integral_constant<int, Gm::B4>{}, std::integral_constant<int, Gm::NSLOT>{});
-    __syncthreads();
-    if (!streamer && ht < Gm::R4) {
-      const int n = wg * Gm::R4 + ht;
-      a.h[n] = f2bf(rbf(row_sum(ht, I / 512)) + bf2f(a.hmid[n]));
+      // ================= phase 4: h = h_mid + W_down . act
+      __syncthreads();
+      if constexpr (!STREAM) xprep_copy(a.act, I);
+      __syncthreads();
+      DL_STAMP(16);
+      if constexpr (STREAM) stream_phase(std::integral_constant<int, Gm::B4>{}, std::integral_constant<int, Gm::NSLOT>{});
+      __syncthreads();
+      DL_STAMP(17);
+      if constexpr (!STREAM) if (ht < Gm::R4) {
+        const int n = wg * Gm::R4 + ht;
+        h_own = rbf(rbf(row_sum(ht, std::integral_constant<int, I / 512>{})) + hmid_own);
+        dl_st1(a.hx + n, h_own);
+        if (l == a.nl - 1) a.h[n] = f2bf(h_own);
+        dl_stores_done();
+       
+      }
+      __syncthreads();
+      DL_STAMP(18);
+      if constexpr (!STREAM) if (lead) dl_grid_arrive(a.bar, wg);
+      DL_STAMP(19);
+#ifdef VQ3_DL_STAMPS
+      if (wg == 0 && lead && l < 62) dl_layer_end[1 + l] = wall_clock64();
+#endif
     }
-    __syncthreads();
-    if (lead) dl_grid_arrive(a.bar);
-  }
+  };
+  if (streamer) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 using Qwen3_4B = Geo<2560, 9728, 32, 8>;
@@ -458,11 +626,15 @@ extern "C" int vq3_qwen_decode_layers_supported(int32_t hidden, int32_t intermed
   return dl_device_ok() ? 1 : 0;
 }
 
+extern "C" int64_t vq3_qwen_decode_layers_workspace_bytes(void) {
+  return (int64_t)sizeof(float) * (Qwen3_4B::NQKV + Qwen3_4B::KO + 2 * 2560 + 9728);
+}
+
 extern "C" int vq3_qwen_decode_layers(const vq3_decode_layers_desc* d, void* stream) {
   VQ3_CHECK_ARG(d, "decode_layers: null descriptor");
-  VQ3_CHECK_ARG(d->weights && d->h && d->qkv && d->attn && d->h_mid && d->act && d->cos && d->sin && d->lens && d->Kcache && d->Vcache &&
-                    d->barrier && d->status,
+  VQ3_CHECK_ARG(d->weights && d->h && d->workspace && d->cos && d->sin && d->lens && d->Kcache && d->Vcache && d->barrier && d->status,
                 "decode_layers: null pointer");
+  VQ3_CHECK_ARG((uintptr_t)d->workspace % 16 == 0 && (uintptr_t)d->h % 16 == 0, "decode_layers: h and workspace must be 16-byte aligned");
   VQ3_CHECK_ARG(d->layers >= 1, "decode_layers: layers must be >= 1, got %d", d->layers);
   VQ3_CHECK_ARG(vq3_qwen_decode_layers_supported(d->hidden, d->intermediate, d->Hq, d->Hkv, d->head_dim, d->Lmax),
                 "decode_layers: unsupported shape / device (hidden %d, intermediate %d, heads %d / %d x %d, Lmax %d; needs Qwen3-4B's "
@@ -471,7 +643,8 @@ extern "C" int vq3_qwen_decode_layers(const vq3_decode_layers_desc* d, void* str
   VQ3_CHECK_ARG(d->cache_layer_stride >= (int64_t)d->Hkv * d->Lmax * DL_D, "decode_layers: cache_layer_stride smaller than one layer's cache");
   Args a;
   a.w = reinterpret_cast<const LayerW*>(d->weights);
-  a.h = (bf16_t*)d->h; a.qkv = (bf16_t*)d->qkv; a.ao = (bf16_t*)d->attn; a.hmid = (bf16_t*)d->h_mid; a.act = (bf16_t*)d->act;
+  a.h = (bf16_t*)d->h;
+  a.qkv = (float*)d->workspace; a.ao = a.qkv + Qwen3_4B::NQKV; a.hmid = a.ao + Qwen3_4B::KO; a.act = a.hmid + 2560; a.hx = a.act + 9728;
   a.cs = (const bf16_t*)d->cos; a.sn = (const bf16_t*)d->sin; a.lens = d->lens;
   a.Kc = (bf16_t*)d->Kcache; a.Vc = (bf16_t*)d->Vcache; a.cache_stride = d->cache_layer_stride;
   a.bar = (unsigned*)d->barrier; a.status = (unsigned*)d->status;

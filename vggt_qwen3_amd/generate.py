@@ -68,6 +68,18 @@ class DecodeState:
         self.next_ids = torch.zeros(B, device=dev, dtype=torch.int32)
         self.generated = torch.zeros((B, gen_cols), device=dev, dtype=torch.int64)
         self.work = torch.zeros(B * 128 + 8, device=dev, dtype=F32)     # pick partials + overflow flag
+        # B = 1 at Qwen3-4B's shape: all decoder layers of a step in ONE persistent launch (csrc/decode_layers.hip) instead of six
+        # launches per layer; every other case decodes with one launch per projection
+        self.persistent = None
+        if (B == 1 and getattr(tm, "_fp8", None) is None and os.environ.get("VQ3_DECODE_PERSISTENT", "1") != "0"
+                and ops.decode_layers_supported(c.hidden_size, c.intermediate_size, tm.Hq, tm.Hkv, tm.D, Lmax)):
+            names = ("qkv", "o", "gu", "down", "ln1", "ln2", "qn", "kn")
+            assert all(tm._w[f"l{i}.{n}"].is_contiguous() for i in range(nl) for n in names)
+            self.persistent = dict(
+                wtab=torch.tensor([[tm._w[f"l{i}.{n}"].data_ptr() for n in names] for i in range(nl)], dtype=torch.int64, device=dev),
+                h=torch.empty((1, c.hidden_size), device=dev, dtype=BF16), workspace=ops.decode_layers_workspace(dev),
+                barrier=torch.zeros(1024, device=dev, dtype=torch.int32),
+                status=torch.zeros(1, device=dev, dtype=torch.int32))
 
 
 def _prefill(tm, st: DecodeState, embeds: torch.Tensor, spans: Sequence[Tuple[int, int]]) -> torch.Tensor:
@@ -104,6 +116,14 @@ def _decode_step(tm, st: DecodeState, cos, sin, opts) -> None:
     """One token for every row. Fixed launch sequence, every varying quantity read from device memory."""
     c = tm.config
     B, Hq, Hkv, D = st.B, tm.Hq, tm.Hkv, tm.D
+    ps = st.persistent
+    if ps is not None:
+        h = ops.gather_rows(tm._w["embed"], st.next_ids, B, B, out=ps["h"])
+        ops.decode_layers(ps["wtab"], h, ps["workspace"], cos, sin, st.lens, st.K, st.V, ps["barrier"], ps["status"], c.hidden_size,
+                          c.intermediate_size, tm.Hq, tm.Hkv, c.rms_norm_eps, D ** -0.5)
+        _logits_and_pick(tm, st, h, opts)
+        ops.decode_advance(st.lens, B, st.step)
+        return
     h = ops.gather_rows(tm._w["embed"], st.next_ids, B, B)
     f8 = tm._fp8 if (tm._fp8 is not None and B <= 2) else None     # e4m3 weight stream (config C5): half the bytes per token
 
@@ -195,6 +215,8 @@ def generate(tm, inputs_embeds: Optional[torch.Tensor] = None, attention_mask: O
         else:
             _decode_step(tm, st, cos, sin, opts)
         done_steps += 1
+    if st.persistent is not None:
+        ops.decode_layers_status(st.persistent["status"])
     gen = st.generated[:, : n_prompt + done_steps].cpu()
     # transformers stops right after the step in which the last row finished: trim what ran past it
     stop = done_steps
@@ -208,5 +230,5 @@ def generate(tm, inputs_embeds: Optional[torch.Tensor] = None, attention_mask: O
             stop = min(done_steps, int(first.max()) + 1)
     out = gen[:, : n_prompt + stop].to(dev)
     if return_stats:
-        return out, {"steps_run": done_steps, "graph": graph is not None, "Lmax": Lmax}
+        return out, {"steps_run": done_steps, "graph": graph is not None, "Lmax": Lmax, "persistent": st.persistent is not None}
     return out

@@ -337,10 +337,14 @@ def f32_to_bf16_acc(src: torch.Tensor, acc: torch.Tensor, accumulate: bool) -> N
                                           _stream()), "vq3_f32_to_bf16_acc")
 
 
-def gather_rows(src: torch.Tensor, idx: torch.Tensor, n: int, n_pad: int) -> torch.Tensor:
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, n: int, n_pad: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(src, BF16, "gather_rows src"); _req(idx, torch.int32, "gather_rows idx")
     assert src.is_contiguous() and src.dim() == 2
-    out = torch.empty((n_pad, src.shape[1]), device=src.device, dtype=BF16)
+    if out is None:
+        out = torch.empty((n_pad, src.shape[1]), device=src.device, dtype=BF16)
+    else:
+        _req(out, BF16, "gather_rows out")
+        assert out.is_contiguous() and tuple(out.shape) == (n_pad, src.shape[1])
     check(_lib.load().vq3_gather_rows(src.data_ptr(), idx.data_ptr(), out.data_ptr(), n, n_pad, src.shape[1],
                                       _stream()), "vq3_gather_rows")
     return out
@@ -730,6 +734,53 @@ def greedy_pick(logits, work, generated, step, finished, penalty, ngram, eos_ids
 
 def decode_advance(lens: Optional[torch.Tensor], B: int, step: Optional[torch.Tensor]) -> None:
     check(_lib.load().vq3_decode_advance(_p(lens), B, _p(step), _stream()), "vq3_decode_advance")
+
+
+def decode_layers_supported(hidden: int, intermediate: int, Hq: int, Hkv: int, head_dim: int, Lmax: int) -> bool:
+    """True when vq3_qwen_decode_layers (all decoder layers of a B = 1 decode step in one persistent launch) takes this shape on this device."""
+    return bool(_lib.load().vq3_qwen_decode_layers_supported(hidden, intermediate, Hq, Hkv, head_dim, Lmax))
+
+
+def decode_layers_workspace(device) -> torch.Tensor:
+    """The rows that travel between the persistent decode kernel's workgroups (vq3_qwen_decode_layers_workspace_bytes)."""
+    return torch.zeros(int(_lib.load().vq3_qwen_decode_layers_workspace_bytes()) // 4, device=device, dtype=F32)
+
+
+def decode_layers(wtab: torch.Tensor, h: torch.Tensor, workspace: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, lens: torch.Tensor,
+                  K: torch.Tensor, V: torch.Tensor, barrier: torch.Tensor, status: torch.Tensor, hidden: int, intermediate: int, Hq: int,
+                  Hkv: int, eps: float, scale: float) -> None:
+    """h [1, hidden] <- the decoder stack applied to it for the token at position lens[0] (vq3_qwen_decode_layers). wtab: int64
+    [layers, 8] device pointers (qkv, o, gate|up, down, ln1, ln2, q_norm, k_norm); K / V: [layers, 1, Hkv, Lmax, 128] caches; `workspace`
+    from decode_layers_workspace(); `barrier` (int32 [1024]) is zeroed here on the stream, `status` (int32 [1]) is sticky - see
+    decode_layers_status()."""
+    for t, nm in ((h, "h"), (cos, "cos"), (sin, "sin"), (K, "K"), (V, "V")):
+        _req(t, BF16, "decode_layers " + nm)
+        assert t.is_contiguous(), nm
+    _req(wtab, torch.int64, "decode_layers wtab"); _req(lens, torch.int32, "decode_layers lens"); _req(workspace, F32, "decode_layers workspace")
+    _req(barrier, torch.int32, "decode_layers barrier"); _req(status, torch.int32, "decode_layers status")
+    nl = wtab.shape[0]
+    assert wtab.is_contiguous() and wtab.shape[1] == 8 and K.dim() == 5 and K.shape[0] == nl and K.shape[1] == 1 and K.shape == V.shape
+    Lmax, D = K.shape[3], K.shape[4]
+    assert h.numel() == hidden and K.shape[2] == Hkv and workspace.is_contiguous()
+    assert workspace.numel() * 4 >= int(_lib.load().vq3_qwen_decode_layers_workspace_bytes())
+    assert barrier.numel() >= 1024 and barrier.is_contiguous()
+    assert cos.shape[0] >= Lmax and cos.shape[1] == D and sin.shape == cos.shape
+    import ctypes as C
+    barrier.zero_()
+    d = _lib.DecodeLayersDesc(wtab.data_ptr(), h.data_ptr(), workspace.data_ptr(), cos.data_ptr(), sin.data_ptr(), lens.data_ptr(),
+                              K.data_ptr(), V.data_ptr(), K.stride(0), barrier.data_ptr(), status.data_ptr(), nl, hidden, intermediate,
+                              Hq, Hkv, D, Lmax, float(eps), float(scale))
+    check(_lib.load().vq3_qwen_decode_layers(C.byref(d), _stream()), "vq3_qwen_decode_layers")
+
+
+def decode_layers_status(status: torch.Tensor) -> None:
+    """Raise if a persistent decode launch reported a failure (synchronises)."""
+    st = int(status.item())
+    if st & 1:
+        raise RuntimeError("vq3_qwen_decode_layers: a grid-barrier wait ran out (the 256 workgroups were not co-resident - is another "
+                           "kernel holding CUs?); set VQ3_DECODE_PERSISTENT=0 to decode with one launch per projection")
+    if st & 2:
+        raise RuntimeError("vq3_qwen_decode_layers: KV cache full")
 
 
 # ---------------------------------------------------------------------------------------------- fp8 forward (config C5)
