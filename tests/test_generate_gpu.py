@@ -373,7 +373,7 @@ def test_persistent_decode_layer_stage_by_stage(ops):
     h_in = h.clone()
     ops.decode_layers(ps["wtab"], h, ps["workspace"], cos, sin, st.lens, st.K, st.V, ps["barrier"], ps["status"], cfg.hidden_size,
                       cfg.intermediate_size, tm.Hq, tm.Hkv, cfg.rms_norm_eps, tm.D ** -0.5)
-    ws = ps["workspace"]
+    ws = ps["workspace"]                                              # bf16 rows: q|k|v, attention output, h_mid, SwiGLU product, h
     NQ, KO, Hd = (tm.Hq + 2 * tm.Hkv) * tm.D, tm.Hq * tm.D, cfg.hidden_size
     w_qkv, w_attn, w_hmid, w_act = ws[:NQ], ws[NQ:NQ + KO], ws[NQ + KO:NQ + KO + Hd], ws[NQ + KO + Hd:NQ + KO + Hd + cfg.intermediate_size]
     ops.decode_layers_status(ps["status"])

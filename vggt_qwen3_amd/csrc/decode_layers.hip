@@ -78,7 +78,7 @@ struct LayerW { dl_gbf qkv, o, gu, down, ln1, ln2, qn, kn; };
 struct Args {
   const LayerW* w;               // [nl] (device)
   bf16_t* h;                     // [H]: the layer stack's input row, overwritten by its output
-  float *qkv, *ao, *hmid, *act, *hx;   // workspace rows (fp32 values on the bf16 grid): (Hq + 2 Hkv) 128, Hq 128, H, I, H
+  bf16_t *qkv, *ao, *hmid, *act, *hx;  // workspace rows (bf16): (Hq + 2 Hkv) 128, Hq 128, H, I, H
   const bf16_t *cs, *sn;         // RoPE tables [>= Lmax, 128]
   const int32_t* lens;           // [1]: cached positions = position of the new token
   bf16_t *Kc, *Vc;               // layer 0's cache [Hkv, Lmax, 128]
@@ -96,6 +96,11 @@ __device__ __forceinline__ void dl_unpack8(const u32x4 v, float* f) {
   f[6] = __builtin_bit_cast(float, v.w << 16); f[7] = __builtin_bit_cast(float, v.w & 0xffff0000u);
 }
 
+typedef __bf16 dl_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dl_dot2(unsigned w, unsigned x, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(dl_bf2, w), __builtin_bit_cast(dl_bf2, x), c, false);
+}
+
 // sum over the 16 lanes of a DPP row, valid in the row's lane 15 (VALU only: no LDS round trip per step)
 __device__ __forceinline__ float dl_row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
@@ -107,14 +112,17 @@ __device__ __forceinline__ float dl_row16_sum(float v) {
 
 // The arrival counter is DL_NBAR words 256 bytes apart (workgroup g adds to word g % DL_NBAR; the waiting wave reads all of them in one
 // round trip and adds): 256 agent-scope adds on ONE address serialise at the memory side - 6-8 us per barrier measured, against ~1 us so.
-constexpr int DL_NBAR = 16, DL_BAR_STRIDE = 64;
+#ifndef VQ3_DL_NBAR
+#define VQ3_DL_NBAR 16
+#endif
+constexpr int DL_NBAR = VQ3_DL_NBAR, DL_BAR_STRIDE = 64;
 // called by a whole wave (helper wave 0); returns when the sum of the counters has reached target (or the status word is raised)
 __device__ __forceinline__ void dl_grid_wait(unsigned* bar, unsigned* status, unsigned target, int lane) {
   unsigned n = 0;
   for (;;) {
     unsigned v = lane < DL_NBAR ? __hip_atomic_load(bar + lane * DL_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
     __builtin_amdgcn_s_sleep(1);
     ++n;
@@ -132,16 +140,20 @@ __device__ __forceinline__ void dl_grid_arrive(unsigned* bar, int wg) {
 // written through, the load bypasses the non-coherent levels. The first version published with a release fence and read behind an
 // acquire fence instead - buffer_wbl2 / buffer_inv sc1 from 1024 helper waves five times per layer: 8-10 us per phase
 // (tools/diag/decode_layers_stamps.py), whatever the depth of the weight ring.
-__device__ __forceinline__ float dl_ld1(const float* p) {
-  return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<unsigned*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+__device__ __forceinline__ unsigned dl_ld32(const bf16_t* p) {      // two bf16
+  return __hip_atomic_load(reinterpret_cast<unsigned*>(const_cast<bf16_t*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ f32x2_t dl_ld2(const float* p) {
+__device__ __forceinline__ u32x2 dl_ld64(const bf16_t* p) {         // four bf16
   const unsigned long long v =
-      __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return f32x2_t{__builtin_bit_cast(float, (unsigned)v), __builtin_bit_cast(float, (unsigned)(v >> 32))};
+      __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<bf16_t*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return u32x2{(unsigned)v, (unsigned)(v >> 32)};
 }
-__device__ __forceinline__ void dl_st1(float* p, float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// rows leave their producers two values at a time: thread 2 i stores (value of thread 2 i, value of thread 2 i + 1) as one 32-bit word
+// (called by WHOLE waves; idx < n decides who stores, n even)
+__device__ __forceinline__ void dl_st_pair(bf16_t* row, int idx, int n, float v) {
+  const float nb = __shfl_down(v, 1, 64);
+  if ((idx & 1) == 0 && idx < n)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(row + idx), pack2bf(v, nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the wave's stores have been acknowledged (CDNA4 counts stores in vmcnt): what a workgroup's arrival at the grid barrier promises.
 // (Tried instead: a 16-bit epoch in the low half of every workspace word, checked and re-read by the consumer, so that a producer arrives
@@ -166,21 +178,22 @@ struct Geo {
   static constexpr int UMAX = C3 / 64 > C4 / 64 ? C3 / 64 : C4 / 64;       // wave-sized pieces per phase and workgroup
   static constexpr int PER_LAYER = 4 * DL_G + HQ;                            // barrier arrivals per layer
   // LDS (bytes)
-  static constexpr int XLO = 0, XHI = KMAX / 8 * 16, PART = 2 * XHI, SC = PART + UMAX * 16 + 64, QS = SC + DL_LMAX * 4,
-                       RED = QS + 3 * DL_D * 4, OPART = RED + 64, LDS_USED = OPART + 4 * DL_D * 4;
+  static constexpr int XS = 0, PART = KMAX / 8 * 16, SC = PART + UMAX * 16 + 64, QS = SC + DL_LMAX * 4,
+                       RED = QS + 3 * DL_D * 4, OPART = RED + 64, LNW = OPART + 4 * DL_D * 4, LDS_USED = LNW + 2 * H * 2;
 };
 
 template <int H, int I, int HQ, int HKV>
 __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args a) {
   using Gm = Geo<H, I, HQ, HKV>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  f32x4* const xlo = reinterpret_cast<f32x4*>(lds + Gm::XLO);     // x[8 c .. 8 c + 3]
-  f32x4* const xhi = reinterpret_cast<f32x4*>(lds + Gm::XHI);     // x[8 c + 4 .. 8 c + 7]
+  u32x4* const xs = reinterpret_cast<u32x4*>(lds + Gm::XS);       // the phase's activation row, bf16: piece c = x[8 c .. 8 c + 7]
   float* const part = reinterpret_cast<float*>(lds + Gm::PART);   // [wave piece u][16-lane group]
   float* const sc = reinterpret_cast<float*>(lds + Gm::SC);
   float* const qs = reinterpret_cast<float*>(lds + Gm::QS);       // q', k', v of the new token (fp32 values on the bf16 grid)
   float* const red = reinterpret_cast<float*>(lds + Gm::RED);
   float* const opart = reinterpret_cast<float*>(lds + Gm::OPART);
+  u32x4* const lnw1 = reinterpret_cast<u32x4*>(lds + Gm::LNW);   // input_layernorm / post_attention_layernorm weights of the layer, staged by
+  u32x4* const lnw2 = lnw1 + H / 8;                               // helper wave 3 while the others work (no registers held across phases)
 
   const int tid = threadIdx.x;
   int lane = tid & 63;
@@ -194,6 +207,11 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
   u32x4 ring[DL_RING];
 
   // ---- weight piece of slot S (compile time) for this thread: uniform base (scalar registers) + per-thread byte offset
+#ifdef VQ3_DL_NOHBM
+  const int wga = 0;     // diagnostic: every workgroup streams workgroup 0's slabs (L2 hits): what is left is the latency chain
+#else
+  const int wga = wg;
+#endif
   const unsigned voff = (unsigned)tid * 16u;
   auto issue = [&](const LayerW& w, auto tag) {
     constexpr int S = decltype(tag)::value;
@@ -202,15 +220,15 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       unsigned off = voff;
       if constexpr (S < Gm::B2) {
         constexpr int j = S - Gm::B0;
-        base = (dl_gchar)w.qkv + ((size_t)wg * Gm::R0 * H * 2 + (size_t)j * DL_TS * 16);
+        base = (dl_gchar)w.qkv + ((size_t)wga * Gm::R0 * H * 2 + (size_t)j * DL_TS * 16);
       } else if constexpr (S < Gm::B3) {
         constexpr int j = S - Gm::B2;
-        base = (dl_gchar)w.o + ((size_t)wg * Gm::R2 * Gm::KO * 2 + (size_t)j * DL_TS * 16);
+        base = (dl_gchar)w.o + ((size_t)wga * Gm::R2 * Gm::KO * 2 + (size_t)j * DL_TS * 16);
       } else if constexpr (S < Gm::B4) {
         constexpr int j = S - Gm::B3;
         constexpr int CB = DL_TS * j;                                // first piece of the step
-        const dl_gchar gate = (dl_gchar)w.gu + (size_t)wg * Gm::RG * H * 2;
-        const dl_gchar up = (dl_gchar)w.gu + ((size_t)I + (size_t)wg * Gm::RG) * H * 2;
+        const dl_gchar gate = (dl_gchar)w.gu + (size_t)wga * Gm::RG * H * 2;
+        const dl_gchar up = (dl_gchar)w.gu + ((size_t)I + (size_t)wga * Gm::RG) * H * 2;
         if constexpr (CB + DL_TS <= Gm::C3H) base = gate + (size_t)CB * 16;
         else if constexpr (CB >= Gm::C3H) {
           base = up + (size_t)(CB - Gm::C3H) * 16;
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
         }
       } else {
         constexpr int j = S - Gm::B4;
-        base = (dl_gchar)w.down + ((size_t)wg * Gm::R4 * I * 2 + (size_t)j * DL_TS * 16);
+        base = (dl_gchar)w.down + ((size_t)wga * Gm::R4 * I * 2 + (size_t)j * DL_TS * 16);
         if (j == Gm::S4 - 1 && DL_TS * j + tid >= Gm::C4) off = 0;
       }
       ring[S % DL_RING] = __builtin_nontemporal_load((dl_gvec)(base + off));
@@ -241,12 +259,12 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       asm volatile("" : "+s"(wv));
       const int u = wv + 8 * j;
       const int kc = (u % WPR) * 64 + lane;
-      float wf[8];
-      dl_unpack8(ring[S % DL_RING], wf);
-      const f32x4 x0 = xlo[kc], x1 = xhi[kc];
-      float acc = wf[0] * x0[0];
-      acc = fmaf(wf[1], x0[1], acc); acc = fmaf(wf[2], x0[2], acc); acc = fmaf(wf[3], x0[3], acc);
-      acc = fmaf(wf[4], x1[0], acc); acc = fmaf(wf[5], x1[1], acc); acc = fmaf(wf[6], x1[2], acc); acc = fmaf(wf[7], x1[3], acc);
+      // v_dot2c_f32_bf16: two products of bf16 pairs per instruction, straight from the packed words (no unpacking of weights or x)
+      const u32x4 wq = ring[S % DL_RING], xq = xs[kc];
+      float acc = dl_dot2(wq.x, xq.x, 0.f);
+      acc = dl_dot2(wq.y, xq.y, acc);
+      acc = dl_dot2(wq.z, xq.z, acc);
+      acc = dl_dot2(wq.w, xq.w, acc);
       acc = dl_row16_sum(acc);
       if ((lane & 15) == 15 && u < UTOT) part[u * 4 + (lane >> 4)] = acc;
     }
@@ -264,7 +282,7 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
   };
   // Qwen3RMSNorm of an H-element row into the x planes (helper wave 0: H / 512 pieces per lane, statistics by one wave_sum). The row is
   // the bf16 input of the stack (layer 0) or a workspace row.
-  auto xprep_rms = [&](const bf16_t* row16, const float* row32, const u32x4 (&lnv)[H / 512]) {
+  auto xprep_rms = [&](const bf16_t* row16, const bf16_t* rowws, const u32x4* lnv) {
     constexpr int NP = H / 512;
     float f[NP][8];
     float ss = 0.f;
@@ -273,12 +291,10 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       for (int i = 0; i < NP; ++i) dl_unpack8(*reinterpret_cast<const u32x4*>(row16 + (lane + 64 * i) * 8), f[i]);
     } else {
 #pragma unroll
-      for (int i = 0; i < NP; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x2_t v = dl_ld2(row32 + (lane + 64 * i) * 8 + 2 * q);
-          f[i][2 * q] = v[0]; f[i][2 * q + 1] = v[1];
-        }
+      for (int i = 0; i < NP; ++i) {
+        const u32x2 lo = dl_ld64(rowws + (lane + 64 * i) * 8), hi = dl_ld64(rowws + (lane + 64 * i) * 8 + 4);
+        dl_unpack8(u32x4{lo[0], lo[1], hi[0], hi[1]}, f[i]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i)
@@ -288,19 +304,17 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       float lw[8];
-      dl_unpack8(lnv[i], lw);
+      dl_unpack8(lnv[lane + 64 * i], lw);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[i][e] = rbf(lw[e] * rbf(f[i][e] * rstd));
-      xlo[lane + 64 * i] = f32x4{f[i][0], f[i][1], f[i][2], f[i][3]};
-      xhi[lane + 64 * i] = f32x4{f[i][4], f[i][5], f[i][6], f[i][7]};
+      xs[lane + 64 * i] = u32x4{pack2bf(f[i][0], f[i][1]), pack2bf(f[i][2], f[i][3]), pack2bf(f[i][4], f[i][5]), pack2bf(f[i][6], f[i][7])};
     }
   };
   // a workspace row as it is (all helper threads)
-  auto xprep_copy = [&](const float* row, int K) {
+  auto xprep_copy = [&](const bf16_t* row, int K) {
     for (int c = ht; c < K / 8; c += DL_TH) {
-      const f32x2_t v0 = dl_ld2(row + c * 8), v1 = dl_ld2(row + c * 8 + 2), v2 = dl_ld2(row + c * 8 + 4), v3 = dl_ld2(row + c * 8 + 6);
-      xlo[c] = f32x4{v0[0], v0[1], v1[0], v1[1]};
-      xhi[c] = f32x4{v2[0], v2[1], v3[0], v3[1]};
+      const u32x2 lo = dl_ld64(row + c * 8), hi = dl_ld64(row + c * 8 + 4);
+      xs[c] = u32x4{lo[0], lo[1], hi[0], hi[1]};
     }
   };
 
@@ -312,6 +326,11 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
 #ifdef VQ3_DL_STAMPS
   if (wg == 0 && lead) dl_layer_end[0] = wall_clock64();
 #endif
+  if (!streamer && hw == 3) {                                       // layer 0's first norm weight (later ones are staged a layer ahead)
+    const LayerW w0 = a.w[0];
+#pragma unroll
+    for (int i = 0; i < H / 512; ++i) lnw1[lane + 64 * i] = *(dl_gvec)(w0.ln1 + (lane + 64 * i) * 8);
+  }
   const int pos = a.lens[0];
   if (pos >= a.Lmax && lead) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const bool cache_ok = pos < a.Lmax;
@@ -334,12 +353,6 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       // (helpers: the thread indices are laundered once per layer - visible as loop invariants they make the compiler hoist every
       // per-thread address of the layer out of the loop and spill them around the attention's row buffers)
       if constexpr (!STREAM) asm volatile("" : "+v"(lane), "+v"(ht));
-      // the two norm weights of the layer: requested now (helper wave 0), used after the barriers
-      u32x4 ln1v[H / 512], ln2v[H / 512];
-      if constexpr (!STREAM) if (hw == 0) {
-#pragma unroll
-        for (int i = 0; i < H / 512; ++i) ln1v[i] = *(dl_gvec)(w.ln1 + (lane + 64 * i) * 8);
-      }
       // attention operands that do not depend on this token: the head's cache, RoPE row and q / k norm weights
       bf16_t* const Kl = a.Kc + (long)l * a.cache_stride + (long)(wg / (HQ / HKV)) * a.Lmax * DL_D;
       bf16_t* const Vl = a.Vc + (long)l * a.cache_stride + (long)(wg / (HQ / HKV)) * a.Lmax * DL_D;
@@ -378,13 +391,27 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       if constexpr (!STREAM) if (hw == 0 && l > 0) dl_grid_wait(a.bar, a.status, base, lane);             // every row of h (previous layer's phase 4)
       DL_STAMP(1);
       __syncthreads();
-      if constexpr (!STREAM) if (hw == 0) xprep_rms(l == 0 ? a.h : nullptr, a.hx, ln1v);
+      if constexpr (!STREAM) if (hw == 0) xprep_rms(l == 0 ? a.h : nullptr, a.hx, lnw1);
       __syncthreads();
       DL_STAMP(2);
+      if constexpr (!STREAM) if (hw == 3) {
+        // norm weights through LDS: this layer's second one (read after two more barriers) and the NEXT layer's first one (its reader,
+        // wave 0, is done with the current one: it was read before the barrier above)
+#pragma unroll
+        for (int i = 0; i < H / 512; ++i) {
+          const u32x4 v2 = *(dl_gvec)(w.ln2 + (lane + 64 * i) * 8), v1 = *(dl_gvec)(wn.ln1 + (lane + 64 * i) * 8);
+          lnw2[lane + 64 * i] = v2;
+          lnw1[lane + 64 * i] = v1;
+        }
+      }
       if constexpr (STREAM) stream_phase(std::integral_constant<int, Gm::B0>{}, std::integral_constant<int, Gm::B2>{});
       __syncthreads();
       DL_STAMP(3);
-      if constexpr (!STREAM) if (ht < Gm::R0) { dl_st1(a.qkv + wg * Gm::R0 + ht, rbf(row_sum(ht, std::integral_constant<int, H / 512>{}))); dl_stores_done(); }
+      if constexpr (!STREAM) if (hw == 0) {
+        static_assert(Gm::R0 % 2 == 0 && Gm::R2 % 2 == 0 && Gm::RG % 2 == 0 && Gm::R4 % 2 == 0 && Gm::RG <= 64, "rows leave in pairs, from helper wave 0");
+        dl_st_pair(a.qkv + wg * Gm::R0, ht, Gm::R0, row_sum(ht < Gm::R0 ? ht : 0, std::integral_constant<int, H / 512>{}));
+        dl_stores_done();
+      }
       __syncthreads();
       DL_STAMP(4);
       if constexpr (!STREAM) if (lead) dl_grid_arrive(a.bar, wg);
@@ -398,8 +425,10 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       if constexpr (!STREAM) if (attn && hw < 3) {
         // wave 0: q' of head wg; wave 1: k' of its kv head; wave 2: v. Lane i holds elements i and i + 64 (the rotate_half pair).
         const int hk = wg / (HQ / HKV);
-        const float* src = a.qkv + (hw == 0 ? wg * DL_D : (hw == 1 ? (HQ + hk) * DL_D : (HQ + HKV + hk) * DL_D));
-        const float x1 = dl_ld1(src + lane), x2 = dl_ld1(src + lane + 64);
+        const bf16_t* src = a.qkv + (hw == 0 ? wg * DL_D : (hw == 1 ? (HQ + hk) * DL_D : (HQ + HKV + hk) * DL_D));
+        const unsigned w1 = dl_ld32(src + (lane & ~1)), w2 = dl_ld32(src + 64 + (lane & ~1));       // the pair holding element lane / lane + 64
+        const float x1 = __builtin_bit_cast(float, (lane & 1) ? (w1 & 0xffff0000u) : (w1 << 16));
+        const float x2 = __builtin_bit_cast(float, (lane & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
         float o1 = x1, o2 = x2;
         if (hw < 2) {
           const float rs = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)DL_D + a.eps);
@@ -510,14 +539,9 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       }
       __syncthreads();
       DL_STAMP(24);
-      if constexpr (!STREAM) if (attn && ht < DL_D) {
-        dl_st1(a.ao + wg * DL_D + ht, rbf(opart[ht] + opart[DL_D + ht] + opart[2 * DL_D + ht] + opart[3 * DL_D + ht]));
+      if constexpr (!STREAM) if (attn && hw < 2) {
+        dl_st_pair(a.ao + wg * DL_D, ht, DL_D, opart[ht] + opart[DL_D + ht] + opart[2 * DL_D + ht] + opart[3 * DL_D + ht]);
         dl_stores_done();
-       
-      }
-      if constexpr (!STREAM) if (hw == 0) {                                                  // the second norm weight: requested now, used two barriers later
-#pragma unroll
-        for (int i = 0; i < H / 512; ++i) ln2v[i] = *(dl_gvec)(w.ln2 + (lane + 64 * i) * 8);
       }
       __syncthreads();
       DL_STAMP(25);
@@ -534,12 +558,10 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       if constexpr (STREAM) stream_phase(std::integral_constant<int, Gm::B2>{}, std::integral_constant<int, Gm::B3>{});
       __syncthreads();
       DL_STAMP(9);
-      if constexpr (!STREAM) if (ht < Gm::R2) {
-        const int n = wg * Gm::R2 + ht;
-        hmid_own = rbf(rbf(row_sum(ht, std::integral_constant<int, Gm::KO / 512>{})) + h_own);
-        dl_st1(a.hmid + n, hmid_own);
+      if constexpr (!STREAM) if (hw == 0) {
+        hmid_own = rbf(rbf(row_sum(ht < Gm::R2 ? ht : 0, std::integral_constant<int, Gm::KO / 512>{})) + h_own);      // (lanes past the rows: unused)
+        dl_st_pair(a.hmid + wg * Gm::R2, ht, Gm::R2, hmid_own);
         dl_stores_done();
-       
       }
       __syncthreads();
       DL_STAMP(10);
@@ -549,17 +571,17 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
 
       // ================= phase 3: act = SwiGLU(W_gate|up . RMSNorm(h_mid)) - a workgroup owns gate AND up of its 38 features
       __syncthreads();
-      if constexpr (!STREAM) if (hw == 0) xprep_rms(nullptr, a.hmid, ln2v);
+      if constexpr (!STREAM) if (hw == 0) xprep_rms(nullptr, a.hmid, lnw2);
       __syncthreads();
       DL_STAMP(12);
       if constexpr (STREAM) stream_phase(std::integral_constant<int, Gm::B3>{}, std::integral_constant<int, Gm::B4>{});
       __syncthreads();
       DL_STAMP(13);
-      if constexpr (!STREAM) if (ht < Gm::RG) {
-        const float g = rbf(row_sum(ht, std::integral_constant<int, H / 512>{})), up = rbf(row_sum(Gm::RG + ht, std::integral_constant<int, H / 512>{}));
-        dl_st1(a.act + wg * Gm::RG + ht, rbf(rbf(silu_f(g)) * up));
+      if constexpr (!STREAM) if (hw == 0) {
+        const int r = ht < Gm::RG ? ht : 0;
+        const float g = rbf(row_sum(r, std::integral_constant<int, H / 512>{})), up = rbf(row_sum(Gm::RG + r, std::integral_constant<int, H / 512>{}));
+        dl_st_pair(a.act + wg * Gm::RG, ht, Gm::RG, rbf(silu_f(g)) * up);
         dl_stores_done();
-       
       }
       __syncthreads();
       DL_STAMP(14);
@@ -575,13 +597,11 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
       if constexpr (STREAM) stream_phase(std::integral_constant<int, Gm::B4>{}, std::integral_constant<int, Gm::NSLOT>{});
       __syncthreads();
       DL_STAMP(17);
-      if constexpr (!STREAM) if (ht < Gm::R4) {
-        const int n = wg * Gm::R4 + ht;
-        h_own = rbf(rbf(row_sum(ht, std::integral_constant<int, I / 512>{})) + hmid_own);
-        dl_st1(a.hx + n, h_own);
-        if (l == a.nl - 1) a.h[n] = f2bf(h_own);
+      if constexpr (!STREAM) if (hw == 0) {
+        h_own = rbf(rbf(row_sum(ht < Gm::R4 ? ht : 0, std::integral_constant<int, I / 512>{})) + hmid_own);
+        dl_st_pair(a.hx + wg * Gm::R4, ht, Gm::R4, h_own);
+        if (l == a.nl - 1 && ht < Gm::R4) a.h[wg * Gm::R4 + ht] = f2bf(h_own);
         dl_stores_done();
-       
       }
       __syncthreads();
       DL_STAMP(18);
@@ -627,7 +647,7 @@ extern "C" int vq3_qwen_decode_layers_supported(int32_t hidden, int32_t intermed
 }
 
 extern "C" int64_t vq3_qwen_decode_layers_workspace_bytes(void) {
-  return (int64_t)sizeof(float) * (Qwen3_4B::NQKV + Qwen3_4B::KO + 2 * 2560 + 9728);
+  return (int64_t)sizeof(bf16_t) * (Qwen3_4B::NQKV + Qwen3_4B::KO + 2 * 2560 + 9728);
 }
 
 extern "C" int vq3_qwen_decode_layers(const vq3_decode_layers_desc* d, void* stream) {
@@ -644,7 +664,7 @@ extern "C" int vq3_qwen_decode_layers(const vq3_decode_layers_desc* d, void* str
   Args a;
   a.w = reinterpret_cast<const LayerW*>(d->weights);
   a.h = (bf16_t*)d->h;
-  a.qkv = (float*)d->workspace; a.ao = a.qkv + Qwen3_4B::NQKV; a.hmid = a.ao + Qwen3_4B::KO; a.act = a.hmid + 2560; a.hx = a.act + 9728;
+  a.qkv = (bf16_t*)d->workspace; a.ao = a.qkv + Qwen3_4B::NQKV; a.hmid = a.ao + Qwen3_4B::KO; a.act = a.hmid + 2560; a.hx = a.act + 9728;
   a.cs = (const bf16_t*)d->cos; a.sn = (const bf16_t*)d->sin; a.lens = d->lens;
   a.Kc = (bf16_t*)d->Kcache; a.Vc = (bf16_t*)d->Vcache; a.cache_stride = d->cache_layer_stride;
   a.bar = (unsigned*)d->barrier; a.status = (unsigned*)d->status;

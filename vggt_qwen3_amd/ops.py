@@ -743,7 +743,7 @@ def decode_layers_supported(hidden: int, intermediate: int, Hq: int, Hkv: int, h
 
 def decode_layers_workspace(device) -> torch.Tensor:
     """The rows that travel between the persistent decode kernel's workgroups (vq3_qwen_decode_layers_workspace_bytes)."""
-    return torch.zeros(int(_lib.load().vq3_qwen_decode_layers_workspace_bytes()) // 4, device=device, dtype=F32)
+    return torch.zeros(int(_lib.load().vq3_qwen_decode_layers_workspace_bytes()) // 2, device=device, dtype=BF16)
 
 
 def decode_layers(wtab: torch.Tensor, h: torch.Tensor, workspace: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, lens: torch.Tensor,
@@ -756,14 +756,14 @@ def decode_layers(wtab: torch.Tensor, h: torch.Tensor, workspace: torch.Tensor, 
     for t, nm in ((h, "h"), (cos, "cos"), (sin, "sin"), (K, "K"), (V, "V")):
         _req(t, BF16, "decode_layers " + nm)
         assert t.is_contiguous(), nm
-    _req(wtab, torch.int64, "decode_layers wtab"); _req(lens, torch.int32, "decode_layers lens"); _req(workspace, F32, "decode_layers workspace")
+    _req(wtab, torch.int64, "decode_layers wtab"); _req(lens, torch.int32, "decode_layers lens"); _req(workspace, BF16, "decode_layers workspace")
     _req(barrier, torch.int32, "decode_layers barrier"); _req(status, torch.int32, "decode_layers status")
     nl = wtab.shape[0]
     assert wtab.is_contiguous() and wtab.shape[1] == 8 and K.dim() == 5 and K.shape[0] == nl and K.shape[1] == 1 and K.shape == V.shape
     Lmax, D = K.shape[3], K.shape[4]
     assert h.numel() == hidden and K.shape[2] == Hkv and workspace.is_contiguous()
-    assert workspace.numel() * 4 >= int(_lib.load().vq3_qwen_decode_layers_workspace_bytes())
-    assert barrier.numel() >= 1024 and barrier.is_contiguous()
+    assert workspace.numel() * 2 >= int(_lib.load().vq3_qwen_decode_layers_workspace_bytes())
+    assert barrier.numel() >= 1024 and barrier.is_contiguous() and workspace.data_ptr() % 16 == 0
     assert cos.shape[0] >= Lmax and cos.shape[1] == D and sin.shape == cos.shape
     import ctypes as C
     barrier.zero_()
