@@ -109,3 +109,25 @@ def test_gemm_split_plan_host_side():
             per = -(-(K // 64) // sl)
             assert full + rem == tiles and full % 256 == 0 and 2 <= sl <= 4 and rem * sl <= 256
             assert (K // 64) - (sl - 1) * per >= 1 and K // 64 // sl >= 8
+
+
+def test_persistent_decode_kernel_has_no_private_segment(tmp_path):
+    """vq3_qwen_decode_layers is launched once per token: any scratch (a spilled register) makes the runtime set up a private segment for
+    every wave slot at each launch - measured 0.3 ms per token, more than the kernel gains. Read the kernel's
+    metadata out of the object the library was linked from."""
+    import shutil
+    import subprocess
+    obj = ROOT / "vggt_qwen3_amd" / "csrc" / "build" / "decode_layers.o"
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    if not obj.exists() or not (llvm / "clang-offload-bundler").exists():
+        pytest.skip("needs the in-tree build directory and the ROCm LLVM tools")
+    fat, co = tmp_path / "fat.bin", tmp_path / "dl.co"
+    subprocess.run([str(llvm / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(obj)], check=True)
+    subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+    notes = subprocess.run([str(llvm / "llvm-readelf"), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+    kern = [b for b in notes.split(".name:") if "decode_layers_kernel" in b.split("\n")[0]]
+    assert kern, "decode_layers_kernel not found in the code object"
+    for b in kern:
+        seg = [ln for ln in b.split("\n") if ".private_segment_fixed_size:" in ln]
+        assert seg and int(seg[0].split(":")[1]) == 0, seg

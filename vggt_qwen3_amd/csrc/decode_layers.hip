@@ -3,7 +3,7 @@
 // the layer being computed is transformers' Qwen3DecoderLayer, modeling_qwen3.py:49-83, 185-207, 237-330.)
 //
 // Why: with one launch per projection (decode.hip) a layer is six 8-29 us kernels whose 21-100 MB of weights stream in 3-17 us - every
-// kernel pays its launch, first-byte latency, reduction and drain, and the HBM pipe is idle in between (2.96 ms / token = 0.34 of the
+// kernel pays its launch, first-byte latency, reduction and drain, and the HBM pipe is idle in between (2.99 ms / token = 0.34 of the
 // 8 TB/s peak). Here the weight stream never stops:
 //
 //  * 256 workgroups (one per CU, made exclusive by their LDS request) x 12 waves. Waves 0-7 STREAM: a workgroup owns a fixed slab of
@@ -11,19 +11,23 @@
 //    thread's 97 16-byte pieces per layer form one sequence with RING = 20 of them in flight at any time (a ring of registers, static
 //    indices) - ACROSS the phases of a layer and across layers, because weight addresses depend on nothing the token computes. The
 //    phases' synchronisation therefore gates the FMAs, not the loads.
-//  * Waves 8-11 HELP: they wait at the grid barrier, prepare the phase's activation vector in LDS (RMSNorm in registers / the
+//  * Waves 8-11 HELP: they wait at the grid barrier, bring the phase's activation row into LDS (bf16; RMSNorm in registers / the
 //    attention output / the SwiGLU product), and after the streamers' partial sums are in LDS add them per row in a fixed order, apply
-//    the epilogue (residual / SwiGLU) and publish the row values. They hold no weight loads, so the few KB they read do not queue
-//    behind 40 MB of weights. Attention for the new token (q/k RMSNorm + RoPE, cache append, softmax over the cached positions) is
-//    helper work of workgroups 0 .. Hq-1, one head each, in decode.hip's arithmetic order.
-//  * Five grid barriers per layer (q|k|v -> attention -> o -> gate|up -> down): one monotonically increasing counter, arrival =
-//    agent-scope release add by one thread per workgroup, wait = agent-scope polling by one thread + acquire fence in every reader.
+//    the epilogue (residual - kept in a register of the thread that produced it - / SwiGLU) and publish the rows two bf16 at a time.
+//    They hold no weight loads. Attention for the new token (q/k RMSNorm + RoPE, cache append, softmax over the cached positions) is
+//    helper work of workgroups 0 .. Hq-1, one head each, in decode.hip's arithmetic order; the first 128 cached key rows are requested
+//    while q|k|v is still being multiplied.
+//  * Five grid barriers per layer (q|k|v -> attention -> o -> gate|up -> down): 16 counter words 256 bytes apart, arrival = relaxed
+//    agent-scope add once the workgroup's stores are acknowledged, wait = one wave per workgroup reading the 16 words. Rows that cross
+//    workgroups are stored and loaded with agent-scope accesses (no cache-wide write-back / invalidate).
 //    Every wait is BOUNDED: after 2^21 polls the waiter raises the status word, every later wait returns at once, the grid drains and
 //    the host reports the failure (the kernel cannot hang the device when a workgroup was not co-resident).
+//  * No scratch: a private segment makes the runtime set up scratch for every wave slot at each launch (0.3 ms per token, measured) -
+//    hence the two role instantiations of the layer loop, the laundered indices and the norm weights staged through LDS below.
 //
 // Arithmetic is that of decode.hip (bf16 rounding points: normed row, projection outputs before the residual, SwiGLU product,
-// probabilities; fp32 sums), only the ORDER of a dot product's fp32 terms differs (16-lane groups per 1 KiB of a row instead of a wave
-// per row), as it does between any two GEMV kernels.
+// probabilities; fp32 sums), only the ORDER of a dot product's fp32 terms differs (v_dot2c pairs, 16-lane groups per 1 KiB of a row
+// instead of a wave per row), as it does between any two GEMV kernels. Measured: DESIGN.md section 7 (2.99 -> 2.33-2.38 ms / token).
 #include <type_traits>
 #include <utility>
 
@@ -386,6 +390,10 @@ __global__ __launch_bounds__(DL_TS + DL_TH) void decode_layers_kernel(const Args
         });
       };
 
+      // (A phase is four workgroup barriers: "the grid barrier has been passed" - "x is in LDS" - "the partial sums are in LDS" - "the
+      // rows have been stored". Tried: two, with helper wave 0 doing everything between a phase's sums and the next RMSNorm alone and every
+      // helper wave polling the grid barrier itself before a copied x - A/B on one box 2.37-2.38 -> 2.44-2.62 ms / token: four polling
+      // waves per workgroup instead of one cost more than the two barriers.)
       // ================= phase 0: q|k|v = W_qkv . RMSNorm(h)
       DL_STAMP(0);
       if constexpr (!STREAM) if (hw == 0 && l > 0) dl_grid_wait(a.bar, a.status, base, lane);             // every row of h (previous layer's phase 4)
