@@ -2,6 +2,8 @@
 include/vq3_hip.h declares, and the ctypes binding covers exactly that set (no compute calls without a GPU)."""
 import ctypes
 import re
+
+import pytest
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
