@@ -403,15 +403,17 @@ def test_persistent_decode_layer_stage_by_stage(ops):
     assert rel(h, h_out)[0] <= 1.5e-2
 
 
-def test_persistent_decode_generate_matches_full_forward():
+@pytest.mark.parametrize("L", [21, 125, 300, 520])
+def test_persistent_decode_generate_matches_full_forward(L):
     """generate() on the persistent route (B = 1, Qwen3-4B's shape, graph replay): the logits behind each greedy pick equal those of a
-    cache-free forward over prompt + generated tokens within the bf16 tie tolerance - the test the per-projection route passes above."""
+    cache-free forward over prompt + generated tokens within the bf16 tie tolerance - the test the per-projection route passes above.
+    Prompt lengths on both sides of the attention's 128-row chunks: one chunk, the 128 boundary crossed while decoding, three chunks
+    (the double-buffered loop's second trip), five."""
     from vggt_qwen3_amd import ops
     if not ops.decode_layers_supported(2560, 9728, 32, 8, 128, 128):
         pytest.skip("needs an MI355X (256 CUs)")
     tm, cfg = _qwen4b_dims(2)
     torch.manual_seed(7)
-    L = 21
     emb = (torch.randn(1, L, cfg.hidden_size) * 0.5).to(BF16).cuda()
     mask = torch.ones(1, L, dtype=torch.long).cuda()
     out, stats = tm.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=9, use_graph=True, return_stats=True)
