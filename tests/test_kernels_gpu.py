@@ -194,7 +194,7 @@ def test_gemm_whole_rounds_plus_row_tail(ops):
         ops.gemm_force_config(-3)
 
 
-@pytest.mark.parametrize("cfg", [-3, 20, 21, 22, 24, 11, 13, 7, 30])
+@pytest.mark.parametrize("cfg", [-3, 20, 21, 22, 24, 25, 11, 13, 7, 30])
 def test_gemm_layernorm_fold(ops, cfg):
     """LayerNorm folded into the GEMMs either side of it (vq3_gemm_bf16_nt_ln): the producer (residual GEMM) leaves per-row
     (sum, sum of squares) over 128-column groups of what it stored, the consumer reads the RAW rows and applies
@@ -202,7 +202,10 @@ def test_gemm_layernorm_fold(ops, cfg):
     configuration; M with a ragged last tile; GELU on the consumer; statistics also from vq3_rowstats128 and bit-identical twice."""
     try:
         ops.gemm_force_config(cfg)
-        M, C, N2 = (16500 if cfg in (30, 21, 22, 24) else 1029), 1024, (1024 if cfg in (21, 22, 24) else 512)
+        # (cfg 25: 65 x 4 = 260 tiles of 256 x 256 = a round of 256 + 4 tiles cut into two K halves - the reducer runs the folded epilogue)
+        M, C, N2 = (16500 if cfg in (30, 21, 22, 24, 25) else 1029), 1024, (1024 if cfg in (21, 22, 24, 25) else 512)
+        if cfg == 25:
+            assert ops.gemm_split_plan(M, N2, C)[2] == 2
         eps = 1e-5
         h = _rand((M, 256), 0.5, seed=1); Wp = _rand((C, 256), 0.3, seed=2)
         R = _rand((M, C), 1.0, seed=3) + 0.7                      # non-zero row means

@@ -294,6 +294,44 @@ def test_fused_qkv_epilogue_with_row_tail_launch():
         assert torch.equal(a, b), name                   # same arithmetic, same rounding points: bit-identical
 
 
+def test_fused_qkv_epilogue_behind_a_split_last_round():
+    """cfg 25 under the fused q|k|v epilogue (round 4: the reducer of a K-split tile runs the head split + LayerNorm + RoPE on the summed
+    tile): 22 x 12 = 264 tiles of 256 x 256 = one round of 256 CUs + 8 tiles cut into two K halves (K = 1024). Against the unsplit kernel:
+    the same values up to the order of the f32 sum."""
+    from vggt_qwen3_amd import ops
+    torch.manual_seed(3)
+    NH, C, Wp, ps = 16, 1024, 7, 5
+    P = ps + 48 * Wp                                     # 341 tokens per frame
+    G, N = 2, 8 * P
+    T = G * N
+    assert T == 5456 and ops.gemm_split_plan(T, 3 * NH * 64, C) == (256, 8, 2)
+    x = torch.randn(T, C, device="cuda").to(BF16)
+    w = (torch.randn(3 * NH * 64, C, device="cuda") * 0.03).to(BF16)
+    bias = torch.randn(3 * NH * 64, device="cuda") * 0.1
+    qn = (torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1)
+    kn = (torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1)
+    ang = torch.rand(50, 16, device="cuda") * 3.0
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(BF16).contiguous(), emb.sin().to(BF16).contiguous()
+    kw = dict(qn=qn, kn=kn, cos=cos, sin=sin, tokens_per_frame=P, patch_start=ps, Wp=Wp, eps=1e-5)
+    try:
+        ops.gemm_force_config(20)
+        ref = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
+        ops.gemm_force_config(25)
+        got = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
+        got2 = ops.linear_vit_qkv(x, w, bias, N, NH, **kw)
+    finally:
+        ops.gemm_force_config(-3)
+    assert not ops.gemm_split_gave_up()
+    for name, a, b, c in zip("QKV", got, ref, got2):
+        af, bf = a.float(), b.float()
+        assert (af - bf).abs().max() <= 2 ** -6 * bf.abs().max(), name
+        assert ((af - bf).norm() / bf.norm()).item() < 2e-3, name
+        assert torch.equal(a, c), name                   # the partial sums meet in a fixed order: repeatable
+    # the split tiles are the last 8 of the launch's order; every row block was written
+    assert all(torch.isfinite(t.float()).all() for t in got)
+
+
 def test_aggregator_is_batch_invariant():
     """precompute_vision() runs the tower once over several micro-batches' images: every sample must come out as in its own
     micro-batch (frame attention per (sample, view), global attention per sample, GEMM rows independent of M - the tile configuration

@@ -49,7 +49,9 @@ constexpr int HALF = 128 * 128;          // bytes per half-tile (128 rows x 64 k
 // 4 = SwiGLU forward (B = gate|up weight [2 I, K]: a tile multiplies BN/2 gate rows and the SAME BN/2 up rows, see set_offsets).
 // Compiled into ONE kernel they cost the 256 x 256 instantiation (256 VGPRs) 80 spilled registers in every launch's epilogue: the plain
 // fc1 launch (49 392 x 4096 x 1024) took 524 us with them and 443 us without (tools/gemm_stamps.py: "stage C" 13.1 -> 6.6 us per tile).
-// SPLIT (256 x 256, plain epilogue only): the launch's last, partly filled round of tiles is cut along K over the CUs it would leave idle
+// SPLIT (256 x 256; plain, LayerNorm-fold and fused q|k|v epilogues - the reducer runs them on the summed tile; on the tower's own shapes,
+// 61740 x 4096 / 3072 x 1024 = 15 rounds + 32 tiles / 11 rounds + 88, it measures 598 against 585 us and 465 against 439 - tools/
+// bench_tower_split.py - so the shipped table keeps cfg 20 there): the launch's last, partly filled round of tiles is cut along K over the CUs it would leave idle
 // (GemmParams: sk_*). 9600 x 2560 outputs - every o / down projection and two of the four dgrads of a pass of 8 micro-batches - are 380
 // tiles = 1.48 rounds of 256 CUs: 124 tiles x 2 K halves run as ONE half-length round instead of a full one.
 // F8 (256 x 256, EK 0 / 2 / 4; config C5): A and B are OCP e4m3 bytes, a K tile is 128 elements - the same 128-byte rows, the same DMA
@@ -709,7 +711,7 @@ bool sk_workspace(hipStream_t s, float** ws, unsigned** cnt) {
 // The split applies when the tile grid leaves a last round at most half full: R = tiles % CUs (or all tiles, when there are fewer than
 // CUs) tiles are cut into S = min(CUs / R, 4) K slices of at least 8 K tiles each. Returns S (0: does not apply).
 int sk_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem, int ktile = BK6) {
-  if (nbatch != 1 || p.out_f32 || p.epi != 0 || p.ln_in) return 0;
+  if (nbatch != 1 || p.out_f32 || (p.epi != 0 && p.epi != 1)) return 0;      // plain, LayerNorm-fold and fused q|k|v epilogues (the reducer runs them on the summed tile)
   static int off = -1;
   if (off < 0) { const char* e = getenv("VQ3_GEMM_SPLIT"); off = (e && atoi(e) == 0) ? 1 : 0; }      // VQ3_GEMM_SPLIT=0: A/B runs
   if (off) return 0;
@@ -743,6 +745,10 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream, bool split = false)
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<AH, BH, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if constexpr (AH + BH == 4)
       if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<2, 2, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if constexpr (AH + BH == 4)
+      if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<2, 2, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if constexpr (AH + BH == 4)
+      if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)gemm_v6_kernel<2, 2, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       vq3_set_error("gemm v6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
       return 2;
@@ -777,7 +783,10 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream, bool split = false)
       const int sl = sk_plan(p, nbatch, ncu, &full, &rem);
       if (sl < 2 || !sk_workspace(stream, &p.sk_ws, &p.sk_cnt)) return -1;
       p.sk_full = full; p.sk_rem = rem; p.sk_s = sl;
-      hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 0, true>), dim3(full + ((rem + 7) & ~7) * sl, 1, 1), dim3(512), SMEM, stream, p);
+      const dim3 sgrid(full + ((rem + 7) & ~7) * sl, 1, 1);
+      if (p.epi == 1) hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 1, true>), sgrid, dim3(512), SMEM, stream, p);
+      else if (p.ln_in) hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 3, true>), sgrid, dim3(512), SMEM, stream, p);
+      else hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 0, true>), sgrid, dim3(512), SMEM, stream, p);
       return 0;
     }
   }
