@@ -128,7 +128,10 @@ __device__ __forceinline__ void dl_grid_wait(unsigned* bar, unsigned* status, un
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= target) break;
-    __builtin_amdgcn_s_sleep(1);
+#ifndef VQ3_DL_SLEEP
+#define VQ3_DL_SLEEP 1
+#endif
+    if (VQ3_DL_SLEEP > 0) __builtin_amdgcn_s_sleep(VQ3_DL_SLEEP);
     ++n;
     if ((n & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
     if (n > DL_POLLS) {
