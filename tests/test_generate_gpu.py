@@ -424,3 +424,28 @@ def test_persistent_decode_generate_matches_full_forward(L):
     for t in range(9):
         row = logits[:, L - 1 + t]
         assert ((row.max(-1).values - row.gather(1, out[:, t][:, None]).squeeze(1)) < TIE_TOL).all(), t
+
+
+def test_persistent_decode_reports_a_full_cache(ops):
+    """The kernel's status word: a launch at lens[0] == Lmax appends nothing, computes no attention and raises bit 2, which
+    ops.decode_layers_status turns into an exception when the caller next synchronises (generate() checks it after its first step and
+    every check_every steps); the word is sticky."""
+    from vggt_qwen3_amd import generate as G
+    if not ops.decode_layers_supported(2560, 9728, 32, 8, 128, 128):
+        pytest.skip("needs an MI355X (256 CUs)")
+    tm, cfg = _qwen4b_dims(1)
+    st = G.DecodeState(tm, 1, 64, 4)
+    ps = st.persistent
+    cos, sin = tm.rope(64)
+    K0 = st.K.clone()
+    st.lens.fill_(64)
+    st.next_ids.fill_(7)
+    h = ops.gather_rows(tm._w["embed"], st.next_ids, 1, 1, out=ps["h"])
+    ops.decode_layers(ps["wtab"], h, ps["workspace"], cos, sin, st.lens, st.K, st.V, ps["barrier"], ps["status"], cfg.hidden_size,
+                      cfg.intermediate_size, tm.Hq, tm.Hkv, cfg.rms_norm_eps, tm.D ** -0.5)
+    with pytest.raises(RuntimeError, match="cache full"):
+        ops.decode_layers_status(ps["status"])
+    assert torch.equal(st.K, K0)                                   # nothing was written past the cache
+    assert int(ps["barrier"].sum().item()) == 4 * 256 + 32         # the grid still drained: every phase arrived (the attention phase without computing)
+    with pytest.raises(RuntimeError, match="cache full"):
+        ops.decode_layers_status(ps["status"])

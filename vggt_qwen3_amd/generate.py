@@ -204,6 +204,8 @@ def generate(tm, inputs_embeds: Optional[torch.Tensor] = None, attention_mask: O
             _decode_step(tm, st, cos, sin, opts)
         torch.cuda.current_stream().wait_stream(side)
         done_steps += 1
+        if st.persistent is not None:
+            ops.decode_layers_status(st.persistent["status"])   # a launch whose workgroups were not co-resident is reported now, not after N slow tokens
         if max_new_tokens > 2:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -215,6 +217,8 @@ def generate(tm, inputs_embeds: Optional[torch.Tensor] = None, attention_mask: O
             graph.replay()
         else:
             _decode_step(tm, st, cos, sin, opts)
+            if st.persistent is not None and done_steps % check_every == 0:
+                ops.decode_layers_status(st.persistent["status"])
         done_steps += 1
     if st.persistent is not None:
         ops.decode_layers_status(st.persistent["status"])
