@@ -38,4 +38,11 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4w -o w -- python3 $C4 > $
 python tools/summarize_pmc.py $O/c4f/f_counter_collection.csv $O/c4w/w_counter_collection.csv $O/out/r4_c4_pmc "$COMMIT" "rocprofv3 --pmc <counter> -- python3 $C4" > /dev/null && echo c4 traffic ok
 rm -rf $O/c4f $O/c4w
 fi
+# decode: the persistent layer-stack kernel against the per-projection launches, kernel stats, bytes per launch
+python tools/bench_decode.py --new 64 2>/dev/null | tail -1 > $O/out/r4_decode_bench.jsonl && VQ3_DECODE_PERSISTENT=0 python tools/bench_decode.py --new 64 2>/dev/null | tail -1 >> $O/out/r4_decode_bench.jsonl && echo decode bench ok
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/dec -o dec -- python3 tools/bench_decode.py --new 64 > $O/dec.log 2>&1 && cp $O/dec/dec_kernel_stats.csv $O/out/r4_decode_kernel_stats.csv && echo decode stats ok
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/decf -o f -- python3 tools/bench_decode.py --new 16 > $O/decf.log 2>&1 && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/decw -o w -- python3 tools/bench_decode.py --new 16 > $O/decw.log 2>&1 && python tools/summarize_decode_pmc.py $O/decf/f_counter_collection.csv $O/decw/w_counter_collection.csv $O/out/r4_decode_pmc_traffic.json > /dev/null && echo decode traffic ok
+rm -rf $O/dec $O/decf $O/decw
+# (r4_decode_layer_stamps.txt needs the diagnostic build: make -C vggt_qwen3_amd/csrc EXTRA=-DVQ3_DL_STAMPS after touching decode_layers.hip,
+#  then python tools/diag/decode_layers_stamps.py 36)
 ls -la $O/out
