@@ -10,9 +10,11 @@ One step = one micro-batch of B=6 synthetic samples per GPU through the whole ho
 RCCL, fused AdamW with fp32 master weights, refresh of the transposed weight copies. The timed window is whole
 accumulation cycles: grad_accum defaults to min(32, --steps) (the reference's stage-1 schedule is 32), so every
 window contains exactly steps/grad_accum optimiser steps + all-reduces and never zero; --grad-accum 1 puts them in
-every step. The trainer runs 8 consecutive micro-batches of a window as ONE forward/backward pass over their 48 samples
-(each micro-batch's loss normalised by its own labelled rows - the reference's arithmetic; tests/test_trainer_gpu.py), so a
-window of 32 steps is 4 passes; steps and ms_per_step still count micro-batches. Weights are random-init at the exact
+every step. The trainer runs consecutive micro-batches of a window as ONE forward/backward pass (Stage1Trainer.pass_size():
+10 micro-batches = 60 samples per pass at the default text_group, so the driver's 20-step window is 2 passes and the reference's
+window of 32 is cut 8 + 8 + 8 + 8; each micro-batch's loss is normalised by its own labelled rows - the reference's arithmetic,
+tests/test_trainer_gpu.py); steps and ms_per_step still count micro-batches. The line's config.micro_batches_per_pass says what ran.
+`python bench.py --gpus N` without WORLD_SIZE in the environment starts its N ranks itself (self_launch). Weights are random-init at the exact
 Qwen3-4B / VGGT-1B / Perceiver shapes, inputs synthetic and already resident in HBM. Prints one JSON line on rank 0.
 """
 from __future__ import annotations
@@ -166,6 +168,24 @@ def cpu_baseline(model, batch, L):
                        % (NL, L, {k: round(v, 3) for k, v in t_all.items()}))}
 
 
+def self_launch(n: int) -> int:
+    """Runs this very command line under torch.distributed.run with n local ranks (rendezvous on 127.0.0.1, a free port) as a child
+    process and returns its exit code. Replaces what the reference gets from `accelerate launch --config_file accelerate_8gpu.yaml`
+    (/root/reference/src/train/train_sft.py:119-133, configs/accelerate_8gpu.yaml)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE in the environment: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +218,13 @@ def main():
     ap.add_argument("--layers", type=int, default=36, help="debug only; anything but 36 marks the line invalid")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, the way the driver's launcher does
+        # (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`).
+        # This process has not touched the GPU (nothing before this line makes a HIP call) and never does: it waits for the
+        # launcher - a CHILD process, never an exec - and leaves with its exit code. Rank 0's JSON line goes through on stdout.
+        return self_launch(args.gpus)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -216,7 +243,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment (launch with --nproc-per-node {args.gpus}, "
+                         "or unset WORLD_SIZE and let bench.py start its ranks itself)")
 
     from vggt_qwen3_amd import ops
     from vggt_qwen3_amd.perceiver import PerceiverConfig
@@ -605,4 +634,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -490,10 +490,16 @@ int vq3_gemm_autotune_hold(int32_t on);
  * K ranges run by rem * slices workgroups: all but the last slice of a tile leave f32 partial tiles in a per-stream workspace (allocated on
  * first use outside graph capture) and count themselves in, the last slice adds them and runs the epilogue. No counterpart in the reference
  * (cuBLAS's stream-K is its own). vq3_gemm_split_plan is host-only (no launch): writes the plan, *slices = 0 where the split does not apply.
- * vq3_gemm_split_status synchronises `stream` and writes 1 to *gave_up if a bounded wait of a split launch on it ever expired (a broken
- * launch; results of that launch are then incomplete), else 0. */
+ * A reducer whose bounded wait expires (a broken launch; its output tile is then incomplete) sets ONE STICKY error word per process,
+ * kept in host-mapped memory and never touched by the per-launch memset of the arrival counts: it stays set until it is read with clear.
+ * vq3_gemm_split_poll reads it from the host without synchronising anything (1 = a split launch COMPLETED so far on any stream gave up since
+ * the last clearing read; `clear` != 0 resets it) - Stage1Trainer polls it once per optimiser step and raises. vq3_gemm_split_status
+ * synchronises `stream` first, then reads and clears. vq3_gemm_split_debug_spin_bound (tests only) sets the reducer's wait bound in polls
+ * (0 = the production bound, 1 << 23) so that the give-up path can be walked on a healthy device. */
 int vq3_gemm_split_plan(int32_t M, int32_t N, int32_t K, int32_t ncu, int32_t* full_out, int32_t* rem_out, int32_t* slices_out);
 int vq3_gemm_split_status(void* stream, int32_t* gave_up);
+int vq3_gemm_split_poll(int32_t* gave_up, int32_t clear);
+int vq3_gemm_split_debug_spin_bound(int64_t polls);
 
 #ifdef __cplusplus
 }

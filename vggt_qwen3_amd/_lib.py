@@ -134,6 +134,8 @@ SIGNATURES = {
     "vq3_gemm_autotune_hold": [i32],
     "vq3_gemm_split_plan": [i32, i32, i32, i32, c_p, c_p, c_p],
     "vq3_gemm_split_status": [c_p, c_p],
+    "vq3_gemm_split_poll": [c_p, i32],
+    "vq3_gemm_split_debug_spin_bound": [i64],
     "vq3_pack_tokens": [c_p, c_p, c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p, c_p],
 }
 _RESTYPES = {"vq3_last_error": C.c_char_p, "vq3_target_arch": C.c_char_p, "vq3_qwen_decode_layers_workspace_bytes": i64}

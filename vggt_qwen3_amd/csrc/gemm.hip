@@ -471,7 +471,7 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
   p.stamps = nullptr;
   p.nbw = 1;
   p.stagger = 0;
-  p.sk_full = p.sk_rem = p.sk_s = 0; p.sk_ws = nullptr; p.sk_cnt = nullptr; p.f8_rs = p.f8_cs = nullptr;
+  p.sk_full = p.sk_rem = p.sk_s = 0; p.sk_ws = nullptr; p.sk_cnt = nullptr; p.sk_err = nullptr; p.sk_spin = 1u << 23; p.f8_rs = p.f8_cs = nullptr;
   if (ve) {
     VQ3_CHECK_ARG(ve->Q && ve->K && ve->V, "gemm_vit_qkv: null output pointer");
     VQ3_CHECK_ARG(!d->transA && !d->transB && d->K % BK == 0 && !d->out_f32 && !d->accumulate && !d->R && !d->colscale && d->act == 0 &&
@@ -728,8 +728,20 @@ extern "C" int vq3_gemm_split_plan(int32_t M, int32_t N, int32_t K, int32_t ncu,
 extern "C" int vq3_gemm_split_status(void* stream, int32_t* gave_up) {
   VQ3_CHECK_ARG(gave_up != nullptr, "gemm_split_status: null output");
   const int r = gemm_split_gave_up((hipStream_t)stream);
-  VQ3_CHECK_ARG(r != -2, "gemm_split_status: could not read the stream's workspace");
+  VQ3_CHECK_ARG(r != -2, "gemm_split_status: could not synchronise the stream");
   *gave_up = r > 0 ? 1 : 0;
+  return 0;
+}
+
+extern "C" int vq3_gemm_split_debug_spin_bound(int64_t polls) {
+  VQ3_CHECK_ARG(polls >= 0 && polls <= (1ll << 31), "gemm_split_debug_spin_bound: polls out of range");
+  gemm_split_set_spin_bound(polls ? (unsigned)polls : (1u << 23));
+  return 0;
+}
+
+extern "C" int vq3_gemm_split_poll(int32_t* gave_up, int32_t clear) {
+  VQ3_CHECK_ARG(gave_up != nullptr, "gemm_split_poll: null output");
+  *gave_up = gemm_split_poll(clear != 0) > 0 ? 1 : 0;
   return 0;
 }
 

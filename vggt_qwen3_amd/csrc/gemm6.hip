@@ -494,8 +494,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
         unsigned spins = 0;
         while (__hip_atomic_load(p.sk_cnt + sk_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.sk_s - 1)) {
           __builtin_amdgcn_s_sleep(16);
-          if (++spins > (1u << 23)) {
-            __hip_atomic_store(p.sk_cnt + SK_MAX_TILES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > p.sk_spin) {
+            __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // sticky, host-visible
             break;
           }
         }
@@ -684,27 +684,40 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
 struct SkWs { float* ws = nullptr; unsigned* cnt = nullptr; };
 std::mutex g_sk_mutex;
 std::map<hipStream_t, SkWs> g_sk;
+// One error word per process in host-mapped pinned memory: a reducer whose bounded wait expired stores 1 there (system scope) and the
+// host reads it WITHOUT synchronising anything. It is never part of the per-launch memset: a give-up inside a training step stays
+// visible until somebody reads it with clear (gemm_split_poll(true) / vq3_gemm_split_status) - the trainer does, once per optimiser step.
+unsigned* g_sk_err = nullptr;
+unsigned g_sk_spin = 1u << 23;
 constexpr size_t SK_WS_BYTES = (size_t)192 * 256 * 256 * 4;          // rem * (slices - 1) <= 192 partial tiles (48 MiB)
-constexpr size_t SK_CNT_BYTES = (SK_MAX_TILES + 4) * sizeof(unsigned);
-bool sk_workspace(hipStream_t s, float** ws, unsigned** cnt) {
+constexpr size_t SK_CNT_BYTES = SK_MAX_TILES * sizeof(unsigned);
+bool sk_workspace(hipStream_t s, float** ws, unsigned** cnt, unsigned** err, unsigned* spin) {
   std::lock_guard<std::mutex> lock(g_sk_mutex);
   SkWs& w = g_sk[s];
   if (!w.ws) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+    if (!g_sk_err) {
+      void* h = nullptr;
+      if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+      g_sk_err = (unsigned*)h;
+      *(volatile unsigned*)g_sk_err = 0u;
+    }
     if (hipMalloc(&w.ws, SK_WS_BYTES) != hipSuccess || hipMalloc(&w.cnt, SK_CNT_BYTES) != hipSuccess) {
       (void)hipGetLastError();
+      if (getenv("VQ3_GEMM_AUTOTUNE_LOG")) fprintf(stderr, "[vq3 gemm] split-K workspace allocation failed: cfg 25 downgraded to cfg 20 on this stream\n");
       w.ws = nullptr;
       return false;
     }
   }
-  // counts (and the error word) are zeroed on the caller's stream before every launch that uses them (a memset node when captured)
+  // the arrival counts are zeroed on the caller's stream before every launch that uses them (a memset node when captured); the error
+  // word is NOT (it is sticky)
   static_assert(SK_CNT_BYTES % 16 == 0, "count block: multiple of 16 bytes");
   if (hipMemsetAsync(w.cnt, 0, SK_CNT_BYTES, s) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }
-  *ws = w.ws; *cnt = w.cnt;
+  *ws = w.ws; *cnt = w.cnt; *err = g_sk_err; *spin = g_sk_spin;
   return true;
 }
 
@@ -781,7 +794,7 @@ int launch_v6(GemmParams& p, int nbatch, hipStream_t stream, bool split = false)
       if (!host_staged_ok(p)) return -1;
       int full = 0, rem = 0;
       const int sl = sk_plan(p, nbatch, ncu, &full, &rem);
-      if (sl < 2 || !sk_workspace(stream, &p.sk_ws, &p.sk_cnt)) return -1;
+      if (sl < 2 || !sk_workspace(stream, &p.sk_ws, &p.sk_cnt, &p.sk_err, &p.sk_spin)) return -1;
       p.sk_full = full; p.sk_rem = rem; p.sk_s = sl;
       const dim3 sgrid(full + ((rem + 7) & ~7) * sl, 1, 1);
       if (p.epi == 1) hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 1, true>), sgrid, dim3(512), SMEM, stream, p);
@@ -846,7 +859,7 @@ int launch_gemm_v6_f8(GemmParams& p, hipStream_t stream) {
   else {
     int full = 0, rem = 0;
     const int sl = sk_plan(p, 1, ncu, &full, &rem, 128);
-    if (sl >= 2 && sk_workspace(stream, &p.sk_ws, &p.sk_cnt)) {
+    if (sl >= 2 && sk_workspace(stream, &p.sk_ws, &p.sk_cnt, &p.sk_err, &p.sk_spin)) {
       p.sk_full = full; p.sk_rem = rem; p.sk_s = sl;
       hipLaunchKernelGGL((gemm_v6_kernel<2, 2, false, 0, true, true>), dim3(full + ((rem + 7) & ~7) * sl, 1, 1), dim3(512), SMEM, stream, p);
     } else {
@@ -893,20 +906,25 @@ int launch_gemm_v6_km(GemmParams& p, int nbatch, hipStream_t stream, bool split)
 }
 
 int gemm_split_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem) { return sk_plan(p, nbatch, ncu, full, rem); }
+// Host read of the sticky error word: no synchronisation (it says what the launches COMPLETED so far reported). clear: reset it.
+int gemm_split_poll(bool clear) {
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  if (!g_sk_err) return 0;
+  const unsigned v = __atomic_load_n(g_sk_err, __ATOMIC_ACQUIRE);
+  if (v && clear) __atomic_store_n(g_sk_err, 0u, __ATOMIC_RELEASE);
+  return v ? 1 : 0;
+}
+void gemm_split_set_spin_bound(unsigned polls) {
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  g_sk_spin = polls;
+}
+// Synchronises `stream`, then reads AND clears the word: 1 = some split launch of this process (any stream) gave up since the last read.
 int gemm_split_gave_up(hipStream_t stream) {
-  unsigned* cnt = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(g_sk_mutex);
-    auto it = g_sk.find(stream);
-    if (it == g_sk.end() || !it->second.cnt) return -1;
-    cnt = it->second.cnt;
-  }
-  unsigned v = 0;
-  if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(&v, cnt + SK_MAX_TILES, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+  if (hipStreamSynchronize(stream) != hipSuccess) {
     (void)hipGetLastError();
     return -2;
   }
-  return v ? 1 : 0;
+  return gemm_split_poll(true);
 }
 
 // shape: 0 = 256 x 256, 1 = 256 x 128, 2 = 128 x 256, 3 = 256 x 256 with the last round split along K (-1 where that does not apply)

@@ -60,11 +60,13 @@ struct GemmParams {
   // sk_full + s * roundup8(sk_rem) + j multiplies K slice s (of sk_s) of tile sk_full + j; slices 0 .. sk_s - 2 leave their f32 accumulators in sk_ws
   // and count themselves in sk_cnt[j], slice sk_s - 1 (dispatched last) waits for that count, adds them and runs the epilogue. sk_s <= 1: off
   int sk_full, sk_rem, sk_s;
+  unsigned sk_spin;      // bound of the reducer's wait in polls (1 << 23 in production; tests shrink it to walk the give-up path)
   // e4m3 operands (gemm6.hip F8 instantiations): fp32 scale per A row (token) and per B row (output channel); null = 1
   const float* f8_rs;
   const float* f8_cs;
   float* sk_ws;
-  unsigned* sk_cnt;      // [sk_rem] arrival counts + one error word at [SK_MAX_TILES] (a bounded wait that gave up), zeroed per launch
+  unsigned* sk_cnt;      // [sk_rem] arrival counts, zeroed per launch
+  unsigned* sk_err;      // STICKY error word (host-mapped, one per process): set when a bounded wait gave up; cleared only when read
 };
 constexpr int SK_MAX_TILES = 128;
 
@@ -755,6 +757,8 @@ int launch_gemm_v6_km(GemmParams& p, int nbatch, hipStream_t stream, bool split)
 // host side of cfg 25 (gemm6.hip): the split plan, and the error word of the stream's workspace (-1: no split launch ever ran on it)
 int gemm_split_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem);
 int gemm_split_gave_up(hipStream_t stream);
+int gemm_split_poll(bool clear);
+void gemm_split_set_spin_bound(unsigned polls);
 // v7 (256x128 tile, four waves, two workgroups per CU: a tile's epilogue runs under the co-resident workgroup's main loop), gemm7.hip.
 // Returns -1 (nothing launched) when the problem is outside its contract: the caller picks another kernel.
 int launch_gemm_v7(GemmParams& p, int nbatch, hipStream_t stream);

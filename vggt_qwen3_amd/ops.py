@@ -958,11 +958,26 @@ def gemm_split_plan(M: int, N: int, K: int, ncu: int = 256):
 
 
 def gemm_split_gave_up() -> bool:
-    """True if a bounded wait of a split GEMM launch on the current stream ever expired (synchronises the stream)."""
+    """Synchronises the current stream, then reads AND clears the process-wide sticky error word of the split GEMM launches: True if a
+    reducer's bounded wait expired (on any stream) since the last clearing read - that launch's output is incomplete."""
     import ctypes as C
     flag = C.c_int32(0)
     check(_lib.load().vq3_gemm_split_status(_stream(), C.addressof(flag)), "vq3_gemm_split_status")
     return bool(flag.value)
+
+
+def gemm_split_poll(clear: bool = True) -> bool:
+    """The same word read from the host with NO synchronisation (it lives in host-mapped memory): what the launches completed so far
+    have reported. Cheap enough for once per optimiser step (Stage1Trainer.check_kernels)."""
+    import ctypes as C
+    flag = C.c_int32(0)
+    check(_lib.load().vq3_gemm_split_poll(C.addressof(flag), 1 if clear else 0), "vq3_gemm_split_poll")
+    return bool(flag.value)
+
+
+def gemm_split_debug_spin_bound(polls: int = 0) -> None:
+    """Tests only: bound of the split reducer's wait in polls (0 = production, 1 << 23)."""
+    check(_lib.load().vq3_gemm_split_debug_spin_bound(int(polls)), "vq3_gemm_split_debug_spin_bound")
 
 
 def gemm_force_config(cfg: int = -3) -> None:

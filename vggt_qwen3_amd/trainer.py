@@ -361,8 +361,17 @@ class Stage1Trainer:
             torch.cuda.current_stream().wait_event(ev)
             self.model._weights_gate = None
 
+    def check_kernels(self) -> None:
+        """Raises if a split-K GEMM reducer gave up its bounded wait in any launch completed so far (its output tile - an activation or a
+        gradient - is then incomplete: training on would be silently wrong). A host read of one word in host-mapped memory, no
+        synchronisation: called once per optimiser step and at the end of fit()."""
+        if ops.gemm_split_poll(clear=True):
+            raise RuntimeError("vq3: a split-K GEMM launch gave up waiting for its partial tiles (broken launch); activations / gradients "
+                               f"of the window ending at micro-batch {self.micro} are incomplete - the optimiser step was NOT applied")
+
     def _optimizer_step_impl(self):
         tm = self.tm
+        self.check_kernels()                 # before the weights are touched
         if self.dist_on:
             for g0 in sorted(self.buckets, reverse=True):     # buckets the backward did not reach (no hook fired)
                 if g0 not in self._fired:
@@ -482,6 +491,8 @@ class Stage1Trainer:
             if save_every_steps and output_dir is not None and self.micro % save_every_steps == 0:
                 self._save(Path(output_dir) / f"step_{self.micro}", rank, checkpoint)
         self.sync_optimizer()
+        torch.cuda.current_stream().synchronize()
+        self.check_kernels()                 # the last window's launches have completed
         self.overlap_optimizer = overlap0
         if output_dir is not None:
             self._save(Path(output_dir), rank, checkpoint)
