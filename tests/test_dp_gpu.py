@@ -245,3 +245,99 @@ def test_bench_one_rank_over_rccl_sharded_mode():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["dp_mode"] == "sharded" and d["loss"] == d["loss"]
     c = d["comm"]
     assert c and c["allreduce_ms_per_opt_step"] > 0 and c["allreduce_bytes_per_opt_step"] > 0 and c["collectives_per_opt_step"] >= 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The reference's OWN multi-GPU route (train_sft.py:119-133,165-170,217): model wrapped by accelerator.prepare in
+# DistributedDataParallel(find_unused_parameters=True), loss.backward() per micro-batch. The text parameters never pass through
+# autograd here, so DDP cannot reduce them: VGGTQwen3VLM reduces the flat gradient itself (autograd_dp = "allreduce", the default)
+# or raises ("raise") - never silently divergent replicas.
+def _ddp_route_worker(rank, world, port, outdir, wrap):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.test_parity_gpu import _build_vlm
+        z = load("vlm_tiny.npz")
+        model = _build_vlm(z, meta(z)).train()
+        tm = model.text_model
+        bs = _batches(z, rank)[:2]                            # (rank 1's second micro-batch has no labelled token at all)
+        kw = lambda b: dict(images=b["pixel_values"], geom_token=b["geom_token"], input_ids=b["input_ids"],
+                            attention_mask=b["attention_mask"], labels=b["labels"])
+        # this rank's own gradient of the two micro-batches, no exchange: the reference point
+        model.autograd_dp = "local"
+        model.zero_grad(set_to_none=True)
+        for b in bs:
+            model(**kw(b)).backward()          # (a micro-batch without labels: NaN loss like the reference, ZERO gradient - vlm._backward_text)
+        local = tm.flat_g.float().cpu().clone()
+        geom_local = [p.grad.float().cpu().clone() for p in model.geom_head.parameters()]
+        # the guarded mode
+        model.autograd_dp = "raise"
+        model.zero_grad(set_to_none=True)
+        with pytest.raises(RuntimeError, match="Stage1Trainer"):
+            model(**kw(bs[0])).backward()
+        # the reducing mode, plain or under the reference's DDP wrapper
+        model.autograd_dp = "allreduce"
+        model.zero_grad(set_to_none=True)
+        net = model
+        if wrap:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            net = DDP(model, find_unused_parameters=True)
+        for b in bs:
+            net(**kw(b)).backward()
+        torch.cuda.synchronize()
+        torch.save({"local": local, "reduced": tm.flat_g.float().cpu(), "geom_local": geom_local,
+                    "geom_reduced": [p.grad.float().cpu() for p in model.geom_head.parameters()],
+                    "grad_is_view": next(iter(tm.parameters())).grad.data_ptr() == tm.grad_views["model.embed_tokens.weight"].data_ptr()},
+                   os.path.join(outdir, f"ddp{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wrap", [False, True])
+def test_autograd_route_reduces_text_gradients_across_ranks(tmp_path, wrap):
+    port = _free_port()
+    mp.start_processes(_ddp_route_worker, args=(2, port, str(tmp_path), wrap), nprocs=2, join=True, start_method="spawn")
+    r = [torch.load(tmp_path / f"ddp{k}.pt") for k in range(2)]
+    want = 0.5 * (r[0]["local"] + r[1]["local"])              # DDP's average of the ranks' window gradients
+    assert want.abs().max() > 0
+    for k in range(2):
+        assert r[k]["grad_is_view"]
+        e = ((r[k]["reduced"] - want).norm() / want.norm()).item()
+        assert e < 2e-2, f"rank {k}: reduced text gradient differs from the average of the ranks' gradients: {e}"
+    assert torch.equal(r[0]["reduced"], r[1]["reduced"])      # replicas hold the same gradient, bit for bit
+    assert (r[0]["local"] - r[1]["local"]).abs().max() > 0    # (and the ranks' own gradients did differ)
+    if wrap:                                                   # geom_head: ordinary autograd leaves - DDP averaged them
+        for a0, a1, g0, g1 in zip(r[0]["geom_local"], r[1]["geom_local"], r[0]["geom_reduced"], r[1]["geom_reduced"]):
+            assert torch.allclose(g0, g1, rtol=1e-5, atol=1e-7)
+            assert torch.allclose(g0, 0.5 * (a0 + a1), rtol=2e-2, atol=1e-4 * float((a0.abs().max() + a1.abs().max())))
+
+
+def test_bench_self_launch_two_ranks_gloo_on_one_gpu():
+    """plain `python3 bench.py --gpus 2` - no WORLD_SIZE / RANK in the environment, the way the driver calls
+    `--gpus 1` - starts its two ranks itself (torch.distributed.run as a child process, before anything touches the GPU) and rank 0's
+    one JSON line comes through with n_gpus = 2 and the communication fields filled. gloo rehearsal backend: both ranks share the
+    box's one card. 2 Qwen3 layers: plumbing, the line says valid: false."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, VQ3_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", VQ3_GEMM_TUNE_WS_MB="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VQ3_GEMM_TUNE_FILE", "VQ3_FORCE_DIST"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--layers", "2",
+           "--no-trim-variant", "--no-cpu-baseline", "--no-variants"]
+    pr = subprocess.run(cmd, env=env, cwd=str(root), capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    assert "launching 2 ranks" in pr.stderr
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 12 and d["value"] > 0
+    assert d["comm"] and d["comm"]["allreduce_ms_per_opt_step"] > 0 and d["comm"]["bus_gb_per_s"] > 0
+    # a WORLD_SIZE that contradicts --gpus is a clear error, not an AssertionError deep in the run
+    bad = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         cwd=str(root), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr and "Traceback" not in bad.stderr

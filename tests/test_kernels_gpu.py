@@ -162,6 +162,40 @@ def test_gemm_last_round_split(ops, M, N, K):
         ops.gemm_force_config(-3)
 
 
+def test_gemm_split_error_word_is_sticky(ops):
+    """a split reducer whose bounded wait expires must leave a signal that SURVIVES later launches. The wait bound is
+    shrunk to 1 poll (vq3_gemm_split_debug_spin_bound; on a healthy device the partial tiles of a 76-K-tile slice cannot have arrived by
+    then), so the give-up path really runs: the process-wide error word - host-mapped, outside the per-launch memset of the arrival counts -
+    is set, stays set across healthy split launches on this and on another stream, is visible to a host poll WITHOUT synchronisation once
+    the launch completed, and clears only when read with clear. Stage1Trainer.check_kernels raises on it."""
+    M, N, K = 1200, 2560, 9728
+    assert ops.gemm_split_plan(M, N, K)[2] >= 2
+    A = _rand((M, K), 0.5, seed=3); W = _rand((N, K), 0.5, seed=4)
+    try:
+        ops.gemm_force_config(25)
+        good = ops.linear(A, W)
+        assert not ops.gemm_split_gave_up()
+        ops.gemm_split_debug_spin_bound(1)
+        ops.linear(A, W)                                       # reducers give up at once (the result of this launch is incomplete)
+        torch.cuda.synchronize()
+        ops.gemm_split_debug_spin_bound(0)
+        assert ops.gemm_split_poll(clear=False)                # host read, no synchronisation needed any more
+        again = ops.linear(A, W)                               # a healthy launch: zeroes its arrival counts, NOT the error word
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            ops.linear(A, W)                                   # another stream's workspace: same word
+        torch.cuda.synchronize()
+        assert torch.equal(again, good)
+        assert ops.gemm_split_poll(clear=False)                # still there
+        from vggt_qwen3_amd.trainer import Stage1Trainer
+        with pytest.raises(RuntimeError, match="split-K"):
+            Stage1Trainer.check_kernels(type("T", (), {"micro": 7})())
+        assert not ops.gemm_split_poll(clear=False) and not ops.gemm_split_gave_up()      # read with clear: gone
+    finally:
+        ops.gemm_split_debug_spin_bound(0)
+        ops.gemm_force_config(-3)
+
+
 def test_gemm_whole_rounds_plus_row_tail(ops):
     """cfg 30 (gemm.hip: launch_split_rows): the 256 x 256 kernel on the row tiles that fill whole rounds of the chip + a second launch
     for the remaining rows - here 65 x 4 = 260 tiles = one round of 256 CUs + 4: rows 0..16383 and a 116-row tail. Same contract as

@@ -113,6 +113,9 @@ class _TextLossFn(torch.autograd.Function):
         model, st = ctx.model, ctx.state
         tm = model.text_model
         gscale = float(grad_out.item())
+        world, group = model._autograd_dp_world()
+        if world > 1:
+            return _TextLossFn._backward_multi_rank(ctx, model, st, gscale, world, group)
         # The parameters' .grad ARE views of the flat gradient buffer (no 8 GB copy per backward): autograd gets None for
         # them and the HIP backward accumulates in place, exactly when .grad is still our view from an earlier backward
         # (optimizer.zero_grad(set_to_none=True) drops the views -> the next backward overwrites; set_to_none=False zeroes
@@ -120,6 +123,42 @@ class _TextLossFn(torch.autograd.Function):
         first = next(iter(tm.parameters()))
         live = first.grad is not None and first.grad.data_ptr() == tm.grad_views["model.embed_tokens.weight"].data_ptr()
         d_geom = model._backward_text(st, gscale, accumulate=live)
+        tm.publish_grads()
+        return (None, None, d_geom if ctx.has_geom else None, *([None] * len(model._text_param_names)))
+
+
+    @staticmethod
+    def _backward_multi_rank(ctx, model, st, gscale, world, group):
+        """loss.backward() with torch.distributed initialised over more than one rank - the reference's own multi-GPU route
+        (train_sft.py:119-133 Accelerator, :165-170 prepare -> DistributedDataParallel(find_unused_parameters=True), :217 backward).
+        The text parameters never pass through autograd (their .grad are views of the flat buffer, filled by the HIP backward), so DDP's
+        reducer cannot see them: it would mark all 4 B of them unused and every rank would train on its own gradient. This route therefore
+        does what DDP does for them, itself: the gradient of THIS backward is all-reduced (SUM, / world: DDP's average) over the flat
+        buffer before it joins what earlier backwards of the window left there. geom_head's fp32 parameters are ordinary autograd leaves:
+        DDP (or the caller) reduces them as for any module. `model.autograd_dp`: "allreduce" (default), "raise", or "local" (the caller
+        owns the exchange - Stage1Trainer never comes through here, it drives forward_state / _backward_text with its own bucketed,
+        overlapped all-reduce and is the fast path)."""
+        from . import dp
+        tm = model.text_model
+        mode = model.autograd_dp
+        if mode == "raise" or (mode == "allreduce" and st.get("pctx") is not None):
+            raise RuntimeError(
+                "VGGTQwen3VLM: loss.backward() under torch.distributed with world_size %d: the text model's gradients live in a flat buffer "
+                "that DistributedDataParallel's reducer never sees - replicas would diverge silently. Use vggt_qwen3_amd.trainer.Stage1Trainer "
+                "(bucketed RCCL all-reduce inside the backward), or set model.autograd_dp = 'allreduce' (this route reduces the flat gradient "
+                "itself; not available with train_projector=True) / 'local' (you reduce text_model.flat_g yourself)." % world)
+        first = next(iter(tm.parameters()))
+        live = first.grad is not None and first.grad.data_ptr() == tm.grad_views["model.embed_tokens.weight"].data_ptr()
+        if mode == "local":
+            d_geom = model._backward_text(st, gscale, accumulate=live)
+        else:
+            keep = tm.flat_g.clone() if live else None          # what earlier backwards of the window accumulated (already reduced)
+            d_geom = model._backward_text(st, gscale, accumulate=False)
+            torch.cuda.current_stream().synchronize()
+            dp.allreduce_tensor(tm.flat_g, group=group)         # every rank comes here once per backward, labelled rows or not
+            tm.flat_g.mul_(1.0 / world)
+            if keep is not None:
+                tm.flat_g.add_(keep)
         tm.publish_grads()
         return (None, None, d_geom if ctx.has_geom else None, *([None] * len(model._text_param_names)))
 
@@ -175,6 +214,16 @@ class VGGTQwen3VLM(nn.Module):
         self._weights_gate = None        # event of an optimiser step still running on Stage1Trainer's side stream (trainer.py)
         self._vis_group = []          # [(images tensor, aggregator tokens)]: precompute_vision() results waiting for their micro-batch
         self._text_param_names = [n for n, _ in self.text_model.named_parameters()]
+        # loss.backward() with torch.distributed initialised over > 1 rank (the reference's Accelerate / DDP route): see
+        # _TextLossFn._backward_multi_rank. "allreduce" | "raise" | "local"; the process group is `autograd_dp_group` (None = WORLD)
+        self.autograd_dp = os.environ.get("VQ3_AUTOGRAD_DP", "allreduce")
+        self.autograd_dp_group = None
+
+    def _autograd_dp_world(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1, None
+        return dist.get_world_size(self.autograd_dp_group), self.autograd_dp_group
 
     def _apply(self, fn, recurse=True):
         """`.to(...)`, `.cpu()`, `.cuda()`, `.float()`, `.bfloat16()` are no-ops: the weights live in HBM in the flat,
