@@ -449,3 +449,68 @@ def test_persistent_decode_reports_a_full_cache(ops):
     assert int(ps["barrier"].sum().item()) == 4 * 256 + 32         # the grid still drained: every phase arrived (the attention phase without computing)
     with pytest.raises(RuntimeError, match="cache full"):
         ops.decode_layers_status(ps["status"])
+
+
+def test_persistent_decode_generate_vs_cpu_oracle():
+    """generate() on the PERSISTENT route (csrc/decode_layers.hip exists at Qwen3-4B's dimensions only, so
+    the transformers goldens - tiny dims - cannot reach it) against oracle.generate.greedy_generate on the same weights: 2 layers at
+    Qwen3-4B's width (2560 / 9728 / 32 q / 8 kv heads of 128), the FULL vocabulary, a 24-token prompt, 8 new tokens, repetition penalty 1.1
+    and a 3-gram ban as the reference's callers set them (src/inference/qa_inference.py:207-216). The oracle re-runs the whole row
+    through oracle.qwen3 every step (no KV cache, no shared code). Ids are equal, or first differ where the ORACLE's own top-2 logits
+    are within the bf16 tie tolerance; both graph replay and eager stepping."""
+    from oracle import generate as og, qwen3 as oq
+    from vggt_qwen3_amd import ops
+    if not ops.decode_layers_supported(2560, 9728, 32, 8, 128, 128):
+        pytest.skip("needs an MI355X (256 CUs)")
+    tm, cfg = _qwen4b_dims(2)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():                                    # norm weights away from 1, as in trained checkpoints
+        for n, p in tm.named_parameters():
+            if "norm" in n:
+                p.copy_((1.0 + 0.2 * torch.randn(p.shape, generator=g)).to(BF16))
+    L, NEW = 24, 8
+    ids = torch.randint(1000, 150000, (1, L), generator=g)
+    ids[0, 5:8] = ids[0, 1:4]                                # a repeated 3-gram in the prompt: the ban has something to act on
+    mask = torch.ones(1, L, dtype=torch.long)
+    tsd = {n: p.detach().cpu() for n, p in tm.named_parameters() if n != "lm_head.weight"}
+    qc = oq.Qwen3Cfg(num_hidden_layers=2, vocab_size=tm.vocab)
+    trace = []
+    ref = og.greedy_generate(tsd, qc, None, mask, max_new_tokens=NEW, repetition_penalty=1.1, no_repeat_ngram_size=3, input_ids=ids, trace=trace)
+    assert ref.shape == (1, L + NEW)
+    for use_graph in (True, False):
+        out, stats = tm.generate(input_ids=ids.cuda(), attention_mask=mask.cuda(), max_new_tokens=NEW, repetition_penalty=1.1,
+                                 no_repeat_ngram_size=3, use_graph=use_graph, return_stats=True)
+        assert stats["persistent"] and stats["graph"] == use_graph and out.shape == (1, L + NEW)
+        assert torch.equal(out[:, :L].cpu(), ids)
+        new, want = out[0, L:].cpu(), ref[0, L:]
+        diff = (new != want).nonzero().flatten()
+        first = int(diff[0]) if diff.numel() else NEW
+        assert first == NEW or trace[first] < TIE_TOL, (use_graph, new.tolist(), want.tolist(), trace)
+        assert first >= 2, (use_graph, new.tolist(), want.tolist(), trace)       # (the first picks sit well apart at this seed)
+
+
+def test_persistent_decode_falls_back_when_barrier_wait_runs_out(monkeypatch):
+    """a persistent launch whose grid barrier gave up (status bit 0) no longer costs the whole generate() call: the eager
+    first decode step is redone with one launch per projection from the restored state and the call goes on on that route, with a
+    warning. The failure is injected by setting the status word from the host right after the launch (ops.decode_layers wrapped)."""
+    from vggt_qwen3_amd import generate as G, ops
+    if not ops.decode_layers_supported(2560, 9728, 32, 8, 128, 128):
+        pytest.skip("needs an MI355X (256 CUs)")
+    tm, cfg = _qwen4b_dims(2)
+    torch.manual_seed(3)
+    emb = (torch.randn(1, 30, cfg.hidden_size) * 0.5).to(BF16).cuda()
+    mask = torch.ones(1, 30, dtype=torch.long).cuda()
+    monkeypatch.setenv("VQ3_DECODE_PERSISTENT", "0")
+    want = tm.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=6)
+    monkeypatch.setenv("VQ3_DECODE_PERSISTENT", "1")
+    real = ops.decode_layers
+
+    def broken(wtab, h, ws, cos, sin, lens, K, V, barrier, status, *a, **k):
+        real(wtab, h, ws, cos, sin, lens, K, V, barrier, status, *a, **k)
+        h.fill_(float("nan"))                                  # what a launch with a failed barrier leaves: garbage
+        status.fill_(1)
+    monkeypatch.setattr(ops, "decode_layers", broken)
+    with pytest.warns(UserWarning, match="not co-resident"):
+        out, stats = tm.generate(inputs_embeds=emb, attention_mask=mask, max_new_tokens=6, return_stats=True)
+    assert not stats["persistent"]
+    assert torch.equal(out, want)

@@ -199,13 +199,28 @@ def generate(tm, inputs_embeds: Optional[torch.Tensor] = None, attention_mask: O
     if max_new_tokens > 1 and use_graph:
         # warm the allocator, then capture one step; replay mutates the same state tensors
         side = torch.cuda.Stream(device=dev)
+        snap = None
+        if st.persistent is not None:            # what the step mutates, should it have to be redone on the other route (see below)
+            snap = (st.lens.clone(), st.step.clone(), st.finished.clone(), st.next_ids.clone(), st.generated.clone())
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             _decode_step(tm, st, cos, sin, opts)
         torch.cuda.current_stream().wait_stream(side)
         done_steps += 1
-        if st.persistent is not None:
-            ops.decode_layers_status(st.persistent["status"])   # a launch whose workgroups were not co-resident is reported now, not after N slow tokens
+        if st.persistent is not None and int(st.persistent["status"].item()) & 1:
+            # The persistent kernel needs its 256 workgroups co-resident; a bounded barrier wait ran out (other tenants / streams hold CUs,
+            # a CU mask): its step's hidden row and the cache rows it appended are garbage. Nothing is lost: the state is put back, the
+            # K / V rows at position lens (the only ones the step wrote) are rewritten by the redo, and this call decodes with one launch
+            # per projection from here on.
+            import warnings
+            warnings.warn("vq3: the persistent decode kernel's workgroups were not co-resident (a grid-barrier wait ran out); this "
+                          "generate() call continues with one launch per projection (VQ3_DECODE_PERSISTENT=0 selects that route up front)")
+            st.persistent = None
+            for dst, src in zip((st.lens, st.step, st.finished, st.next_ids, st.generated), snap):
+                dst.copy_(src)
+            _decode_step(tm, st, cos, sin, opts)
+        elif st.persistent is not None:
+            ops.decode_layers_status(st.persistent["status"])   # (cache full)
         if max_new_tokens > 2:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -215,6 +230,8 @@ def generate(tm, inputs_embeds: Optional[torch.Tensor] = None, attention_mask: O
             break
         if graph is not None:
             graph.replay()
+            if st.persistent is not None and done_steps % check_every == 0:
+                ops.decode_layers_status(st.persistent["status"])       # a failure mid-way surfaces within check_every tokens, not after all of them
         else:
             _decode_step(tm, st, cos, sin, opts)
             if st.persistent is not None and done_steps % check_every == 0:
