@@ -108,64 +108,51 @@ class BatchStream:
 
 
 def cpu_baseline(model, batch, L):
-    """The CPU oracle (PyTorch-CPU restatement of the reference's path) timed on this host's cores on a bounded
-    sample, extrapolated to one full training sample. Reported baseline only."""
-    from oracle import perceiver as operc, qwen3 as oq, vggt as ov
+    """The CPU oracle (PyTorch-CPU restatement of the reference's path, oracle/) timed on this host's cores on ONE WHOLE training sample of
+    the workload, nothing extrapolated: the 72-block tower forward (bf16, no_grad), the 6-layer Perceiver forward (fp32, no_grad: the
+    reference never back-propagates into it), the splice, all 36 Qwen3-4B layers + full-vocabulary lm_head + shifted CE forward AND
+    backward (bf16 parameters, torch autograd) - what VGGTQwen3VLM.forward + loss.backward() cost the reference on CPU (config C1's
+    arithmetic: vggt_qwen3_vlm.py:128-201, train_sft.py:217). No optimiser step (it would add 16 B / parameter of host traffic, not
+    arithmetic of the path). Reported baseline only; about 20-30 s on a 128-core host."""
+    from oracle import perceiver as operc, qwen3 as oq, vggt as ov, vlm as ovlm
     nthreads = torch.get_num_threads()
     t_all = {}
-    # Perceiver: full size, one sample, fp32 as in the reference's CPU forward
-    psd = {k: v.detach().float().cpu() for k, v in model.projector.state_dict().items()}
-    tok = torch.randn(1, 128, model.projector.in_dim)
-    t0 = time.perf_counter(); operc.projector(tok, psd, model.projector.cfg.num_heads, model.projector.cfg.num_layers)
-    t_all["perceiver_fwd"] = time.perf_counter() - t0
-    del psd
-    # Qwen3: NL layers at full width, one sample, fwd + bwd, bf16
-    NL = 2
     tm = model.text_model
-    cfg = oq.Qwen3Cfg(num_hidden_layers=NL, vocab_size=tm.vocab)
-    sd = {}
-    for n, p in tm.named_parameters():
-        if n.startswith("model.layers."):
-            if int(n.split(".")[2]) >= NL:
-                continue
-        if n.startswith("model.embed") or n.startswith("lm_head"):
-            continue
-        sd[n] = p.detach().cpu().requires_grad_(True)
-    emb = (torch.randn(1, L, cfg.hidden_size) * 0.5).to(torch.bfloat16)
-    mask = batch["attention_mask"][:1].cpu()
-    t0 = time.perf_counter()
-    h = oq.model_forward(emb, mask, sd, cfg)
-    h.float().pow(2).mean().backward()
-    t_all[f"qwen_{NL}layers_fwd_bwd"] = time.perf_counter() - t0
-    del sd
-    # lm_head + loss over all L positions as the reference does, fwd + bwd
-    E = tm._w["embed"].detach().cpu().requires_grad_(True)
-    hl = (torch.randn(1, L, cfg.hidden_size)).to(torch.bfloat16).requires_grad_(True)
-    t0 = time.perf_counter()
-    logits = torch.nn.functional.linear(hl, E)
-    oq.causal_lm_loss(logits, batch["labels"][:1].cpu()).backward()
-    t_all["lm_head_loss_fwd_bwd"] = time.perf_counter() - t0
-    del E
-    # VGGT: one frame, depth 1 (1 DINO + 1 frame + 1 global block) at full width
     agg = model.vision_model.aggregator
-    vsd = {}
-    for n, t in agg.named_tensors().items():
-        parts = n.split(".")
-        if ("blocks" in n) and any(x.isdigit() and int(x) >= 1 for x in parts):
-            continue
-        vsd[n] = t.detach().float().cpu()
-    img = batch["pixel_values"][:1, :1].cpu()
-    t0 = time.perf_counter()
+    img = batch["pixel_values"][:1].cpu()
+    ids, mask, labels = batch["input_ids"][:1].cpu(), batch["attention_mask"][:1].cpu(), batch["labels"][:1].cpu()
+    vsd = {n: t.detach().cpu() for n, t in agg.named_tensors().items()}
+    psd = {k: v.detach().float().cpu() for k, v in model.projector.state_dict().items()}
+    tsd = {n: p.detach().cpu().requires_grad_(True) for n, p in tm.named_parameters() if n != "lm_head.weight"}
+    cfg = oq.Qwen3Cfg(num_hidden_layers=tm.config.num_hidden_layers, vocab_size=tm.vocab)
+    t_start = time.perf_counter()
     with torch.no_grad():
-        ov.aggregator(img, vsd, num_heads=agg.num_heads, depth=1, dino_depth=1)
-    t_all["vggt_3blocks_fwd"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        last = ov.aggregator(img, vsd, num_heads=agg.num_heads, depth=agg.depth, dino_depth=agg.dino_depth)[-1]
+        t_all["vggt_fwd"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        vis = operc.projector(ovlm.select_tokens(last, model.num_vis_tokens).float(), psd, model.projector.cfg.num_heads, model.projector.cfg.num_layers)
+        t_all["perceiver_fwd"] = time.perf_counter() - t0
+    del vsd, psd
+    t0 = time.perf_counter()
+    emb = torch.nn.functional.embedding(ids, tsd["model.embed_tokens.weight"])
+    feats = vis
+    if batch.get("geom_token") and model.geom_tokens:
+        gsd = {"geom_head." + k: v.detach().float().cpu() for k, v in model.geom_head.state_dict().items()}
+        g = ovlm.encode_geom({k: v[:1].float().cpu() for k, v in batch["geom_token"].items() if k != "mask"}, gsd, model.geom_tokens)
+        feats = torch.cat([g, vis], dim=1)
+    emb = ovlm.splice(emb, ids, feats.to(emb.dtype), model.image_id)
+    loss, _ = oq.causal_lm(emb, mask, labels, tsd, cfg)
+    t_all["qwen_fwd"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    loss.backward()
+    t_all["qwen_bwd"] = time.perf_counter() - t0
+    per_sample = time.perf_counter() - t_start
     V = batch["pixel_values"].shape[1]
-    per_sample = (t_all["perceiver_fwd"] + 36 / NL * t_all[f"qwen_{NL}layers_fwd_bwd"] + t_all["lm_head_loss_fwd_bwd"]
-                  + 24 * V * t_all["vggt_3blocks_fwd"])
     return {"value": 1.0 / per_sample, "unit": "samples/s", "cores": nthreads, "kind": "port",
-            "sample": ("1 sample: full Perceiver fwd (fp32) + %d of 36 Qwen3-4B layers fwd+bwd (bf16, L=%d) + lm_head/CE "
-                       "fwd+bwd + 3 of 72 VGGT blocks fwd, extrapolated linearly; parts(s)=%s"
-                       % (NL, L, {k: round(v, 3) for k, v in t_all.items()}))}
+            "sample": ("1 whole sample, measured end to end (no extrapolation): VGGT %d+%d+%d blocks fwd (bf16, %d view(s)) + Perceiver fwd (fp32) + "
+                       "Qwen3-4B %d layers + full-vocabulary lm_head + CE fwd+bwd (bf16, L=%d), torch autograd on the oracle; loss %.4f; parts(s)=%s"
+                       % (agg.dino_depth, agg.depth, agg.depth, V, cfg.num_hidden_layers, L, float(loss), {k: round(v, 2) for k, v in t_all.items()}))}
 
 
 def self_launch(n: int) -> int:

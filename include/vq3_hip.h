@@ -483,6 +483,13 @@ int vq3_gemm_tile_order(int32_t M, int32_t N, int32_t bm, int32_t bn, int32_t wg
  * ranks would disagree on near-ties. No counterpart in the reference (cuBLAS heuristics are internal). */
 int vq3_gemm_tune_table_load(const char* path, int32_t* entries_out);
 int vq3_gemm_tune_workspace(void* ptr, int64_t bytes);
+/* Lazy form of the above, and the source of the split-K launches' per-stream workspaces: `fn(bytes, device, kind)` is called from inside
+ * a GEMM call - never under graph capture - the first time a measurement (kind 0: trial output + flush buffer, may be called again with a
+ * larger size; the previous block may then be released) or a split launch on a new stream (kind 1: 48 MiB + counts, must stay alive for
+ * the life of the process) needs device memory on `device`; it returns a 256-byte aligned pointer or NULL ("none available": the shape is
+ * not measured / the launch runs unsplit). With a provider registered the library itself never calls hipMalloc. NULL detaches. */
+typedef void* (*vq3_ws_provider_t)(int64_t bytes, int32_t device, int32_t kind);
+int vq3_gemm_workspace_provider(vq3_ws_provider_t fn);
 int vq3_gemm_autotune_hold(int32_t on);
 
 /* Last-round K split of the 256x256 GEMM kernel (cfg 25; chosen by measurement like every other configuration). An M x N output is

@@ -134,6 +134,7 @@ SIGNATURES = {
     "vq3_gemm_autotune_hold": [i32],
     "vq3_gemm_split_plan": [i32, i32, i32, i32, c_p, c_p, c_p],
     "vq3_gemm_split_status": [c_p, c_p],
+    "vq3_gemm_workspace_provider": [c_p],
     "vq3_gemm_split_poll": [c_p, i32],
     "vq3_gemm_split_debug_spin_bound": [i64],
     "vq3_pack_tokens": [c_p, c_p, c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p, c_p],

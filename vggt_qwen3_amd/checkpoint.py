@@ -40,6 +40,8 @@ def save_model(model, out_dir, max_shard_bytes: int = 5 << 30, include_vision: b
     """Write `out_dir/pytorch_model_fp32/{shards, index}`. Returns the weight map (name -> shard file)."""
     root = Path(out_dir) / MERGED_DIR
     root.mkdir(parents=True, exist_ok=True)
+    if hasattr(model, "_pass_weights_gate"):
+        model._pass_weights_gate()            # an optimiser step Stage1Trainer left running on its side stream finishes first
     shards: List[Dict[str, torch.Tensor]] = [{}]
     size, total = 0, 0
     for name, t in checkpoint_items(model, include_vision):

@@ -222,6 +222,10 @@ int g_autotune = -1;
 // heuristic answers), never a silent allocation.
 void* g_ws = nullptr;
 size_t g_ws_bytes = 0;
+int g_ws_dev = -1;                    // device the registered workspace lives on (-1: whatever the caller registered by hand)
+// vq3_gemm_workspace_provider: the caller's allocator (a torch tensor factory) asked for device memory the moment a measurement - or a
+// split-K launch's first use of a stream - actually needs it: an inference-only process or a multi-rank job (hold on) never pays for it
+vq3_ws_provider_t g_provider = nullptr;
 // vq3_gemm_autotune_hold: nothing is measured while it is on (multi-rank jobs: a measurement synchronises the device under in-flight
 // collectives and every rank would rank near-ties on its own; the table and the heuristic are the same function on every rank)
 int g_hold = 0;
@@ -306,6 +310,16 @@ int tune(const GemmParams& p0, const std::vector<int>& cands, int transA, int tr
   const size_t need = ((size_t)p.M * p.N * esz * (size_t)nbatch + 256 + 255) & ~(size_t)255;
   void* scratch_c = nullptr;
   void* flush = nullptr;
+  if (g_provider) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!g_ws || g_ws_dev != dev || need + FLUSH_BYTES > g_ws_bytes) {
+      // lazily, for THIS device, at least what this shape needs (the provider rounds up to its default size and keeps the tensor alive)
+      void* w = g_provider((int64_t)(need + FLUSH_BYTES), dev, 0);
+      if (!w) return -1;                                       // no memory to measure in: the table / heuristic answers
+      g_ws = w; g_ws_bytes = need + FLUSH_BYTES; g_ws_dev = dev;
+    }
+  }
   if (g_ws) {
     if (need + FLUSH_BYTES > g_ws_bytes) return -1;           // the caller's workspace decides what may be measured
     scratch_c = g_ws;
@@ -757,13 +771,21 @@ extern "C" int vq3_gemm_tune_table_load(const char* path, int32_t* entries_out) 
 extern "C" int vq3_gemm_tune_workspace(void* ptr, int64_t bytes) {
   VQ3_CHECK_ARG((ptr == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)ptr % 256 == 0), "gemm_tune_workspace: bad workspace");
   std::lock_guard<std::mutex> lock(g_tune_mutex);
-  g_ws = ptr; g_ws_bytes = (size_t)bytes;
+  g_ws = ptr; g_ws_bytes = (size_t)bytes; g_ws_dev = -1;
   return 0;
 }
 
 extern "C" int vq3_gemm_autotune_hold(int32_t on) {
   std::lock_guard<std::mutex> lock(g_tune_mutex);
   g_hold = on ? 1 : 0;
+  return 0;
+}
+
+extern "C" int vq3_gemm_workspace_provider(vq3_ws_provider_t fn) {
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  g_provider = fn;
+  if (g_ws_dev >= 0) { g_ws = nullptr; g_ws_bytes = 0; g_ws_dev = -1; }      // a workspace the old provider gave is no longer ours
+  gemm_split_set_provider(fn);
   return 0;
 }
 

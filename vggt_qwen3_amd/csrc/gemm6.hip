@@ -689,6 +689,7 @@ std::map<hipStream_t, SkWs> g_sk;
 // visible until somebody reads it with clear (gemm_split_poll(true) / vq3_gemm_split_status) - the trainer does, once per optimiser step.
 unsigned* g_sk_err = nullptr;
 unsigned g_sk_spin = 1u << 23;
+vq3_ws_provider_t g_sk_provider = nullptr;      // caller-owned memory for the per-stream workspaces (vq3_gemm_workspace_provider)
 constexpr size_t SK_WS_BYTES = (size_t)192 * 256 * 256 * 4;          // rem * (slices - 1) <= 192 partial tiles (48 MiB)
 constexpr size_t SK_CNT_BYTES = SK_MAX_TILES * sizeof(unsigned);
 bool sk_workspace(hipStream_t s, float** ws, unsigned** cnt, unsigned** err, unsigned* spin) {
@@ -703,9 +704,23 @@ bool sk_workspace(hipStream_t s, float** ws, unsigned** cnt, unsigned** err, uns
       g_sk_err = (unsigned*)h;
       *(volatile unsigned*)g_sk_err = 0u;
     }
-    if (hipMalloc(&w.ws, SK_WS_BYTES) != hipSuccess || hipMalloc(&w.cnt, SK_CNT_BYTES) != hipSuccess) {
-      (void)hipGetLastError();
-      if (getenv("VQ3_GEMM_AUTOTUNE_LOG")) fprintf(stderr, "[vq3 gemm] split-K workspace allocation failed: cfg 25 downgraded to cfg 20 on this stream\n");
+    bool ok = false;
+    if (g_sk_provider) {
+      // one block from the caller's allocator (kept alive by the caller for the life of the process): partial tiles, then the counts
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      char* blk = (char*)g_sk_provider((int64_t)(SK_WS_BYTES + SK_CNT_BYTES), dev, 1);
+      if (blk) { w.ws = (float*)blk; w.cnt = (unsigned*)(blk + SK_WS_BYTES); ok = true; }
+    } else {
+      // a plain C caller that registered no provider: the library's own allocation, once per stream
+      ok = hipMalloc(&w.ws, SK_WS_BYTES) == hipSuccess && hipMalloc(&w.cnt, SK_CNT_BYTES) == hipSuccess;
+      if (!ok) (void)hipGetLastError();
+    }
+    if (!ok) {
+      static bool said = false;
+      if (!said) fprintf(stderr, "[vq3 gemm] no memory for a split-K workspace (48 MiB): cfg 25 launches run as cfg 20 on this stream (same result, "
+                                 "another order of the f32 sums)\n");
+      said = true;
       w.ws = nullptr;
       return false;
     }
@@ -913,6 +928,10 @@ int gemm_split_poll(bool clear) {
   const unsigned v = __atomic_load_n(g_sk_err, __ATOMIC_ACQUIRE);
   if (v && clear) __atomic_store_n(g_sk_err, 0u, __ATOMIC_RELEASE);
   return v ? 1 : 0;
+}
+void gemm_split_set_provider(vq3_ws_provider_t fn) {
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  g_sk_provider = fn;
 }
 void gemm_split_set_spin_bound(unsigned polls) {
   std::lock_guard<std::mutex> lock(g_sk_mutex);

@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "vq3_hip.h"
 
 namespace vq3gemm {
 
@@ -759,6 +760,7 @@ int gemm_split_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* re
 int gemm_split_gave_up(hipStream_t stream);
 int gemm_split_poll(bool clear);
 void gemm_split_set_spin_bound(unsigned polls);
+void gemm_split_set_provider(vq3_ws_provider_t fn);
 // v7 (256x128 tile, four waves, two workgroups per CU: a tile's epilogue runs under the co-resident workgroup's main loop), gemm7.hip.
 // Returns -1 (nothing launched) when the problem is outside its contract: the caller picks another kernel.
 int launch_gemm_v7(GemmParams& p, int nbatch, hipStream_t stream);

@@ -50,28 +50,63 @@ def round_up(x: int, m: int) -> int:
 
 
 # ----------------------------------------------------------------------------------------------- GEMM
-_TUNE_WS = None      # None: not set up yet; False: no workspace; else the uint8 tensor the GEMM tuner measures in
+_TUNE_WS = None      # None: not set up yet; else {"tune": {device: tensor}, "split": [tensors]} - memory the library asked the provider for
+_WS_PROVIDER = None  # the ctypes callback object (must outlive its registration)
+
+
+def _ws_provider(nbytes: int, device: int, kind: int) -> int:
+    """vq3_ws_provider_t: called by the library, from inside a GEMM call and never under graph capture, the first time it needs device
+    memory - kind 0: the kernel-choice tuner is about to MEASURE a shape on `device` (trial output + 320 MiB cache flush; at least
+    VQ3_GEMM_TUNE_WS_MB, default 1024, so that later shapes fit without another call); kind 1: a split-K launch's first use of a stream
+    (48 MiB of partial tiles, kept for the life of the process). Returns 0 ("none": the shape is not measured / the launch runs unsplit)
+    rather than raising through the C frame."""
+    import os
+    try:
+        dev = torch.device("cuda", int(device))
+        if kind == 0:
+            mb = int(os.environ.get("VQ3_GEMM_TUNE_WS_MB", "1024"))
+            if mb <= 0:
+                return 0
+            t = torch.empty(max(int(nbytes), mb << 20), dtype=torch.uint8, device=dev)
+            _TUNE_WS["tune"][int(device)] = t          # (a smaller block of an earlier call is released here)
+        else:
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            _TUNE_WS["split"].append(t)
+        return t.data_ptr()
+    except Exception:      # out of memory, no such device: the library falls back (and says so)
+        return 0
 
 
 def gemm_tune_setup(force: bool = False) -> None:
-    """Once per process, before the first GEMM: hand the kernel-choice tuner a torch-owned workspace (VQ3_GEMM_TUNE_WS_MB, default
-    1024: trial output + 320 MiB cache flush; 0 = none, the library then allocates its own on first use) and, in a multi-rank job, stop
-    it from measuring at all (the shipped table, then the heuristic, answer - the same function on every rank; VQ3_GEMM_AUTOTUNE_DIST=1
-    lets every rank measure as a single process would). Stage1Trainer calls it again once torch.distributed is up."""
-    global _TUNE_WS
+    """Once per process, before the first GEMM: register the workspace PROVIDER (nothing is allocated until the tuner actually measures a
+    shape or a split-K launch first runs on a stream: an inference-only process whose shapes are all in the shipped table, or a rank of a
+    multi-rank job, never holds the 1 GiB tuning workspace) and, in a multi-rank job, stop the tuner from measuring at all (the shipped
+    table, then the heuristic, answer - the same function on every rank; VQ3_GEMM_AUTOTUNE_DIST=1 lets every rank measure as a single
+    process would) and release what it held. Stage1Trainer calls it again once torch.distributed is up (force=True, with its process group)."""
+    global _TUNE_WS, _WS_PROVIDER
     if _TUNE_WS is not None and not force:
         return
+    import ctypes as C
     import os
     lib = _lib.load()
     if _TUNE_WS is None:
-        _TUNE_WS = False
-        mb = int(os.environ.get("VQ3_GEMM_TUNE_WS_MB", "1024"))
-        if os.environ.get("VQ3_GEMM_AUTOTUNE", "1") != "0" and mb > 0 and torch.cuda.is_available():
-            _TUNE_WS = torch.empty(mb << 20, dtype=torch.uint8, device="cuda")
-            check(lib.vq3_gemm_tune_workspace(_TUNE_WS.data_ptr(), _TUNE_WS.numel()), "vq3_gemm_tune_workspace")
+        _TUNE_WS = {"tune": {}, "split": []}
+        if torch.cuda.is_available():
+            _WS_PROVIDER = C.CFUNCTYPE(C.c_void_p, C.c_int64, C.c_int32, C.c_int32)(_ws_provider)
+            check(lib.vq3_gemm_workspace_provider(C.cast(_WS_PROVIDER, C.c_void_p)), "vq3_gemm_workspace_provider")
+    hold = _multi_rank(_TUNE_GROUP) and os.environ.get("VQ3_GEMM_AUTOTUNE_DIST", "0") != "1"
+    check(lib.vq3_gemm_autotune_hold(1 if hold else 0), "vq3_gemm_autotune_hold")
+    if hold and _TUNE_WS["tune"]:
+        check(lib.vq3_gemm_tune_workspace(None, 0), "vq3_gemm_tune_workspace")        # nothing will be measured: give the memory back
+        _TUNE_WS["tune"].clear()
+
+
+_TUNE_GROUP = None   # the process group whose size decides "multi-rank" (Stage1Trainer sets its own; None = the default group)
+
+
+def _multi_rank(group=None) -> bool:
     import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    check(lib.vq3_gemm_autotune_hold(1 if (multi and os.environ.get("VQ3_GEMM_AUTOTUNE_DIST", "0") != "1") else 0), "vq3_gemm_autotune_hold")
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
 def gemm_raw(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,

@@ -287,9 +287,17 @@ class Qwen3ForCausalLM(nn.Module):
         m.load_hf_state_dict(sd, strict=True)
         return m
 
+    def _pass_weights_gate(self) -> None:
+        """An optimiser step Stage1Trainer left running on its side stream (overlap_optimizer) must be complete before anything reads the
+        weights from another stream: the trainer leaves its event here (and on the VLM, vlm.py: _pass_weights_gate)."""
+        ev = getattr(self, "_weights_gate", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)       # (the event stays: the VLM's own gate clears both)
+
     def generate(self, *args, **kwargs):
         """Greedy decoding with a KV cache (vggt_qwen3_amd/generate.py); transformers-compatible keywords."""
         from .generate import generate as _generate
+        self._pass_weights_gate()
         return _generate(self, *args, **kwargs)
 
     # ------------------------------------------------------------------ helpers
@@ -314,6 +322,7 @@ class Qwen3ForCausalLM(nn.Module):
         through a byte-transposed copy: W's per-output-channel scales run along that contraction, so they are folded into dY before
         its rows are quantised (vq3_quant_fp8_rows_scaled). Embedding / lm_head, norms, attention and the weight-gradient GEMMs stay
         bf16 (they read the saved bf16 activations and bf16 dY)."""
+        self._pass_weights_gate()                 # (quantises the weights: an optimiser step on the trainer's side stream must be complete)
         self._fp8 = {} if on else None
         if dgrad is None:
             dgrad = os.environ.get("VQ3_FP8_DGRAD", "1") != "0"

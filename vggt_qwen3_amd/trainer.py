@@ -60,6 +60,7 @@ class Stage1Trainer:
         self.warmup = int(warmup_ratio * max_steps)
         self.pg = process_group
         self.dist_on = dist.is_available() and dist.is_initialized()
+        ops._TUNE_GROUP = process_group       # "multi-rank" is decided on the trainer's own group
         ops.gemm_tune_setup(force=True)      # multi-rank: no kernel-choice measurements (table, then heuristic: the same on every rank)
         self.world = dist.get_world_size(process_group) if self.dist_on else 1
         self.rank = dist.get_rank(process_group) if self.dist_on else 0
@@ -353,6 +354,7 @@ class Stage1Trainer:
             ev = torch.cuda.Event()
             ev.record(self._opt_stream)
         self.model._weights_gate = ev
+        self.tm._weights_gate = ev           # (readers that only know the text model: generate(), enable_fp8_forward / requantize_fp8)
 
     def sync_optimizer(self) -> None:
         """Make the current stream wait for an optimiser step that is still running on the side stream (no-op otherwise)."""
@@ -360,6 +362,13 @@ class Stage1Trainer:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
             self.model._weights_gate = None
+            self.tm._weights_gate = None
+
+    def grad_norm(self) -> Optional[torch.Tensor]:
+        """Pre-clip global gradient norm of the last optimiser step (device scalar), ordered after a step that may still be running on the
+        side stream (`last_grad_norm` read directly from the main stream is not)."""
+        self.sync_optimizer()
+        return self.last_grad_norm
 
     def check_kernels(self) -> None:
         """Raises if a split-K GEMM reducer gave up its bounded wait in any launch completed so far (its output tile - an activation or a

@@ -345,6 +345,7 @@ class VGGTQwen3VLM(nn.Module):
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
             self._weights_gate = None
+            self.text_model._weights_gate = None
 
     def _take_prefetched(self, images: torch.Tensor):
         """(kind, tensor) of a prefetch_images() result for this very tensor object - kind "encoded": projector output, "tokens": the
