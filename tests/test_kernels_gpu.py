@@ -961,3 +961,42 @@ def test_dropout_mask_does_not_depend_on_the_access_width(ops, dt):
     ref = (base[:n].float() * (1.0 / 0.7)).to(dt)
     m = a != 0
     assert torch.equal(a[m], ref[m])
+
+
+def test_gemm_v7_ln_fold_is_repeatable(ops):
+    """Round 5: cfg 24 (gemm7.hip, two workgroups per CU) staged the folded LayerNorm's (mu, rstd) pairs in LDS behind a raw s_barrier
+    without waiting for its own LDS write - about one launch in three at 6174 x 4096 x 1024 one wave normalised 16 rows x 64 columns of
+    one tile with stale pairs (errors the size of the activations themselves; found through tests/test_fulldepth_gpu.py). The kernel's
+    arithmetic is the 256 x 256 kernel's (same K order, same rounding points): every launch must equal cfg 20 BIT FOR BIT - fc1 with the
+    fold + bias + GELU and the fused q|k|v epilogue behind the fold, 40 launches each on a grid of more than two workgroups per CU."""
+    torch.manual_seed(0)
+    M, C = 6174, 1024
+    x = torch.randn(M, C, device="cuda").to(BF16)
+    w1 = (torch.randn(4 * C, C, device="cuda") * 0.03).to(BF16)
+    wq = (torch.randn(3 * C, C, device="cuda") * 0.03).to(BF16)
+    b4, c4 = torch.randn(4 * C, device="cuda"), torch.randn(4 * C, device="cuda")
+    b3, c3 = torch.randn(3 * C, device="cuda"), torch.randn(3 * C, device="cuda")
+    st = ops.rowstats128(x)
+    ang = torch.rand(34, 16, device="cuda") * 3.0
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(BF16).contiguous(), emb.sin().to(BF16).contiguous()
+    qn = (torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1)
+
+    def fc1():
+        return (ops.linear(x, w1, bias=b4, act=ops.ACT_GELU, ln_fold=ops.ln_fold(stats_in=st, eps=1e-5, colsum=c4)),)
+
+    def qkv():
+        return ops.linear_vit_qkv(x, wq, b3, 1029, 16, qn=qn, kn=qn, cos=cos, sin=sin, tokens_per_frame=1029, patch_start=5, Wp=32, eps=1e-5,
+                                  ln_fold=ops.ln_fold(stats_in=st, eps=1e-5, colsum=c3))
+    try:
+        for fn in (fc1, qkv):
+            ops.gemm_force_config(20)
+            ref = [t.clone() for t in fn()]
+            assert all(torch.isfinite(t.float()).all() for t in ref)
+            ops.gemm_force_config(24)
+            for it in range(40):
+                got = fn()
+                for a, b in zip(got, ref):
+                    assert torch.equal(a, b), (fn.__name__, it, float((a.float() - b.float()).abs().max()))
+    finally:
+        ops.gemm_force_config(-3)

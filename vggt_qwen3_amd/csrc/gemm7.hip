@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256, 2) void gemm_v7_kernel(GemmParams p) {
   V7_BARRIER();
   if (ln_on) {
     lnp[tid] = float2{ln_mu, ln_rs};
+    // The raw s_barrier does NOT wait for this wave's outstanding LDS write (V7_BARRIER carries no s_waitcnt: in the main loop the LDS is
+    // written by DMA only, retired by the counted vmcnt): without the wait below a wave could pass the barrier with its pair still in
+    // flight and another wave's first read of lnp[] - row group (i = 0, mt = 0) - returned what the ring's slot 4 held before: ONE
+    // wave's 16 rows x 64 columns of one tile per launch or so came out normalised with a stale (mu, rstd) (round 5: found through the
+    // full-depth parity test, tools/diag/g7_pattern.py; tests/test_kernels_gpu.py::test_gemm_v7_ln_fold_is_repeatable).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     V7_BARRIER();
   }
   auto stage_all = [&](auto act_tag, auto mode_tag, auto ln_tag) {

@@ -405,23 +405,38 @@ template <int QB, int NT, int VAR = 0>
 __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                  int N, int NH, long ldo, float scale_log2e, int q_begin, int q_end, int o_rows,
-                                                                 int tail_begin) {
+                                                                 int tail_begin, int nblk) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * FA_KV * 128];   // 2 stages x (K tile | V tile)
   static_assert(FT_SMEM <= 2 * 2 * FA_KV * 128, "the tail rows' staging / merge area fits the key loop's LDS");
+  // XCD-aware placement (nblk > 0: a 1-D grid of nblk * pairs workgroups). The hardware deals consecutive workgroup ids round-robin over
+  // the 8 XCDs, each with a private 4 MiB L2: with (query block, pair) = (blockIdx.x, blockIdx.y) the nblk blocks of ONE (sample, head)
+  // pair - which all walk the same K and V rows - ran on nblk different XCDs, every one fetching the pair's K / V through the fabric on
+  // its own (N = 1029: 5 x 263 KB per pair, 1.26 GB per 960-pair launch for 0.25 GB of distinct rows). Here workgroup w is the
+  // (w / 8)-th item of XCD w % 8's contiguous slice of the (pair-major) item list, so a pair's blocks are dispatched together on one
+  // XCD and share its L2. Bijective for any grid size (same construction as gemm_common.h: tile_coords_id); only speed depends on it.
+  int bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
+  if (nblk > 0) {
+    const int total = gridDim.x, w = blockIdx.x;
+    const int xcd = w & 7, idx = w >> 3, qd = total >> 3, rm = total & 7;
+    const int sidx = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    by = sidx / nblk;
+    bx = sidx - by * nblk;
+    nbx = nblk;
+  }
   // tail_begin >= 0: the LAST workgroup of every (sample, head) pair takes the <= 16 ragged rows tail_begin .. N - 1 with its keys split
   // over the four waves (flash_tail_body). It is dispatched right behind the pair's exact blocks, so its K / V rows come from the L2 they
   // are filling - as a launch of its own the tail rows cost one more read of every K and V from HBM (35 us at 48 x 16 pairs)
   if constexpr (NT == 256 && QB == 2) {      // (the host only asks for it with two query blocks per wave; kept out of the 168-register QB = 1 build)
-    if (tail_begin >= 0 && blockIdx.x == gridDim.x - 1) {
-      flash_tail_body(smem, Q, K, V, O, N, NH, ldo, scale_log2e, tail_begin, o_rows, (long)blockIdx.y);
+    if (tail_begin >= 0 && bx == nbx - 1) {
+      flash_tail_body(smem, Q, K, V, O, N, NH, ldo, scale_log2e, tail_begin, o_rows, (long)by);
       return;
     }
   }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  const long nb = blockIdx.y;
-  const int q0 = q_begin + blockIdx.x * (NT / 2 * QB) + wid * (32 * QB);
+  const long nb = by;
+  const int q0 = q_begin + bx * (NT / 2 * QB) + wid * (32 * QB);
   const bf16_t* Qb = Q + nb * (long)N * 64;
   const bf16_t* Kb = K + nb * (long)N * 64;
   const bf16_t* Vb = V + nb * (long)N * 64;
@@ -994,11 +1009,19 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
                            (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N);
       else
         hipLaunchKernelGGL((flash_attn_hd64_kernel<1, 64>), dim3(1, G * NH), dim3(64), 0, side, (const bf16_t*)Q, (const bf16_t*)K,
-                           (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N, N, -1);
+                           (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, q_main, N, N, -1, 0);
       (void)hipEventRecord(ev_join, side);
     }
   }
   dim3 grid((q_main + 128 * qb - 1) / (128 * qb) + (tail_begin >= 0 ? 1 : 0), G * NH);
+  // XCD-aware 1-D grid (see the kernel): VQ3_FLASH_XCD=0 keeps the (block, pair) grid for A/B runs
+  static int xcd_env = -1;
+  if (xcd_env < 0) { const char* e = getenv("VQ3_FLASH_XCD"); xcd_env = e ? atoi(e) : 1; }
+  int nblk = 0;
+  if (xcd_env && grid.x > 1 && (long)grid.x * grid.y < (1L << 30)) {
+    nblk = (int)grid.x;
+    grid = dim3(grid.x * grid.y, 1);
+  }
   // variant: measured (tools/bench_flash.py, 6 x 16 heads): 8232 keys 920 (0) / 951 (1) TF/s, 1029 keys 563 / 560 - the overlap pays once the
   // key loop is long; VQ3_FLASH_VAR pins one
   static int fvar_env = -2;
@@ -1006,13 +1029,13 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
   const int fvar = fvar_env >= 0 ? fvar_env : (N >= 2048 ? 1 : 0);
   if (qb == 2 && fvar == 1)
     hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, tail_begin);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, tail_begin, nblk);
   else if (qb == 2)
     hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, tail_begin);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, tail_begin, nblk);
   else
     hipLaunchKernelGGL((flash_attn_hd64_kernel<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, -1);
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, -1, nblk);
   if (forked) (void)hipStreamWaitEvent((hipStream_t)stream, ev_join, 0);
   VQ3_CHECK_LAUNCH("flash_attn_fwd");
   return 0;
