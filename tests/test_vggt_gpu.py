@@ -367,3 +367,31 @@ def test_aggregator_forward_head_equals_the_slice_the_reference_takes(n, monkeyp
         assert got.shape == want.shape
         assert relerr(got, want) < 1e-3
         assert (got.float() - want.float()).abs().max() <= 2 ** -6 * want.float().abs().max()
+
+
+@pytest.mark.parametrize("cfg", [20, 21, 22, 24, 25, 30, -3])
+def test_tower_forward_is_repeatable_under_every_gemm_kernel(cfg):
+    """Round 5 (the gemm7 race): every GEMM kernel the tuner may pick for the tower's launches - 256 x 256 (20), its two-phase persistent
+    forms (21 / 22), two workgroups per CU (24), the K-split last round (25), whole rounds + row tail (30), and the tuner's own choice (-3) -
+    must give the SAME BITS for the same input, launch after launch (none of them uses atomics; every one sums K in a fixed order), on a
+    grid that over-subscribes the chip (7 frames x 1029 tokens = 7203 rows: 29 x 32 tiles of 256 x 128), and all of them agree within
+    bf16 rounding. Full width (C = 1024, 16 heads), one DINOv2 + one frame + one global block, LayerNorm folds on."""
+    from vggt_qwen3_amd import ops
+    from vggt_qwen3_amd.vggt import VGGT
+    model = VGGT(img_size=518, patch_size=14, embed_dim=1024, depth=1, dino_depth=1, device="cuda", seed=5)
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(7, 1, 3, 448, 448, generator=g).cuda()
+    agg = model.aggregator
+    ops.gemm_force_config(20)
+    try:
+        base = agg(img)[0][-1].clone()
+        ops.gemm_force_config(cfg)
+        first = agg(img)[0][-1].clone()
+        for it in range(10):
+            again = agg(img)[0][-1]
+            assert torch.equal(again, first), (cfg, it, float((again.float() - first.float()).abs().max()))
+    finally:
+        ops.gemm_force_config(-3)
+    assert torch.isfinite(first.float()).all()
+    assert ((first.float() - base.float()).norm() / base.float().norm()).item() < 5e-3, cfg
+    assert not ops.gemm_split_gave_up()
