@@ -563,11 +563,13 @@ def main():
         # PMC counters cannot be read from inside the run: `traffic` is the rocprofv3 --pmc result of THIS command at the
         # commit named beside it (tools/summarize_pmc.py writes the file); null when no such profile has been committed
         traffic, traffic_src = None, None
-        tj = ROOT / "profiles" / "r4_pmc_traffic.json"
-        if tj.exists():
-            tjd = json.loads(tj.read_text())
-            traffic = round(tjd["traffic_bytes_per_launch"])
-            traffic_src = {"file": "profiles/r4_pmc_traffic.json", "measured_at_commit": tjd.get("commit"), "command": tjd.get("command")}
+        for tname in ("r5_pmc_traffic.json", "r4_pmc_traffic.json"):     # the newest committed PMC pass of this command
+            tj = ROOT / "profiles" / tname
+            if tj.exists():
+                tjd = json.loads(tj.read_text())
+                traffic = round(tjd["traffic_bytes_per_launch"])
+                traffic_src = {"file": "profiles/" + tname, "measured_at_commit": tjd.get("commit"), "command": tjd.get("command")}
+                break
         roof = {"bound": "mfma", "kernel": "gemm kernels behind vq3_gemm_bf16_nt (gemm_v2 / gemm_v3 / gemm_v6)", "achieved": round(ach, 1),
                 "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,

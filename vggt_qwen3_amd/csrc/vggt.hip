@@ -441,19 +441,6 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   const bf16_t* Kb = K + nb * (long)N * 64;
   const bf16_t* Vb = V + nb * (long)N * 64;
 
-  // Q' fragments (B operand): lane (r,h) holds Q'[q0 + 32 qb + r][16 s + 8 h .. +8]
-  bf16x8 qf[QB][4];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    int qr = q0 + 32 * qb + r;
-    qr = qr < q_end ? qr : q_end - 1;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 raw = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 16 * s + 8 * h);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qf[qb][s][j] = (short)f2bf(bf2f((bf16_t)raw[j]) * scale_log2e);
-    }
-  }
   f32x16 o0[QB], o1[QB];
   float m_run[QB], l_run[QB];
   // -m replicated over an accumulator-shaped vector: the first QK MFMA of a tile takes it as C and writes the scores to
@@ -535,8 +522,25 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       voff[db] = FA_KV * 128 + fa_vswz(4 * h + vq, 4 * db + 2 * g16 + (vp >> 1)) + 8 * (vp & 1);
   }
 
+  // Prologue: the first K / V tile AND the Q rows are requested together (two independent round trips in flight at once; the Q rows
+  // used to be loaded, waited for and converted before the first tile was even requested: ~1 us of a 25 us workgroup at N = 1029)
   load_tile(0);
+  // Q' fragments (B operand): lane (r,h) holds Q'[q0 + 32 qb + r][16 s + 8 h .. +8]
+  bf16x8 qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    int qr = q0 + 32 * qb + r;
+    qr = qr < q_end ? qr : q_end - 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (long)qr * 64 + 16 * s + 8 * h);
+  }
   store_tile(0);
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[qb][s][j] = (short)f2bf(bf2f((bf16_t)qf[qb][s][j]) * scale_log2e);
   __syncthreads();
 
   // a wave whose 32 * QB query rows all lie past N (the ragged last block: N = 1029 leaves 5 rows for wave 0 and none for waves
@@ -889,26 +893,47 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     }
   }
 
-  // ---- epilogue: lane owns query q0 + 32*qb + r, d = 32*db + (i&3) + 8*(i>>2) + 4h
+  // ---- epilogue: lane owns query q0 + 32*qb + r, d = 32*db + (i&3) + 8*(i>>2) + 4h. Straight from the registers a wave instruction
+  // would write 32 rows x 16 B - 32 partially written 128-byte lines per instruction, 32 instructions per wave. The K / V stages are dead
+  // (every wave passed the last tile's barrier), so the wave lays its 32 * QB rows x 128 B out in a private slice of them - 16-byte chunk
+  // XOR (row >> 1) & 7: the 8-byte quad writes of 16 rows x 2 halves cover all 64 banks - and stores WHOLE rows: 16 B per lane, 8 lanes
+  // per row, 8 rows per instruction (cdna guide: attention, "O staged through LDS and stored as whole rows").
+  if (active) {
+    constexpr int RW = 32 * QB;                                 // rows of this wave
+    // (the thread index is made opaque here: every address below is formed AFTER the key loop - hoisted in front of it they cost the
+    // loop 4-11 registers: a spill in the VAR = 1 build, the third wave per SIMD in the QB = 1 build)
+    int te = threadIdx.x;
+    asm volatile("" : "+v"(te));
+    const int lane_e = te & 63, wid_e = __builtin_amdgcn_readfirstlane(te >> 6);
+    const int r = lane_e & 31, h = lane_e >> 5, lane = lane_e;
+    const int q0 = q_begin + bx * (NT / 2 * QB) + wid_e * (32 * QB);
+    char* ob = smem + wid_e * (RW * 128);
+    const long g = nb / NH;
+    const int hd = (int)(nb % NH);
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int q = q0 + 32 * qb + r;
-    if (q < q_end) {
+    for (int qb = 0; qb < QB; ++qb) {
       const float inv = 1.f / (LSUM ? lacc[qb][0] : l_run[qb]);
-      const long g = nb / NH;
-      const int hd = (int)(nb % NH);
-      bf16_t* orow = O + (g * o_rows + q) * ldo + hd * 64;     // o_rows = N, or the leading rows kept per group
+      const int row = 32 * qb + r;
+      const int sw = (row >> 1) & 7;
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {
-        const int d = 8 * i4 + 4 * h;
         u32x2 w0, w1;
         w0[0] = pack2bf(o0[qb][4 * i4 + 0] * inv, o0[qb][4 * i4 + 1] * inv);
         w0[1] = pack2bf(o0[qb][4 * i4 + 2] * inv, o0[qb][4 * i4 + 3] * inv);
         w1[0] = pack2bf(o1[qb][4 * i4 + 0] * inv, o1[qb][4 * i4 + 1] * inv);
         w1[1] = pack2bf(o1[qb][4 * i4 + 2] * inv, o1[qb][4 * i4 + 3] * inv);
-        *reinterpret_cast<u32x2*>(orow + d) = w0;
-        *reinterpret_cast<u32x2*>(orow + 32 + d) = w1;
+        *reinterpret_cast<u32x2*>(ob + row * 128 + ((i4 ^ sw) << 4) + 8 * h) = w0;            // d = 8 i4 + 4 h .. + 3
+        *reinterpret_cast<u32x2*>(ob + row * 128 + (((4 + i4) ^ sw) << 4) + 8 * h) = w1;      // d = 32 + 8 i4 + 4 h .. + 3
       }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's own writes (no other wave touches the slice)
+    const int lr = lane >> 3, lc = lane & 7;
+#pragma unroll
+    for (int pass = 0; pass < RW / 8; ++pass) {
+      const int row = pass * 8 + lr;
+      const int q = q0 + row;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ob + row * 128 + ((lc ^ ((row >> 1) & 7)) << 4));
+      if (q < q_end) *reinterpret_cast<u32x4*>(O + (g * o_rows + q) * ldo + hd * 64 + lc * 8) = v;
     }
   }
 }
@@ -958,8 +983,8 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
   VQ3_CHECK_ARG(head_dim == 64, "flash_attn_fwd: head_dim must be 64, got %d", head_dim);
   VQ3_CHECK_ARG(G > 0 && NH > 0 && N > 0, "flash_attn_fwd: bad shape");
   VQ3_CHECK_ARG((long)G * NH <= 65535, "flash_attn_fwd: too many (group, head) pairs");
-  VQ3_CHECK_ARG(ldo >= (long)NH * 64 && ldo % 4 == 0, "flash_attn_fwd: bad ldo");
-  VQ3_CHECK_ARG(((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) % 16 == 0 && (uintptr_t)O % 8 == 0, "flash_attn_fwd: misaligned operand");
+  VQ3_CHECK_ARG(ldo >= (long)NH * 64 && ldo % 8 == 0, "flash_attn_fwd: bad ldo (rows leave as 16-byte pieces: ldo %% 8 == 0)");
+  VQ3_CHECK_ARG(((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) % 16 == 0, "flash_attn_fwd: misaligned operand");
   static int qb_forced = -1;
   if (qb_forced < 0) { const char* e = getenv("VQ3_FLASH_QB"); qb_forced = e ? atoi(e) : 0; }
   // two query blocks per wave (every K / V fragment read feeds two MFMA chains) once there are enough rows to fill them
