@@ -152,7 +152,7 @@ def cpu_baseline(model, batch, L):
     return {"value": 1.0 / per_sample, "unit": "samples/s", "cores": nthreads, "kind": "port",
             "sample": ("1 whole sample, measured end to end (no extrapolation): VGGT %d+%d+%d blocks fwd (bf16, %d view(s)) + Perceiver fwd (fp32) + "
                        "Qwen3-4B %d layers + full-vocabulary lm_head + CE fwd+bwd (bf16, L=%d), torch autograd on the oracle; loss %.4f; parts(s)=%s"
-                       % (agg.dino_depth, agg.depth, agg.depth, V, cfg.num_hidden_layers, L, float(loss), {k: round(v, 2) for k, v in t_all.items()}))}
+                       % (agg.dino_depth, agg.depth, agg.depth, V, cfg.num_hidden_layers, L, float(loss.detach()), {k: round(v, 2) for k, v in t_all.items()}))}
 
 
 def self_launch(n: int) -> int:
