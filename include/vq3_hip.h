@@ -258,7 +258,9 @@ int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* qn_b, const 
                    int32_t head_dim, int32_t tokens_per_frame, int32_t patch_start, int32_t Wp, int32_t use_norm,
                    int32_t use_rope, float eps, void* stream);
 /* F.scaled_dot_product_attention(q, k, v), non-causal, head_dim 64: Q, K, V bf16 [G*NH, N, 64] (V as stored: the kernel
- * reads it transposed out of LDS) -> O bf16 token-major O[(g*N + n)*ldo + h*64 + d]. */
+ * reads it transposed out of LDS) -> O bf16 token-major O[(g*N + n)*ldo + h*64 + d]. Q, K, V, O 16-byte aligned, ldo % 8 == 0 (a head's
+ * 128 output bytes of a row leave as 16-byte pieces). Workgroups are placed so that the query blocks of one (group, head) pair - which
+ * walk the same K / V rows - run on ONE XCD and share its L2 (vggt.hip; VQ3_FLASH_XCD=0: the plain 2-D grid). */
 int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N,
                        int32_t head_dim, int64_t ldo, float scale, void* stream);
 /* The same for the first q_rows queries of every group only (keys / values: all N): O[(g*q_rows + n)*ldo + h*64 + d], n < q_rows.
