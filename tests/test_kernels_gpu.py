@@ -1000,3 +1000,46 @@ def test_gemm_v7_ln_fold_is_repeatable(ops):
                     assert torch.equal(a, b), (fn.__name__, it, float((a.float() - b.float()).abs().max()))
     finally:
         ops.gemm_force_config(-3)
+
+
+@pytest.mark.parametrize("cfg", [20, 21, 22, 24, 25, 30])
+def test_qwen_layer_is_repeatable_under_every_gemm_kernel(ops, cfg):
+    """The text model's launches under every NT kernel the tuner may pick (as tests/test_vggt_gpu.py does for the tower): two Qwen3-4B-width
+    layers, 1536 token rows (grids that over-subscribe two workgroups per CU on the wide outputs), forward + backward twice from the same
+    inputs - hidden states, d(inputs_embeds) and the projection / norm weight gradients must come out bit-identical (fixed summation orders
+    everywhere; only the scalar loss is an f32-atomic sum and is compared to 1e-6) and within bf16 rounding of cfg 20's."""
+    from vggt_qwen3_amd.qwen3 import Qwen3Config, Qwen3ForCausalLM
+    c = Qwen3Config.qwen3_4b(); c.num_hidden_layers = 2; c.vocab_size = 2048
+    tm = Qwen3ForCausalLM(c, device="cuda", seed=4)
+    g = torch.Generator().manual_seed(8)
+    B, L = 8, 192
+    emb = (torch.randn(B, L, c.hidden_size, generator=g) * 0.5).to(BF16).cuda()
+    mask = torch.ones(B, L, dtype=torch.long); mask[1, 100:] = 0; mask[5, 37:] = 0
+    labels = torch.full((B, L), -100, dtype=torch.long)
+    labels[:, 20:36] = torch.randint(0, 2048, (B, 16), generator=g)
+    mask, labels = mask.cuda(), labels.cuda()
+
+    def run():
+        h, saved = tm.forward_hidden(emb, mask, save=True)
+        loss, head = tm.loss_head(h, labels, save=True, L=saved["L"])
+        dh = tm.backward_loss_head(head, B * saved["L"], 1.0, accumulate=False)
+        d_emb = tm.backward_hidden(saved, dh, accumulate=False)
+        torch.cuda.synchronize()
+        return [h.clone(), d_emb.clone(), tm._g["l0.qkv"].clone(), tm._g["l1.gu"].clone(), tm._g["l1.down"].clone(), tm._g["l0.ln2"].clone()], float(loss)
+    try:
+        ops.gemm_force_config(20)
+        base, lb = run()
+        ops.gemm_force_config(cfg)
+        first, l1 = run()
+        for it in range(3):
+            again, l2 = run()
+            for k, (a, b) in enumerate(zip(again, first)):
+                assert torch.equal(a, b), (cfg, it, k, float((a.float() - b.float()).abs().max()))
+            assert abs(l2 - l1) <= 1e-6 * abs(l1)
+    finally:
+        ops.gemm_force_config(-3)
+    for k, (a, b) in enumerate(zip(first, base)):
+        assert torch.isfinite(a.float()).all()
+        assert ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item() < 2e-2, (cfg, k)
+    assert abs(l1 - lb) <= 2e-3 * abs(lb)
+    assert not ops.gemm_split_gave_up()
