@@ -1053,3 +1053,24 @@ def test_qwen_layer_is_repeatable_under_every_gemm_kernel(ops, cfg):
         assert ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item() < tol, (cfg, mode, k)
     assert abs(l1 - lb) <= (2e-2 if mode == "fp8" else 2e-3) * abs(lb)
     assert not ops.gemm_split_gave_up()
+
+
+def test_attention_kernels_are_repeatable(ops):
+    """Same inputs, same bits, launch after launch, on grids larger than the chip: the VGGT flash kernel at 8232 keys (VAR 1: QK of keys
+    32-63 under the exponentials of keys 0-31; XCD-aware placement) and at 1029 keys with the ragged-row workgroup, its leading-rows form,
+    and the Perceiver's one-launch cross-attention (dropout on: the mask is a pure function of seed / offset / element index)."""
+    g = torch.Generator().manual_seed(12)
+    for G, NH, N, nq in ((2, 16, 8232, None), (40, 16, 1029, None), (40, 16, 1029, 128)):
+        Q = torch.randn(G, NH, N, 64, generator=g).to(BF16).cuda()
+        K = torch.randn(G, NH, N, 64, generator=g).to(BF16).cuda()
+        V = torch.randn(G, NH, N, 64, generator=g).to(BF16).cuda()
+        ref = ops.flash_attn(Q, K, V, q_rows=nq).clone()
+        assert torch.isfinite(ref.float()).all()
+        for it in range(6):
+            assert torch.equal(ops.flash_attn(Q, K, V, q_rows=nq), ref), (G, N, nq, it)
+    B, H, N, T, hd = 48, 8, 128, 128, 512
+    q = torch.randn(B * N, H * hd, generator=g).to(BF16).cuda()
+    kv = torch.randn(B * T, 2 * H * hd, generator=g).to(BF16).cuda()
+    ref = ops.perceiver_xattn(q, kv, B, H, N, T, hd, 128, 0.1, 1234, 77).clone()
+    for it in range(6):
+        assert torch.equal(ops.perceiver_xattn(q, kv, B, H, N, T, hd, 128, 0.1, 1234, 77), ref), it
