@@ -1007,9 +1007,9 @@ def test_qwen_layer_is_repeatable_under_every_gemm_kernel(ops, cfg):
     """The text model's launches under every NT kernel the tuner may pick (as tests/test_vggt_gpu.py does for the tower), every schedule
     of the k-major (weight-gradient / dgrad) kernels (103 / 105: gemm3.hip; 106 / 107: the k-major 8-phase kernel without / with the
     last-round split), the e4m3 projections ("fp8") and the W^T dgrad route ("wt"): two Qwen3-4B-width layers, 1536 token rows (grids
-    that over-subscribe two workgroups per CU on the wide outputs), forward + backward twice from the same inputs - hidden states,
-    d(inputs_embeds) and the projection / norm weight gradients must come out bit-identical (fixed summation orders everywhere; only the
-    scalar loss is an f32-atomic sum and is compared to 1e-6) and within bf16 (e4m3: 8e-2) rounding of the plain cfg 20 run."""
+    that over-subscribe two workgroups per CU on the wide outputs), forward + backward four times from the same inputs - the hidden
+    states must come out bit-identical, d(inputs_embeds) and the weight gradients within 1e-3 (see below), the scalar loss (an f32-atomic
+    sum) within 1e-6, and everything within bf16 (e4m3: 8e-2) rounding of the plain cfg 20 run."""
     from vggt_qwen3_amd.qwen3 import Qwen3Config, Qwen3ForCausalLM
     c = Qwen3Config.qwen3_4b(); c.num_hidden_layers = 2; c.vocab_size = 2048
     tm = Qwen3ForCausalLM(c, device="cuda", seed=4)
@@ -1042,8 +1042,13 @@ def test_qwen_layer_is_repeatable_under_every_gemm_kernel(ops, cfg):
         first, l1 = run()
         for it in range(3):
             again, l2 = run()
-            for k, (a, b) in enumerate(zip(again, first)):
-                assert torch.equal(a, b), (cfg, it, k, float((a.float() - b.float()).abs().max()))
+            # forward: bit for bit. Backward: the lm_head's input-gradient product (M = labelled rows, K = vocabulary) meets its K slices
+            # through f32 atomics (qwen3.py: backward_loss_head, ksplit) - the one place of the layer stack whose f32 summation ORDER is
+            # not fixed - so everything downstream may move by a bf16 ulp here and there: 1e-3 relative, no more
+            assert torch.equal(again[0], first[0]), (cfg, it, float((again[0].float() - first[0].float()).abs().max()))
+            for k, (a, b) in enumerate(zip(again[1:], first[1:])):
+                e = ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+                assert e < 1e-3, (cfg, it, k + 1, e)
             assert abs(l2 - l1) <= 1e-6 * abs(l1)
     finally:
         ops.gemm_force_config(-3)

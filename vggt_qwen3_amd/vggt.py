@@ -353,8 +353,7 @@ class Aggregator(nn.Module):
         # [camera | register | patch tokens]: frame 0 takes slot 0 of the learned tokens, the other frames slot 1
         cam, reg = self.p("camera_token").detach()[0], self.p("register_token").detach()[0]   # [2,1,C], [2,4,C]
         sp = torch.cat([cam, reg], dim=1)                                                     # [2, 5, C]
-        sel = torch.ones(S, dtype=torch.long, device=dev)
-        sel[0] = 0
+        sel = (torch.arange(S, device=dev) != 0).long()         # frame 0 -> slot 0, the others -> slot 1 (no host scalar: capturable)
         xv = x.view(B, S, P, C)
         xv[:, :, : self.patch_start_idx] = sp[sel][None]
         rope = self._rope_tables(max(Hp, Wp))
