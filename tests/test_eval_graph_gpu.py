@@ -1,4 +1,5 @@
-"""Eval-mode forwards replay HIP graphs of their two static parts (vlm.py: _graph_call; round 5): the tower + projector for an image
+"""OPT-IN (model.eval_graphs / VQ3_EVAL_GRAPH=1; measured slower than stream launches for this path, see vlm.py): eval-mode forwards
+replay HIP graphs of their two static parts (vlm.py: _graph_call; round 5): the tower + projector for an image
 shape, the decoder layers for a (B, L). The reference's unit is VGGTQwen3VLM.forward under no_grad / .eval()
 (/root/reference/src/models/vggt_qwen3_vlm.py:179-201, as its evaluation callers use it). Checked here: graph replay gives the eager
 forward's loss for every batch (inputs are copied into the graph's static buffers), a changed weight is seen, replaced derived tensors

@@ -1051,7 +1051,7 @@ def test_qwen_layer_is_repeatable_under_every_gemm_kernel(ops, cfg):
             assert torch.equal(again[0], first[0]), (cfg, it, float((again[0].float() - first[0].float()).abs().max()))
             for k, (a, b) in enumerate(zip(again[1:], first[1:])):
                 e = ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
-                assert e < 1e-2, (cfg, it, k + 1, e)
+                assert e < (6e-2 if mode == "fp8" else 1e-2), (cfg, mode, it, k + 1, e)      # (e4m3: a flipped rounding of dY is a 6 % step)
             assert abs(l2 - l1) <= 1e-6 * abs(l1)
     finally:
         ops.gemm_force_config(-3)

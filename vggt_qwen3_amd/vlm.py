@@ -210,10 +210,14 @@ class VGGTQwen3VLM(nn.Module):
             self.text_model.enable_fp8_forward(True)
         self._vis_stream = None
         self._vision_head = os.environ.get("VQ3_VISION_HEAD", "1") != "0"
-        # eval-mode forwards (no_grad, .eval(): the reference's inference / evaluation callers) replay HIP graphs of their two static parts -
-        # the tower + projector for an image shape, the 36 decoder layers for a (B, L) - captured at the second sight of a shape; the
-        # data-dependent glue between them (splice map, labelled rows, loss) stays eager. VQ3_EVAL_GRAPH=0 / model.eval_graphs = False: off
-        self.eval_graphs = os.environ.get("VQ3_EVAL_GRAPH", "1") != "0"
+        # OPT-IN (VQ3_EVAL_GRAPH=1 / model.eval_graphs = True; default off): eval-mode forwards (no_grad, .eval(): the reference's
+        # inference / evaluation callers) replay HIP graphs of their two static parts - the tower + projector for an image shape, the 36
+        # decoder layers for a (B, L) - captured at the second sight of a shape; the data-dependent glue between them (splice map,
+        # labelled rows, loss) stays eager. Measured (round 5, bench.py forward_only): SLOWER than stream launches - 40.7 against 34.3 ms
+        # per 6-sample forward, 195.3 against 190.5 ms at 48 samples: these ~750 kernels are 20-400 us each, the host is far ahead of the
+        # device, and a hipGraph launch serialises the tower's two-stream row-tail chains; graphs pay where the host is the bottleneck
+        # (the decode step, generate.py), not here. Kept because it is exact and tested (tests/test_eval_graph_gpu.py).
+        self.eval_graphs = os.environ.get("VQ3_EVAL_GRAPH", "0") == "1"
         self._graphs = {}             # key -> [sightings, graph, static inputs, static output]
         self._graph_stream = None
         self._prefetched = None
