@@ -770,6 +770,19 @@ class Qwen3ForCausalLM(nn.Module):
             self._wd_count = 0
         return dh
 
+    @staticmethod
+    def _lm_dgrad_slices(Vp: int, ntile: int) -> int:
+        """K slices of the lm_head's input-gradient product: the divisor of Vp / 64 (slices stay whole 64-element K tiles) nearest to one
+        workgroup per CU for `ntile` output tiles; 1 = no such divisor (the f32-atomic split takes over; VQ3_LMHEAD_DGRAD_ATOMIC=1 forces it)."""
+        if os.environ.get("VQ3_LMHEAD_DGRAD_ATOMIC") == "1" or Vp % 64:
+            return 1
+        q = Vp // 64
+        want = max(2, min(64, 256 // max(1, ntile)))
+        divs = [d for d in range(2, min(q, 128) + 1) if q % d == 0]
+        if not divs:
+            return 1
+        return min(divs, key=lambda d: (abs(d - want), d))
+
     def backward_loss_head(self, head_ctx, rows: int, gscale: float, accumulate: bool) -> torch.Tensor:
         """Backward of loss_head: returns d(loss)/d(h_last) [rows, H] (zero on rows without a label) and writes the
         lm_head contribution to the tied embedding gradient."""
@@ -782,9 +795,19 @@ class Qwen3ForCausalLM(nn.Module):
         dE = self.flat_g[self.table["embed"][0]: self.table["embed"][0] + Vp * H].view(Vp, H)
         # d(hn)[n8, H] = dlogits[n8, Vp] . E[Vp, H]       (E: k-major B; pad rows/cols are zero on both sides)
         # n8 is a handful of rows and K = 152 000: split the contraction over ~one workgroup per CU
-        d_hn32 = torch.zeros((n8, H), device=dev, dtype=F32)
         ntile = ((n8 + 127) // 128) * ((H + 127) // 128)
-        ops.gemm_raw(dlog, E, d_hn32, n8, H, Vp, Vp, H, H, alpha=gscale, transB=True, ksplit=max(2, 256 // ntile))
+        S = self._lm_dgrad_slices(Vp, ntile)
+        if S > 1:
+            # K slices as a BATCHED product into f32 slabs [S, n8, H], summed in slice order (vq3_colsum_f32): no atomics, so the whole
+            # backward is a fixed sequence of f32 sums - the same bits run after run (round 5; the atomic split below let a 1e-7
+            # difference here grow into bf16-ulp noise on every gradient downstream). S * n8 * H * 4 B of slab: 20-40 MB per pass.
+            Ks = Vp // S
+            slabs = torch.empty((S, n8 * H), device=dev, dtype=F32)
+            ops.gemm_raw(dlog, E, slabs, n8, H, Ks, Vp, H, H, alpha=gscale, transB=True, nb1=S, sA=(Ks, 0), sB=(Ks * H, 0), sC=(n8 * H, 0))
+            d_hn32 = ops.colsum_f32(slabs).view(n8, H)
+        else:
+            d_hn32 = torch.zeros((n8, H), device=dev, dtype=F32)
+            ops.gemm_raw(dlog, E, d_hn32, n8, H, Vp, Vp, H, H, alpha=gscale, transB=True, ksplit=max(2, 256 // ntile))
         d_hn = ops.cast(d_hn32, BF16)
         # dE[Vp, H] (+)= dlogits^T[Vp, n8] . hn[n8, H]    (both k-major; contraction = the n8 selected rows)
         ops.gemm_raw(dlog, head_ctx["hn"], dE, Vp, H, n8, Vp, H, H, accumulate=accumulate, alpha=gscale, transA=True,
