@@ -1028,7 +1028,8 @@ def test_qwen_layer_is_repeatable_under_every_gemm_kernel(ops, cfg):
         dh = tm.backward_loss_head(head, B * saved["L"], 1.0, accumulate=False)
         d_emb = tm.backward_hidden(saved, dh, accumulate=False)
         torch.cuda.synchronize()
-        return [h.clone(), d_emb.clone(), tm._g["l0.qkv"].clone(), tm._g["l1.gu"].clone(), tm._g["l1.down"].clone(), tm._g["l0.ln2"].clone()], float(loss)
+        return [h.clone(), d_emb.clone(), tm._g["l0.qkv"].clone(), tm._g["l1.gu"].clone(), tm._g["l1.down"].clone(), tm._g["l0.ln2"].clone(),
+                tm._g["l0.qn"].clone(), tm._g["l1.kn"].clone(), tm._g["embed"][:2048].clone(), tm._g["norm"].clone()], float(loss)
     try:
         ops.gemm_force_config(20)
         base, lb = run()

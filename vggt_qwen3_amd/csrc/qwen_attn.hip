@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
                                                          int Hq, int Hkv, int kv_parts, long part_stride, long T) {
   // VQ3_QKPREP_BWD_TOKENS_PER_PART tokens per workgroup: the norm-weight partials of a workgroup's tokens are summed in registers and
   // meet in LDS once (one zeroing, one round of LDS atomics, two barriers and one partial row per 8 tokens instead of per token: kernel 150 -> 114-118 us cold at 9600 tokens, the two column sums 2 x 50 -> 2 x 5-14 us)
-  __shared__ float dw_s[2][D];
+  // (round 5: the eight half-waves' partials meet in LDS in a FIXED order - slot per half-wave, summed 0..7 - instead of through LDS float
+  // atomics: the q_norm / k_norm weight gradients were the last run-to-run difference of a training step's gradients)
+  __shared__ float dw_s[8][2][D];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int j = lane & 31, half = lane >> 5;
   const int e = 2 * j;
-  if (threadIdx.x < 2 * D) (&dw_s[0][0])[threadIdx.x] = 0.f;
-  __syncthreads();
   const int HT = Hq + 2 * Hkv;
   float aq1[2] = {0.f, 0.f}, aq2[2] = {0.f, 0.f}, ak1[2] = {0.f, 0.f}, ak2[2] = {0.f, 0.f};
   float wq1[2], wq2[2], wk1[2], wk2[2];
@@ -193,19 +193,22 @@ __global__ __launch_bounds__(256) void qkprep_bwd_kernel(const bf16_t* __restric
     }
   }
   }   // tokens of this workgroup
+  const int hw = 2 * wid + half;                   // this half-wave's slot: it covers all D features (lane j: e, e+1, e+64, e+65)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    atomicAdd(&dw_s[0][e + u], aq1[u]);
-    atomicAdd(&dw_s[0][e + u + 64], aq2[u]);
-    atomicAdd(&dw_s[1][e + u], ak1[u]);
-    atomicAdd(&dw_s[1][e + u + 64], ak2[u]);
+    dw_s[hw][0][e + u] = aq1[u];
+    dw_s[hw][0][e + u + 64] = aq2[u];
+    dw_s[hw][1][e + u] = ak1[u];
+    dw_s[hw][1][e + u + 64] = ak2[u];
   }
   __syncthreads();
   // plain-store partial rows [workgroup][D] (summed by vq3_colsum_f32_to_bf16): no contended global atomics
-  if (threadIdx.x < D) {
-    dq_w[(long)blockIdx.x * D + threadIdx.x] = dw_s[0][threadIdx.x];
-  } else {
-    dk_w[(long)blockIdx.x * D + threadIdx.x - D] = dw_s[1][threadIdx.x - D];
+  {
+    const int which = threadIdx.x < D ? 0 : 1, x = threadIdx.x < D ? threadIdx.x : threadIdx.x - D;
+    float v = dw_s[0][which][x];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) v += dw_s[i][which][x];
+    (which ? dk_w : dq_w)[(long)blockIdx.x * D + x] = v;
   }
 }
 
