@@ -213,6 +213,16 @@ constexpr float FA_THR = 6.0f;
 #ifndef FA_QK_OVERLAP
 #define FA_QK_OVERLAP 1
 #endif
+#ifndef FA_PRIO
+#define FA_PRIO 0      // 1: s_setprio 1 around the MFMA bursts (experiment: make EXTRA=-DFA_PRIO=1)
+#endif
+#if FA_PRIO
+#define FA_PRIO_HI() __builtin_amdgcn_s_setprio(1)
+#define FA_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define FA_PRIO_HI() ((void)0)
+#define FA_PRIO_LO() ((void)0)
+#endif
 #ifndef FA_QK_HINT
 #define FA_QK_HINT 0
 #endif
@@ -669,6 +679,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   do {                                                                                                                  \
     const u32x4 ta = {va[BUFI][0][0], va[BUFI][0][1], va[BUFI][1][0], va[BUFI][1][1]};                                  \
     const u32x4 tb = {vb[BUFI][0][0], vb[BUFI][0][1], vb[BUFI][1][0], vb[BUFI][1][1]};                                  \
+    FA_PRIO_HI();                                                                                                       \
     _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                                 \
       bf16x8 pf;                                                                                                        \
       _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                     \
@@ -677,6 +688,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1[qb], 0, 0, 0);            \
       if (LSUM) lacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf, lacc[qb], 0, 0, 0);                       \
     }                                                                                                                   \
+    FA_PRIO_LO();                                                                                                       \
   } while (0)
     // one MFMA, then a few of the next chunk's VALU instructions, ... (scheduler hint for the region up to the next wait)
 #define FA_MIX()                                                                                                        \
