@@ -223,6 +223,12 @@ constexpr float FA_THR = 6.0f;
 #define FA_PRIO_HI() ((void)0)
 #define FA_PRIO_LO() ((void)0)
 #endif
+#ifndef FA_DMA
+#define FA_DMA 1       // K / V tiles by LDS-DMA (0: through staging registers, round 2-4's form)
+#endif
+#ifndef FA_LSUM_VAR1
+#define FA_LSUM_VAR1 0 // 1: row sums on the matrix pipe in the VAR 1 kernel too (spills 8 registers even with the DMA staging: off)
+#endif
 #ifndef FA_QK_HINT
 #define FA_QK_HINT 0
 #endif
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   // of the query's lane (both half-waves: the MFMA sums over all 16 keys of the chunk) - the sums of the bf16-rounded P, i.e. exactly the
   // weights the numerator uses. PMC (profiles/r3_flash_pmc.txt): the VALU is the busier pipe of this kernel (61 % against 43 %) and the
   // two overlap little; this moves 68 of ~300 vector instructions per tile (the adds + the cross-half exchange) to 8 MFMAs.
-  constexpr bool LSUM = FA_LSUM_MFMA && QB == 2 && VAR == 0;      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
+  constexpr bool LSUM = FA_LSUM_MFMA && QB == 2 && (VAR == 0 || FA_LSUM_VAR1);      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
   f32x16 lacc[LSUM ? QB : 1];
   bf16x8 ones8;
 #pragma unroll
@@ -491,6 +497,34 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   const int nt = (N + FA_KV - 1) / FA_KV;
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Kb), 0, N * 128, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Vb), 0, N * 128, 0x00020000);
+#if FA_DMA
+  // K / V tiles go global -> LDS directly (buffer_load ... lds: 1 KiB per wave instruction = 8 rows of 128 B, lane p writes position p):
+  // no staging registers, no LDS store instructions. The images' XOR swizzles move to the SOURCE side - position c of row r holds data
+  // chunk c ^ s(r) - and the tile still advances through the scalar offset; rows past N read as zero through the descriptor.
+  int goffK[NS], goffV[NS];                 // per-lane byte offsets into the (sample, head)'s K / V
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int row = srow0 + RSTEP * i;
+    goffK[i] = row * 128 + ((sch ^ ((row >> 1) & 7)) << 4);
+    goffV[i] = row * 128 + ((sch ^ (((row >> 1) & 1) << 2)) << 4);
+  }
+  const int wrow0 = (tid >> 6) * 8;         // first row of this wave's 8-row piece (step i: + RSTEP * i)
+  auto dma_tile = [&](int t, int buf) {
+    const int soff = t * (FA_KV * 128);
+    char* sb = smem + buf * (2 * FA_KV * 128);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass of hipcc has no such builtin: with it in sight the kernel's launch stub is silently dropped)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(sb + (wrow0 + RSTEP * i) * 128), 16, goffK[i], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(sb + FA_KV * 128 + (wrow0 + RSTEP * i) * 128), 16, goffV[i], soff, 0, 0);
+#else
+      (void)sb; (void)soff; (void)goffK[i]; (void)goffV[i]; (void)rsK; (void)rsV; (void)wrow0;
+#endif
+    }
+  };
+  auto load_tile = [&](int t, int buf) { dma_tile(t, buf); };
+  auto store_tile = [&](int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };      // this wave's pieces have landed (the barrier publishes them)
+#else
   u32x4 kreg[NS], vreg[NS];
   int goff[NS], kst[NS], vst[NS];          // per-lane byte offsets: in the (sample, head)'s K / V, in the LDS K image, in the LDS V image
 #pragma unroll
@@ -500,7 +534,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     kst[i] = fa_swz(row, sch);
     vst[i] = FA_KV * 128 + fa_vswz(row, sch);
   }
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t, int) {
     const int soff = t * (FA_KV * 128);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -516,6 +550,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       *reinterpret_cast<u32x4*>(sb + vst[i]) = vreg[i];
     }
   };
+#endif
   int koff0[4], koff1[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -534,7 +569,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
 
   // Prologue: the first K / V tile AND the Q rows are requested together (two independent round trips in flight at once; the Q rows
   // used to be loaded, waited for and converted before the first tile was even requested: ~1 us of a 25 us workgroup at N = 1029)
-  load_tile(0);
+  load_tile(0, 0);
   // Q' fragments (B operand): lane (r,h) holds Q'[q0 + 32 qb + r][16 s + 8 h .. +8]
   bf16x8 qf[QB][4];
 #pragma unroll
@@ -563,7 +598,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     const bool more = t + 1 < nt;
     const char* sb = smem + STG * (2 * FA_KV * 128);
     const unsigned sbase = lds_base + (unsigned)(STG * (2 * FA_KV * 128));
-    if (more) load_tile(t + 1);
+    if (more) load_tile(t + 1, STG ^ 1);
     if (active) {
     // ---- S^T = K . Q'^T - m
     f32x16 s0[QB], s1[QB];
@@ -756,7 +791,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     const bool more = t + 1 < nt;
     const char* sb = smem + STG * (2 * FA_KV * 128);
     const unsigned sbase = lds_base + (unsigned)(STG * (2 * FA_KV * 128));
-    if (more) load_tile(t + 1);
+    if (more) load_tile(t + 1, STG ^ 1);
     if (active) {
       f32x16 s0[QB], s1[QB];
       u32x2 va[2][2], vb[2][2];
