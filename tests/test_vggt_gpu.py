@@ -395,3 +395,25 @@ def test_tower_forward_is_repeatable_under_every_gemm_kernel(cfg):
     assert torch.isfinite(first.float()).all()
     assert ((first.float() - base.float()).norm() / base.float().norm()).item() < 5e-3, cfg
     assert not ops.gemm_split_gave_up()
+
+
+@pytest.mark.parametrize("N,nq", [(1029, None), (541, None), (8232, None), (1029, 128), (21, None)])
+def test_flash_attention_does_not_read_past_the_last_row(N, nq):
+    """K / V rows of the last, partly filled 64-key tile lie past N: for every (sample, head) pair but the last they are the NEXT pair's
+    rows, for the last pair they are whatever follows the tensors in memory. They must never reach the result (the buffer descriptor's
+    range check returns zeros for them, and their scores are masked): Q, K and V here are views at the front of larger allocations whose
+    remainder is NaN, and the output must be finite and equal to the run on exact-size tensors."""
+    from vggt_qwen3_amd import ops
+    G, NH = 2, 16
+    g = torch.Generator().manual_seed(N)
+    n = G * NH * N * 64
+    base = [torch.randn(n, generator=g).to(BF16).cuda() for _ in range(3)]
+    want = ops.flash_attn(*[t.view(G, NH, N, 64) for t in base], q_rows=nq).clone()
+    padded = []
+    for t in base:
+        big = torch.full((n + 64 * 64 * 4,), float("nan"), dtype=BF16, device="cuda")
+        big[:n].copy_(t)
+        padded.append(big[:n].view(G, NH, N, 64))
+    got = ops.flash_attn(*padded, q_rows=nq)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, want)
