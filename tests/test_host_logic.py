@@ -397,3 +397,46 @@ def test_trainer_pass_sizes_cut_a_window_into_equal_passes():
         for cap in (1, 3, 8, 10, 16):
             p = passes(w, cap)
             assert sum(p) == w and max(p) - min(p) <= 1 and len(p) == -(-w // cap)
+
+
+def test_lm_head_dgrad_slice_rule():
+    """qwen3.py: _lm_dgrad_slices - K slices of the lm_head's input-gradient product are whole 64-element K tiles (a divisor of Vp / 64),
+    near one workgroup per CU; no such divisor (or VQ3_LMHEAD_DGRAD_ATOMIC=1) -> 1 = the f32-atomic split takes over."""
+    import os
+    from vggt_qwen3_amd.qwen3 import Qwen3ForCausalLM as Q
+    for Vp, ntile in ((152000, 40), (152000, 20), (2048, 20), (320, 2), (151936, 40), (64 * 97, 4)):
+        S = Q._lm_dgrad_slices(Vp, ntile)
+        assert S >= 1 and (S == 1 or (Vp % (64 * S) == 0 and S <= 128)), (Vp, ntile, S)
+    assert Q._lm_dgrad_slices(152000, 40) == 5 and Q._lm_dgrad_slices(2048, 20) == 8
+    assert Q._lm_dgrad_slices(64 * 97, 4) in (1, 97)          # a prime number of K tiles: one slice per tile, or none
+    assert Q._lm_dgrad_slices(100, 4) == 1                     # not a multiple of 64
+    os.environ["VQ3_LMHEAD_DGRAD_ATOMIC"] = "1"
+    try:
+        assert Q._lm_dgrad_slices(152000, 40) == 1
+    finally:
+        del os.environ["VQ3_LMHEAD_DGRAD_ATOMIC"]
+
+
+def test_bench_self_launch_command_line(monkeypatch):
+    """bench.py: self_launch - `python bench.py --gpus N` without WORLD_SIZE becomes `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node=N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` as a CHILD process (never an exec)."""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("vq3_bench_cpu", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "8"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-5:] == [str(root / "bench.py"), "--gpus", "4", "--steps", "8"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
