@@ -229,6 +229,30 @@ constexpr float FA_THR = 6.0f;
 #ifndef FA_LSUM_VAR1
 #define FA_LSUM_VAR1 0 // 1: row sums on the matrix pipe in the VAR 1 kernel too (spills 8 registers even with the DMA staging: off)
 #endif
+#ifndef FA_LSUM4
+#define FA_LSUM4 0     // row sums on the matrix pipe by v_mfma_f32_4x4x4_16b_bf16 (16 blocks of 4 x 4, A = ones: every lane gets the sum of the
+#endif                 // four bf16 values IT supplied as B): two 8-cycle instructions and 4 accumulator registers per 16-key chunk and query
+                       // block where the 32 x 32 x 16 form takes one 32-cycle instruction and 16 registers. Bit mask: 1 = VAR 1, 2 = VAR 0, 4 = QB 1
+#ifndef FA_PKSUM
+#define FA_PKSUM 1     // VALU row sums (the kernels without the matrix-pipe sums) as v_pk_add_f32: two exponentials per add instruction
+#endif
+#ifndef FA_X
+#define FA_X 0         // diagnostic builds only (wrong results): 1 the exponentials become multiplies, 2 no row sums, 3 no growth scan
+#endif
+#if FA_X == 1
+#define FA_EXP2(x) ((x) * 1.0009765625f)
+#else
+#define FA_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+#ifndef FA_MIXMODE
+#define FA_MIXMODE 2   // P.V sections: 0 = hint "one MFMA, six VALU, ...", 1 = no hint, 2 = hint "the MFMAs first, then the VALU work"
+#endif
+#ifndef FA_PHASED
+#define FA_PHASED 0    // bit 0: steady-state tile of the VAR 1 kernel = all exponentials, then all P.V MFMAs (0: the interleaved order); bit 1: the same in tile_body
+#endif
+#ifndef FA_PIN_EXP
+#define FA_PIN_EXP 0
+#endif
 #ifndef FA_QK_HINT
 #define FA_QK_HINT 0
 #endif
@@ -468,8 +492,14 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   // of the query's lane (both half-waves: the MFMA sums over all 16 keys of the chunk) - the sums of the bf16-rounded P, i.e. exactly the
   // weights the numerator uses. PMC (profiles/r3_flash_pmc.txt): the VALU is the busier pipe of this kernel (61 % against 43 %) and the
   // two overlap little; this moves 68 of ~300 vector instructions per tile (the adds + the cross-half exchange) to 8 MFMAs.
-  constexpr bool LSUM = FA_LSUM_MFMA && QB == 2 && (VAR == 0 || FA_LSUM_VAR1);      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
+  constexpr bool LSUM4 = (QB == 2 && VAR == 1 && (FA_LSUM4 & 1)) || (QB == 2 && VAR == 0 && (FA_LSUM4 & 2)) || (QB == 1 && (FA_LSUM4 & 4));
+  constexpr bool LSUM = !LSUM4 && FA_LSUM_MFMA && QB == 2 && (VAR == 0 || FA_LSUM_VAR1);      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
+  constexpr bool MSUM = LSUM || LSUM4;                     // row sums on the matrix pipe (either form): no VALU partial sums
   f32x16 lacc[LSUM ? QB : 1];
+  f32x4 lacc4[LSUM4 ? QB : 1];
+  bf16x4 ones4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ones4[j] = (short)0x3F80;
   bf16x8 ones8;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones8[j] = (short)0x3F80;
@@ -485,6 +515,10 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     if (LSUM) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) lacc[qb][i] = 0.f;
+    }
+    if (LSUM4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lacc4[qb][i] = 0.f;
     }
   }
 
@@ -686,6 +720,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
           o0[qb][i] *= alpha; o1[qb][i] *= alpha;
           s0[qb][i] -= adv; s1[qb][i] -= adv;
           if (LSUM) lacc[qb][i] *= alpha;
+          if (LSUM4 && i < 4) lacc4[qb][i] *= alpha;
         }
         if (NEGM) {
 #pragma unroll
@@ -698,15 +733,25 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     // ---- P^T = exp2(S^T) in four chunks of 16 keys, O^T += V^T . P^T chunk by chunk: the exponentials of chunk u + 1 sit between
     // the MFMAs of chunk u (an MFMA holds the SIMD's issue port for 8 of its 32 cycles: the VALU work rides in the other 24), and
     // the V^T fragments of step u + 1 are in flight while step u multiplies
-    float ps[QB];
+    f32x2_t ps[QB];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) ps[qb] = 0.f;
+    for (int qb = 0; qb < QB; ++qb) ps[qb] = f32x2_t{0.f, 0.f};
+#if FA_PKSUM
+#define FA_PSADD(P, A, B) (P) += f32x2_t{(A), (B)}
+#define FA_PSADD4(P, A, B, C, D) (P) += (f32x2_t{(A), (B)} + f32x2_t{(C), (D)})     /* half the dependent adds on the accumulator */
+#else
+#define FA_PSADD(P, A, B) (P)[0] += (A) + (B)
+#define FA_PSADD4(P, A, B, C, D) (P)[0] += ((A) + (B)) + ((C) + (D))
+#endif
 #define FA_EXP(U)                                                                                                       \
   do {                                                                                                                  \
     _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                                 \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                   \
-        if ((U) < 2) { s0[qb][8 * ((U) & 1) + j] = __builtin_amdgcn_exp2f(s0[qb][8 * ((U) & 1) + j]); if (!LSUM) ps[qb] += s0[qb][8 * ((U) & 1) + j]; } \
-        else { s1[qb][8 * ((U) & 1) + j] = __builtin_amdgcn_exp2f(s1[qb][8 * ((U) & 1) + j]); if (!LSUM) ps[qb] += s1[qb][8 * ((U) & 1) + j]; }         \
+      _Pragma("unroll") for (int j = 0; j < 8; j += 4) {                                                                \
+        constexpr int e_ = 8 * ((U) & 1);                                                                               \
+        if ((U) < 2) { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) s0[qb][e_ + j + jj] = FA_EXP2(s0[qb][e_ + j + jj]);              \
+                       if (!MSUM && FA_X != 2) FA_PSADD4(ps[qb], s0[qb][e_ + j], s0[qb][e_ + j + 1], s0[qb][e_ + j + 2], s0[qb][e_ + j + 3]); } \
+        else { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) s1[qb][e_ + j + jj] = FA_EXP2(s1[qb][e_ + j + jj]);                      \
+               if (!MSUM && FA_X != 2) FA_PSADD4(ps[qb], s1[qb][e_ + j], s1[qb][e_ + j + 1], s1[qb][e_ + j + 2], s1[qb][e_ + j + 3]); }   \
       }                                                                                                                 \
     }                                                                                                                   \
   } while (0)
@@ -722,10 +767,15 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), pf, o0[qb], 0, 0, 0);            \
       o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1[qb], 0, 0, 0);            \
       if (LSUM) lacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf, lacc[qb], 0, 0, 0);                       \
+      if (LSUM4) {                                                                                                      \
+        lacc4[qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, bf16x4{pf[0], pf[1], pf[2], pf[3]}, lacc4[qb], 0, 0, 0); \
+        lacc4[qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, bf16x4{pf[4], pf[5], pf[6], pf[7]}, lacc4[qb], 0, 0, 0); \
+      }                                                                                                                 \
     }                                                                                                                   \
     FA_PRIO_LO();                                                                                                       \
   } while (0)
     // one MFMA, then a few of the next chunk's VALU instructions, ... (scheduler hint for the region up to the next wait)
+#if FA_MIXMODE == 0
 #define FA_MIX()                                                                                                        \
   do {                                                                                                                  \
     _Pragma("unroll") for (int g = 0; g < 2 * QB; ++g) {                                                                \
@@ -733,6 +783,46 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);                                                                \
     }                                                                                                                   \
   } while (0)
+#elif FA_MIXMODE == 1
+#define FA_MIX() ((void)0)
+#elif FA_MIXMODE == 2
+#define FA_MIX()                                                                                                        \
+  do {                                                                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3 * QB, 0);                                                             \
+    __builtin_amdgcn_sched_group_barrier(0x006, 64, 0);                                                                 \
+  } while (0)
+#elif FA_MIXMODE == 3
+#define FA_MIX()                                                                                                        \
+  do {                                                                                                                  \
+    _Pragma("unroll") for (int g = 0; g < QB; ++g) {                                                                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                                \
+      __builtin_amdgcn_sched_group_barrier(0x006, 12, 0);                                                               \
+    }                                                                                                                   \
+  } while (0)
+#else
+#define FA_MIX()                                                                                                        \
+  do {                                                                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x006, 64, 0);                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 3 * QB, 0);                                                             \
+  } while (0)
+#endif
+#if FA_PHASED & 2
+    FA_EXP(0);
+    FA_VISSUE(1, 1);
+    FA_EXP(1);
+    FA_EXP(2);
+    FA_EXP(3);
+    FA_VWAIT(0, 4);
+    FA_PV(0, 0);
+    FA_VISSUE(2, 0);
+    FA_VWAIT(1, 4);
+    FA_PV(1, 1);
+    FA_VISSUE(3, 1);
+    FA_VWAIT(0, 4);
+    FA_PV(2, 0);
+    FA_VWAIT(1, 0);
+    FA_PV(3, 1);
+#else
     FA_EXP(0);
     FA_VISSUE(1, 1);
     FA_VWAIT(0, 4);
@@ -751,10 +841,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     FA_MIX();
     FA_VWAIT(1, 0);
     FA_PV(3, 1);
-    if (!LSUM) {
+#endif
+    if (!MSUM) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps[qb]), __float_as_uint(ps[qb]), false, false);
+        const float pst = ps[qb][0] + ps[qb][1];
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(pst), __float_as_uint(pst), false, false);
         l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
       }
     }
@@ -770,7 +862,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         m_run[qb] += adv;
         l_run[qb] *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; if (LSUM4 && i < 4) lacc4[qb][i] *= alpha; }
         if (NEGM) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) negm[qb][i] = -m_run[qb];
@@ -820,16 +912,27 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         for (int qb = 0; qb < QB; ++qb) s1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kg, qf[qb][sidx], s1[qb], 0, 0, 0);
       }
       int mi[QB];
-      float ps[QB];
+      f32x2_t ps[QB];
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        ps[qb] = 0.f;
+        ps[qb] = f32x2_t{0.f, 0.f};
         mi[qb] = max(__float_as_int(s0[qb][0]), __float_as_int(s0[qb][1]));
 #pragma unroll
-        for (int i = 2; i < 16; i += 2) mi[qb] = max(max(mi[qb], __float_as_int(s0[qb][i])), __float_as_int(s0[qb][i + 1]));
+        for (int i = 2; i < (FA_X == 3 ? 2 : 16); i += 2) mi[qb] = max(max(mi[qb], __float_as_int(s0[qb][i])), __float_as_int(s0[qb][i + 1]));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[qb][i] = __builtin_amdgcn_exp2f(s0[qb][i]); if (!LSUM) ps[qb] += s0[qb][i]; }
+        for (int i = 0; i < 16; i += 4) {
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii) s0[qb][i + ii] = FA_EXP2(s0[qb][i + ii]);
+          if (!MSUM && FA_X != 2) FA_PSADD4(ps[qb], s0[qb][i], s0[qb][i + 1], s0[qb][i + 2], s0[qb][i + 3]);
+        }
       }
+#if FA_PIN_EXP
+      // The exponentials above must be ISSUED here, among the MFMAs of keys 32-63: the textbook-order branch below recomputes s0, which
+      // makes them dead on that path, and LLVM then sinks all 32 of them into the fast path's successor block - a stretch of pure VALU
+      // work with the matrix pipe idle (the overlap this tile form exists for was not in the generated code).
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) asm volatile("" : "+v"(s0[qb]));
+#endif
 #if FA_QK_HINT
 #pragma unroll
       for (int gidx = 0; gidx < 4 * QB; ++gidx) {           // one MFMA, then six of the 24 VALU instructions per MFMA, ...
@@ -845,7 +948,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) mi[qb] = max(max(mi[qb], __float_as_int(s1[qb][i])), __float_as_int(s1[qb][i + 1]));
+        for (int i = 0; i < (FA_X == 3 ? 2 : 16); i += 2) mi[qb] = max(max(mi[qb], __float_as_int(s1[qb][i])), __float_as_int(s1[qb][i + 1]));
         const auto sw = __builtin_amdgcn_permlane32_swap(mi[qb], mi[qb], false, false);
         const int mm = max((int)sw[0], (int)sw[1]);
         rel[qb] = mm > 0 ? __int_as_float(mm) : 0.f;
@@ -876,13 +979,14 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
           const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-adv);         // tile 0: O = l = 0, and 0 * 2^+big would be NaN
           m_run[qb] += adv;
           l_run[qb] *= alpha;
-          ps[qb] = 0.f;
+          ps[qb] = f32x2_t{0.f, 0.f};
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             o0[qb][i] *= alpha; o1[qb][i] *= alpha;
             if (LSUM) lacc[qb][i] *= alpha;
+            if (LSUM4 && i < 4) lacc4[qb][i] *= alpha;
             s0[qb][i] = __builtin_amdgcn_exp2f(s0[qb][i] - adv);
-            if (!LSUM) ps[qb] += s0[qb][i];
+            if (!MSUM) ps[qb][i & 1] += s0[qb][i];
             s1[qb][i] -= adv;
           }
           rel[qb] = (t > 0 && !(adv > 0.f)) ? rel[qb] : 0.f;
@@ -890,6 +994,23 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       }
       FA_VISSUE(0, 0);
       FA_VISSUE(1, 1);
+#if FA_PHASED & 1
+      // every exponential of the tile first, then the 16 P.V MFMAs (and, behind the barrier, the next tile's 16 K.Q MFMAs) as one
+      // stretch of matrix work: the SIMD's two waves - one of each resident workgroup - fall into opposite phases, and a wave in its
+      // MFMA stretch leaves the issue port to the other wave's exponentials (measured against the interleaved order below)
+      FA_EXP(2);
+      FA_EXP(3);
+      FA_VWAIT(0, 4);
+      FA_PV(0, 0);
+      FA_VISSUE(2, 0);
+      FA_VWAIT(1, 4);
+      FA_PV(1, 1);
+      FA_VISSUE(3, 1);
+      FA_VWAIT(0, 4);
+      FA_PV(2, 0);
+      FA_VWAIT(1, 0);
+      FA_PV(3, 1);
+#else
       FA_VWAIT(0, 4);
       FA_PV(0, 0);
       FA_EXP(2);
@@ -904,10 +1025,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       FA_PV(2, 0);
       FA_VWAIT(1, 0);
       FA_PV(3, 1);
-      if (!LSUM) {
+#endif
+      if (!MSUM) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps[qb]), __float_as_uint(ps[qb]), false, false);
+          const float pst = ps[qb][0] + ps[qb][1];
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(pst), __float_as_uint(pst), false, false);
           l_run[qb] += __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         }
       }
@@ -922,7 +1045,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
           m_run[qb] += adv;
           l_run[qb] *= alpha;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; }
+          for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; if (LSUM4 && i < 4) lacc4[qb][i] *= alpha; }
         }
       }
     }
@@ -959,7 +1082,12 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     const int hd = (int)(nb % NH);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      const float inv = 1.f / (LSUM ? lacc[qb][0] : l_run[qb]);
+      float lsum = LSUM ? lacc[qb][0] : l_run[qb];
+      if (LSUM4) {                                          // every lane holds the sum of its OWN half of the keys: add the other half-wave's
+        const auto sw4 = __builtin_amdgcn_permlane32_swap(__float_as_uint(lacc4[qb][0]), __float_as_uint(lacc4[qb][0]), false, false);
+        lsum = __uint_as_float(sw4[0]) + __uint_as_float(sw4[1]);
+      }
+      const float inv = 1.f / lsum;
       const int row = 32 * qb + r;
       const int sw = (row >> 1) & 7;
 #pragma unroll
