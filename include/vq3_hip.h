@@ -267,6 +267,14 @@ int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, int
  * The reference keeps only the first num_vis_tokens rows of the last global block's output (src/models/vggt_qwen3_vlm.py:148-156). */
 int vq3_flash_attn_fwd_rows(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N,
                             int32_t q_rows, int32_t head_dim, int64_t ldo, float scale, void* stream);
+/* vq3_flash_attn_fwd_rows with a promise from the caller: |scale * q . k| <= score_bound for every (query, key) pair (q_rows = N: all
+ * queries). VGGT's frame / global blocks normalise q and k with a LayerNorm over the 64 head channels before the (norm-preserving) RoPE
+ * (upstream vggt/layers/attention.py: q_norm / k_norm; not vendored, third_party/README.md:5-11), so |q| <= 8 max|gamma_q| + |beta_q| and
+ * likewise |k|: a bound that depends on the WEIGHTS only. score_bound <= 62.4 (= 90 / log2 e) selects kernels without a running maximum
+ * (exact - softmax is shift-invariant; no accumulator fill, growth scan or rescale per key tile); larger or negative (= none): the general
+ * kernels. A wrong promise can overflow: the caller owns it. VQ3_FLASH_NOMAX=0 ignores the promise (A/B runs). */
+int vq3_flash_attn_fwd_bounded(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N,
+                               int32_t q_rows, int32_t head_dim, int64_t ldo, float scale, float score_bound, void* stream);
 
 /* Fused cross-attention of a PerceiverLayer (src/models/projector_perceiver.py:33,44: nn.MultiheadAttention(latents, context,
  * context) with attention-weight dropout): O[b N + n, h D + :] = dropout(softmax_t(alpha q[b,n,h] . k[b,t,h])) . v[b,t,h], one launch.

@@ -91,6 +91,103 @@ def test_flash_attention_spiked_max(N):
     assert (out.float() - ref).abs().max().item() < 0.05
 
 
+@pytest.mark.parametrize("G,NH,N,nq", [(2, 2, 21, None), (3, 2, 138, None), (2, 16, 1029, None), (1, 2, 2058, None), (36, 16, 1029, None),
+                                       (1, 16, 8232, None), (3, 16, 1029, 128), (2, 4, 1029, 600)])
+def test_flash_attention_with_a_score_bound_vs_sdpa(G, NH, N, nq):
+    """vq3_flash_attn_fwd_bounded (the kernels without a running maximum) against SDPA in fp32 - on unit-normal operands, and on operands
+    scaled so that the scores fill the promised range: some rows whose largest score sits near +bound (2^+72 and more as the exponent's argument),
+    some near -bound with every other score below (all weights tiny: 2^-65 and less), a dominant key in the tail tile."""
+    from vggt_qwen3_amd import ops
+    g = torch.Generator().manual_seed(N)
+    Q = torch.randn(G, NH, N, 64, generator=g)
+    K = torch.randn(G, NH, N, 64, generator=g)
+    V = torch.randn(G, NH, N, 64, generator=g)
+    bound = 60.0                                                   # natural units; the library's limit is 90 / log2(e) = 62.4
+    rows = N if nq is None else nq
+
+    def run(Q, K, V, bound):
+        Qd, Kd, Vd = Q.to(BF16).cuda(), K.to(BF16).cuda(), V.to(BF16).cuda()
+        out = ops.flash_attn(Qd, Kd, Vd, q_rows=nq, score_bound=bound).view(G, rows, NH, 64).transpose(1, 2)
+        ref = torch.nn.functional.scaled_dot_product_attention(Qd[:, :, :rows].float(), Kd.float(), Vd.float())
+        assert torch.isfinite(out).all()
+        return out, ref
+    out, ref = run(Q, K, V, bound)
+    assert relerr(out, ref) < 1e-2
+    # scores near the edge of the promise: |q| = |k| = sqrt(8 * 50) for the chosen pairs -> q . k / 8 = +-50 (picks that share a head
+    # interact through the shifted keys: up to ~ +-58)
+    Q2, K2 = Q.clone(), K.clone()
+    unit = lambda v: v / v.norm()
+    a = (8 * 50.0) ** 0.5
+    picks = [(0, 0, 3 % rows, 5 % N, 1.0), (0, 0, 7 % rows, N - 1, 1.0), (G - 1, NH - 1, rows - 1, 2 % N, -1.0), (G - 1, 0, 11 % rows, 9 % N, -1.0)]
+    for gi, hi, qi, ki, sign in picks:
+        d = unit(torch.randn(64, generator=g))
+        Q2[gi, hi, qi] = a * d
+        if sign > 0:
+            K2[gi, hi, ki] = a * d                                  # one key at +50, the others ~ N(0, 50 / 8)
+        else:
+            K2[gi, hi] = K2[gi, hi] - (K2[gi, hi] @ d)[:, None] * d[None, :] - 0.9 * a * d[None, :]      # every key at -0.9 * 50 along d ...
+            K2[gi, hi, ki] = -a * d                                 # ... one at -50: all scores of this query in [-50, -45]
+    q2, k2 = Q2.to(BF16).float(), K2.to(BF16).float()
+    assert (torch.einsum("ghqd,ghkd->ghqk", q2[:, :, :rows], k2).abs().max() / 8).item() <= bound
+    out2, ref2 = run(Q2, K2, V, bound)
+    assert relerr(out2, ref2) < 1e-2
+    assert (out2.float().cpu() - ref2.cpu()).abs().max().item() < 0.05
+    for gi, hi, qi, ki, sign in picks:                              # the edge rows on their own
+        assert relerr(out2[gi, hi, qi], ref2[gi, hi, qi]) < 2e-2, (gi, hi, qi, sign)
+
+
+def test_flash_attention_score_bound_above_the_limit_takes_the_general_kernels():
+    """A promise the no-maximum kernels cannot use (bound > 62.4) must run the general ones: scores of +-200 (2^+-288 as exponent arguments:
+    overflow without a running maximum) stay exact. A negative bound means 'no promise'."""
+    from vggt_qwen3_amd import ops
+    g = torch.Generator().manual_seed(5)
+    G, NH, N = 1, 2, 600
+    Q = torch.randn(G, NH, N, 64, generator=g)
+    K = torch.randn(G, NH, N, 64, generator=g)
+    V = torch.randn(G, NH, N, 64, generator=g)
+    d = torch.randn(64, generator=g); d = d / d.norm()
+    Q[0, 0, 5] = 40.0 * d; K[0, 0, 300] = 40.0 * d; K[0, 0, 301] = -40.0 * d              # q . k / 8 = +-200
+    Qd, Kd, Vd = Q.to(BF16).cuda(), K.to(BF16).cuda(), V.to(BF16).cuda()
+    ref = torch.nn.functional.scaled_dot_product_attention(Qd.float(), Kd.float(), Vd.float())
+    for bound in (250.0, -1.0, float("inf")):
+        out = ops.flash_attn(Qd, Kd, Vd, score_bound=bound).view(G, N, NH, 64).transpose(1, 2)
+        assert torch.isfinite(out).all() and relerr(out, ref) < 1e-2, bound
+
+
+def test_vggt_score_bound_from_the_norm_weights_holds():
+    """The bound the aggregator promises for its frame / global attentions (vggt.py: from the q / k LayerNorm weights) against the scores
+    the fused q|k|v epilogue actually produces, with non-trivial norm weights and biases; the DINOv2 stage (no q / k norm) promises nothing."""
+    from vggt_qwen3_amd import ops
+    from vggt_qwen3_amd.vggt import VGGT
+    model = VGGT(img_size=70, patch_size=14, embed_dim=128, depth=2, dino_depth=1, device="cuda", seed=3)
+    agg = model.aggregator
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in agg.named_tensors().items():
+            if "q_norm" in n or "k_norm" in n:
+                p.copy_((1.5 * torch.randn(p.shape, generator=g) + (1.0 if n.endswith("weight") else 0.0)).to(p.dtype))
+    agg.invalidate_compute_copies()
+    cc = agg._prepare()
+    assert all("score_bound" not in w for w in cc["dino"])
+    seen = []
+    real = ops.flash_attn
+
+    def spy(Q, K, V, out=None, q_rows=None, score_bound=None):
+        if score_bound is not None:
+            s = torch.einsum("ghqd,ghkd->ghqk", Q.float(), K.float()).abs().max().item() / 8.0
+            seen.append((s, score_bound))
+        return real(Q, K, V, out=out, q_rows=q_rows, score_bound=score_bound)
+    ops.flash_attn = spy
+    try:
+        agg(torch.rand(1, 2, 3, 70, 70, generator=g).cuda())
+    finally:
+        ops.flash_attn = real
+    assert len(seen) == 4                                           # 2 frame + 2 global blocks
+    for s, b in seen:
+        assert s <= b, (s, b)
+        assert b < 40 * s                                           # (and not vacuous)
+
+
 @pytest.mark.parametrize("H,W,S,B,C", [(56, 56, 3, 2, 128), (70, 84, 2, 1, 256), (112, 112, 2, 1, 128)])
 def test_aggregator_vs_cpu_restatement(H, W, S, B, C):
     from oracle import vggt as ov

@@ -99,6 +99,7 @@ SIGNATURES = {
     "vq3_vit_qkprep": [c_p] * 10 + [i64, i32, i32, i32, i32, i32, i32, i32, i32, f32, c_p],
     "vq3_flash_attn_fwd": [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i64, f32, c_p],
     "vq3_flash_attn_fwd_rows": [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i64, f32, c_p],
+    "vq3_flash_attn_fwd_bounded": [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i64, f32, f32, c_p],
     "vq3_adamw_step": [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p, f32, c_p],
     "vq3_sumsq": [c_p, i32, i64, c_p, c_p, c_p],
     "vq3_dropout": [c_p, i32, i64, f32, C.c_uint64, C.c_uint64, c_p],

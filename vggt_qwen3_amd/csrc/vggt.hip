@@ -247,6 +247,9 @@ constexpr float FA_THR = 6.0f;
 #ifndef FA_MIXMODE
 #define FA_MIXMODE 2   // P.V sections: 0 = hint "one MFMA, six VALU, ...", 1 = no hint, 2 = hint "the MFMAs first, then the VALU work"
 #endif
+#ifndef FA_NOMAX_LSUM
+#define FA_NOMAX_LSUM 0 // the kernels without a running maximum, two query blocks per wave: row sums on the matrix pipe (0: packed VALU adds)
+#endif
 #ifndef FA_PHASED
 #define FA_PHASED 0    // bit 0: steady-state tile of the VAR 1 kernel = all exponentials, then all P.V MFMAs (0: the interleaved order); bit 1: the same in tile_body
 #endif
@@ -441,7 +444,12 @@ __global__ __launch_bounds__(256) void flash_tail_hd64_kernel(const bf16_t* __re
 // second stream they run beside the 4 exact blocks. Query rows q_begin <= q < q_end are processed, keys 0 .. N - 1.
 // VAR (two query blocks per wave only): 0 = row sums of P on the matrix pipe; 1 = keys 32-63 multiplied while keys 0-31 are scanned and
 // exponentiated (row sums on the VALU: both together do not fit 256 registers)
-template <int QB, int NT, int VAR = 0>
+// NOMAX (the caller vouches for |score| <= FA_NOMAX_BOUND in the exponent's units, e.g. from the weights of a q / k LayerNorm in front of
+// the attention): softmax is shift-invariant and bf16 / f32 keep their relative precision at any scale, so with every 2^score inside
+// 2^+-90 the running maximum is not needed at all - no -m fill of the score accumulators (the first K.Q MFMA starts from the inline
+// constant 0), no growth scan, no deferred rescale, no textbook-order branch: per 64-key tile and wave 32 v_mov + 32 v_max3 + the
+// decision go away beside 64 v_exp_f32 (the VALU is this kernel's busier pipe). Sums stay below 2^90 * N, far from the f32 range.
+template <int QB, int NT, int VAR = 0, bool NOMAX = false>
 __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                  int N, int NH, long ldo, float scale_log2e, int q_begin, int q_end, int o_rows,
@@ -486,14 +494,14 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   // -m replicated over an accumulator-shaped vector: the first QK MFMA of a tile takes it as C and writes the scores to
   // other registers, so no per-tile fill of the accumulator is needed (m only changes on the rare deferred rescale).
   // One query block per wave only: with two the 16 extra registers per block would push the kernel past 256 VGPRs.
-  constexpr bool NEGM = (QB == 1);
+  constexpr bool NEGM = (QB == 1) && !NOMAX;
   f32x16 negm[NEGM ? QB : 1];
   // Row sums of P on the MATRIX pipe: one more MFMA per 16-key chunk with an all-ones A operand leaves sum_k P[k][q] in every register
   // of the query's lane (both half-waves: the MFMA sums over all 16 keys of the chunk) - the sums of the bf16-rounded P, i.e. exactly the
   // weights the numerator uses. PMC (profiles/r3_flash_pmc.txt): the VALU is the busier pipe of this kernel (61 % against 43 %) and the
   // two overlap little; this moves 68 of ~300 vector instructions per tile (the adds + the cross-half exchange) to 8 MFMAs.
   constexpr bool LSUM4 = (QB == 2 && VAR == 1 && (FA_LSUM4 & 1)) || (QB == 2 && VAR == 0 && (FA_LSUM4 & 2)) || (QB == 1 && (FA_LSUM4 & 4));
-  constexpr bool LSUM = !LSUM4 && FA_LSUM_MFMA && QB == 2 && (VAR == 0 || FA_LSUM_VAR1);      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
+  constexpr bool LSUM = !LSUM4 && FA_LSUM_MFMA && QB == 2 && (NOMAX ? (FA_NOMAX_LSUM != 0) : (VAR == 0 || FA_LSUM_VAR1));      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
   constexpr bool MSUM = LSUM || LSUM4;                     // row sums on the matrix pipe (either form): no VALU partial sums
   f32x16 lacc[LSUM ? QB : 1];
   f32x4 lacc4[LSUM4 ? QB : 1];
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[qb][i] = -m_run[qb]; s1[qb][i] = -m_run[qb]; }
+        for (int i = 0; i < 16; ++i) { s0[qb][i] = NOMAX ? 0.f : -m_run[qb]; s1[qb][i] = NOMAX ? 0.f : -m_run[qb]; }
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -676,7 +684,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
   } while (0)
     float rel[QB];
-    bool slow = (t == 0);
+    bool slow = (t == 0) && !NOMAX;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       if (kbase + FA_KV > N) {   // wave-uniform: key tail of the last tile
@@ -687,7 +695,9 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
           if (key0 + 32 >= N) s1[qb][i] = -INFINITY;
         }
       }
-      if (t == 0) {
+      if (NOMAX) {
+        rel[qb] = 0.f;
+      } else if (t == 0) {
         // exact float maximum (may be negative): the first tile sets the scale
         float mx = fmaxf(s0[qb][0], s1[qb][0]);
 #pragma unroll
@@ -707,7 +717,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         slow = slow || !(rel[qb] <= 100.f);                                        // also catches NaN
       }
     }
-    if (__any(slow)) {
+    if (!NOMAX && __any(slow)) {
       // textbook order (first tile; overflow guard): advance the max first, rescale, subtract, then exponentiate
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
@@ -854,7 +864,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     bool grow = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) grow = grow || (rel[qb] > FA_THR);
-    if (__any(grow)) {
+    if (!NOMAX && __any(grow)) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         const float adv = rel[qb] > FA_THR ? rel[qb] : 0.f;
@@ -1052,7 +1062,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     if (more) store_tile(STG ^ 1);
     __syncthreads();
   };
-  constexpr bool FAST = (QB == 2) && FA_QK_OVERLAP && VAR == 1;
+  constexpr bool FAST = (QB == 2) && FA_QK_OVERLAP && VAR == 1 && !NOMAX;
   for (int t = 0; t < nt; t += 2) {
     if constexpr (FAST) {
       tile_fast(t, std::integral_constant<int, 0>{});
@@ -1151,8 +1161,10 @@ extern "C" int vq3_vit_qkprep(const void* qkv, const float* qn_w, const float* q
   return 0;
 }
 
+constexpr float FA_NOMAX_BOUND = 90.f;      // |score| * log2(e) up to which the kernels without a running maximum are used
+
 static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N, int32_t q_rows,
-                               int32_t head_dim, int64_t ldo, float scale, void* stream) {
+                               int32_t head_dim, int64_t ldo, float scale, void* stream, float score_bound = -1.f) {
   VQ3_CHECK_ARG(Q && K && V && O, "flash_attn_fwd: null pointer");
   VQ3_CHECK_ARG(q_rows > 0 && q_rows <= N, "flash_attn_fwd: q_rows must be in 1..N, got %d", q_rows);
   VQ3_CHECK_ARG(head_dim == 64, "flash_attn_fwd: head_dim must be 64, got %d", head_dim);
@@ -1227,7 +1239,17 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
   static int fvar_env = -2;
   if (fvar_env == -2) { const char* e = getenv("VQ3_FLASH_VAR"); fvar_env = e ? atoi(e) : -1; }
   const int fvar = fvar_env >= 0 ? fvar_env : (N >= 2048 ? 1 : 0);
-  if (qb == 2 && fvar == 1)
+  // the caller's bound on |scale * q.k| (vq3_flash_attn_fwd_bounded; < 0 = none): small enough -> the kernels without a running maximum
+  static int nomax_env = -1;
+  if (nomax_env < 0) { const char* e = getenv("VQ3_FLASH_NOMAX"); nomax_env = e ? atoi(e) : 1; }
+  const bool nomax = nomax_env && score_bound >= 0.f && score_bound * 1.44269504088896340736f <= FA_NOMAX_BOUND;
+  if (nomax && qb == 2)
+    hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256, 0, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, tail_begin, nblk);
+  else if (nomax)
+    hipLaunchKernelGGL((flash_attn_hd64_kernel<1, 256, 0, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, -1, nblk);
+  else if (qb == 2 && fvar == 1)
     hipLaunchKernelGGL((flash_attn_hd64_kernel<2, 256, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q,
                        (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, N, NH, (long)ldo, sl2, 0, q_main, q_rows, tail_begin, nblk);
   else if (qb == 2)
@@ -1244,6 +1266,15 @@ static int flash_attn_fwd_impl(const void* Q, const void* K, const void* V, void
 extern "C" int vq3_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH,
                                   int32_t N, int32_t head_dim, int64_t ldo, float scale, void* stream) {
   return flash_attn_fwd_impl(Q, K, V, O, G, NH, N, N, head_dim, ldo, scale, stream);
+}
+
+// The same two calls with a promise: |scale * q . k| <= score_bound for every (query, key) pair (e.g. derived from the weights of the
+// q / k LayerNorms in front of the attention; q_rows = N for all queries). A bound of at most 90 / log2(e) = 62.4 selects kernels that keep no
+// running maximum (exact: softmax is shift-invariant, and every 2^score then lies inside the bf16 / f32 range with room for the sums);
+// a larger bound, or a negative one (= none), runs the general kernels. A WRONG promise can overflow - the caller owns it.
+extern "C" int vq3_flash_attn_fwd_bounded(const void* Q, const void* K, const void* V, void* O, int32_t G, int32_t NH, int32_t N,
+                                          int32_t q_rows, int32_t head_dim, int64_t ldo, float scale, float score_bound, void* stream) {
+  return flash_attn_fwd_impl(Q, K, V, O, G, NH, N, q_rows, head_dim, ldo, scale, stream, score_bound);
 }
 
 // The same attention for the first q_rows queries of every group only (all N keys): O[(g*q_rows + n)*ldo + h*64 + d], n < q_rows. The

@@ -693,9 +693,10 @@ def linear_vit_qkv(x: torch.Tensor, w: torch.Tensor, bias, N: int, NH: int, *, q
     return Q, Kt, V
 
 
-def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None, q_rows: Optional[int] = None) -> torch.Tensor:
+def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None, q_rows: Optional[int] = None, score_bound: Optional[float] = None) -> torch.Tensor:
     """softmax(Q K^T / 8) V for Q,K,V bf16 [G, NH, N, 64] -> token-major [G*N, NH*64]; with q_rows only the first q_rows queries of
-    every group are computed (all N keys) -> [G*q_rows, NH*64]."""
+    every group are computed (all N keys) -> [G*q_rows, NH*64]. score_bound: the caller's promise |q . k| / 8 <= score_bound for every
+    pair (vq3_flash_attn_fwd_bounded: a small bound selects the kernels without a running maximum; None = no promise)."""
     _req(Q, BF16, "flash Q"); _req(K, BF16, "flash K"); _req(V, BF16, "flash V")
     assert Q.is_contiguous() and K.is_contiguous() and V.is_contiguous() and K.shape == Q.shape and V.shape == Q.shape
     G, NH, N, D = Q.shape
@@ -703,7 +704,10 @@ def flash_attn(Q, K, V, out: Optional[torch.Tensor] = None, q_rows: Optional[int
     if out is None:
         out = torch.empty((G * nq, NH * D), device=Q.device, dtype=BF16)
     assert out.shape[0] >= G * nq
-    if q_rows is None:
+    if score_bound is not None:
+        check(_lib.load().vq3_flash_attn_fwd_bounded(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), G, NH, N, nq, D,
+                                                     out.stride(0), D ** -0.5, float(score_bound), _stream()), "vq3_flash_attn_fwd_bounded")
+    elif q_rows is None:
         check(_lib.load().vq3_flash_attn_fwd(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), G, NH, N, D,
                                              out.stride(0), D ** -0.5, _stream()), "vq3_flash_attn_fwd")
     else:

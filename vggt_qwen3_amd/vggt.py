@@ -160,6 +160,12 @@ class Aggregator(nn.Module):
             if qk:
                 d["qn"] = (f(prefix + "attn.q_norm.weight"), f(prefix + "attn.q_norm.bias"))
                 d["kn"] = (f(prefix + "attn.k_norm.weight"), f(prefix + "attn.k_norm.bias"))
+                # A bound on |q . k| / sqrt(hd) from the WEIGHTS alone: LayerNorm over the hd head channels leaves sum(xhat^2) <= hd, so
+                # |gamma o xhat + beta| <= sqrt(hd) max|gamma| + |beta|, RoPE rotates pairs (norm-preserving); 5 % for the bf16 roundings
+                # of q, k and the scaled q. A small bound lets the attention run without a running maximum (vq3_flash_attn_fwd_bounded).
+                hd = d["qn"][0].numel()
+                lim = lambda wb: float(hd ** 0.5 * wb[0].abs().max() + wb[1].norm())
+                d["score_bound"] = 1.05 * lim(d["qn"]) * lim(d["kn"]) * hd ** -0.5
             if self._ln_fold:
                 # Linear(LayerNorm(x)) = rstd (x . (gamma o W)^T - mu colsum) + (b + W . beta): the frozen tower's two pre-norms are
                 # folded into the weights once (ops.ln_fold); colsum is taken from the bf16-rounded product the GEMM will read
@@ -257,7 +263,7 @@ class Aggregator(nn.Module):
                                              tokens_per_frame=P, patch_start=self.patch_start_idx, Wp=Wp, eps=1e-5, **kw)
             else:
                 Q, K, V = ops.linear_vit_qkv(x, w["qkv_wf"], w["qkv_d"], N, NH, **kw)
-            o = ops.flash_attn(Q, K, V, q_rows=keep)
+            o = ops.flash_attn(Q, K, V, q_rows=keep, score_bound=w.get("score_bound") if rope is not None else None)
             x = head(x)
             st2 = torch.empty((x.shape[0], C // 128, 2), device=x.device, dtype=torch.float32)
             st3 = torch.empty_like(st2)
@@ -299,7 +305,7 @@ class Aggregator(nn.Module):
                                          tokens_per_frame=P, patch_start=self.patch_start_idx, Wp=Wp, eps=1e-5)
         else:
             Q, K, V = ops.linear_vit_qkv(xn, w["qkv_w"], w["qkv_b"], N, NH)
-        o = ops.flash_attn(Q, K, V, q_rows=keep)
+        o = ops.flash_attn(Q, K, V, q_rows=keep, score_bound=w.get("score_bound") if rope is not None else None)
         x = ops.linear(o, w["proj_w"], bias=w["proj_b"], colscale=w["ls1"], residual=head(x))
         xn2, _ = ops.layernorm_fwd(x, w["n2"][0], w["n2"][1], eps)
         h = ops.linear(xn2, w["fc1_w"], bias=w["fc1_b"], act=ops.ACT_GELU)
