@@ -84,10 +84,8 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // Exact-form (erf) GELU, torch.nn.GELU()'s default, two values per VALU instruction: GELU(x) = x * Phi(x) with
 //   Phi(-a) = 2^q(a),  a = min(|x|, 5.5),  q = degree-7 fit of log2 Phi(-a) on [0, 5.5]      (Phi(x) = 1 - Phi(-x) for x > 0)
 // log2 Phi(-a) is smooth (it does not saturate as erf does), so 7 packed FMAs + one v_exp_f32 give |error| <= 7e-7 absolute and
-// 1.2e-5 relative for |x| < 3 (Phi of the negative tail is the quantity computed directly, so it keeps its relative accuracy);
-// the result is rounded to bf16 (2^-9 relative) right after. No v_rcp, no log2(e) multiply, none of libm erff's range checks:
-// on the VGGT fc1 GEMM (25 M outputs per launch, one workgroup per CU: nothing overlaps the epilogue) the activation is what the
-// tile's tail costs - 18.6 us of an 88.6 us launch with the Abramowitz-Stegun 7.1.26 form (v_rcp + v_exp + 12 scalar-lane ops).
+// 1.2e-5 relative for |x| < 3 (Phi of the negative tail is the quantity computed directly, so it keeps its relative accuracy).
+// This is the form for f32 results; values that are rounded to bf16 right after take gelu_erf2_b below.
 __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
   const f32x2_t a = {fminf(fabsf(x[0]), 5.5f), fminf(fabsf(x[1]), 5.5f)};
   f32x2_t q = {-1.921234625e-06f, -1.921234625e-06f};
@@ -102,8 +100,35 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
   const f32x2_t phi = {0.5f + copysignf(h[0], x[0]), 0.5f + copysignf(h[1], x[1])};
   return x * phi;
 }
+// The same function for values that are ROUNDED TO BF16 right after (GEMM epilogues with a bf16 output, gelu_fwd): GELU(x) = relu(x) - a * Phi(-a) with
+//   Phi(-a) = 2^q(a),  a = min(|x|, 5.5),  q = degree-5 fit of log2 Phi(-a) on [0, 5.5]      (x > 0: x (1 - Phi(-a)) = x - a Phi(-a))
+// log2 Phi(-a) is smooth (it does not saturate as erf does), so 5 FMAs + one v_exp_f32 give |q error| <= 3.7e-4: GELU within 2.5e-4
+// relative (Phi of the negative tail is the quantity computed directly, so it keeps its relative accuracy) = 0.13 ulp of the bf16 the
+// result is rounded to right after; 3.4e-5 absolute. relu(x) is formed as (x + |x|) / 2 so that a NaN stays a NaN (v_max would drop it).
+// No v_rcp, no log2(e) multiply, none of libm erff's range checks: on the VGGT fc1 GEMM (25 M outputs per launch, one workgroup per
+// CU: nothing overlaps the epilogue) the activation is what the tile's tail costs, and the VALU's ISSUE slots are what it costs in
+// (packed f32 and v_exp_f32 take two each): 11 slots per value here against 14 for the degree-7 form with phi = 0.5 + copysign(0.5 - e, x)
+// (round 2-4; 1.2e-5 relative) and ~30 for the Abramowitz-Stegun 7.1.26 form (v_rcp + v_exp + 12 scalar-lane ops).
+__device__ __forceinline__ f32x2_t gelu_erf2_b(f32x2_t x) {
+  const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2_t a = {fminf(ax[0], 5.5f), fminf(ax[1], 5.5f)};
+  f32x2_t q = {-2.3323995992541313e-04f, -2.3323995992541313e-04f};
+  q = __builtin_elementwise_fma(q, a, f32x2_t{4.869441967457533e-03f, 4.869441967457533e-03f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{-4.4596340507268906e-02f, -4.4596340507268906e-02f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{-4.6968939900398254e-01f, -4.6968939900398254e-01f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{-1.1462510824203491e+00f, -1.1462510824203491e+00f});
+  q = __builtin_elementwise_fma(q, a, f32x2_t{-1.0003620386123657e+00f, -1.0003620386123657e+00f});
+  const f32x2_t t = {a[0] * __builtin_amdgcn_exp2f(q[0]), a[1] * __builtin_amdgcn_exp2f(q[1])};
+  return __builtin_elementwise_fma(x + ax, f32x2_t{0.5f, 0.5f}, -t);
+}
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2(f32x2_t{x, x})[0]; }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_b(float x) { return gelu_erf2_b(f32x2_t{x, x})[0]; }
+// sigmoid through v_rcp_f32 (1 ulp) instead of the correctly rounded f32 division hipcc emits for `1.f / y` (v_div_scale x 2, v_rcp,
+// four FMAs, v_div_fmas, v_div_fixup: ~10 VALU issue slots per value in epilogues whose results are rounded to bf16 right after - the
+// SwiGLU forward / backward tails of the two widest text GEMMs). Every SiLU / sigmoid of the library goes through these two, so fused and
+// unfused forms of an op stay bit-identical to each other.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 // Counter-based dropout decision (vq3_dropout, the fused Perceiver cross-attention): 24 uniform bits from (seed, element index);
 // an element is kept when they are >= (unsigned)(p * 2^24). Stateless, so a re-run with the same (seed, offset) repeats the mask.

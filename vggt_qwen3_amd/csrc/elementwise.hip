@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restr
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float gf = bf2f((bf16_t)g[j]), uf = bf2f((bf16_t)u[j]), df = bf2f((bf16_t)d[j]);
-      const float sg = 1.f / (1.f + __expf(-gf));
+      const float sg = sigmoid_f(gf);
       const float sl = gf * sg;
       og[j] = (short)f2bf(df * uf * (sg * (1.f + gf * (1.f - sg))));
       ou[j] = (short)f2bf(df * sl);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict_
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x2_t g = gelu_erf2(f32x2_t{bf2f((bf16_t)zz[2 * j]), bf2f((bf16_t)zz[2 * j + 1])});
+      const f32x2_t g = gelu_erf2_b(f32x2_t{bf2f((bf16_t)zz[2 * j]), bf2f((bf16_t)zz[2 * j + 1])});
       o[2 * j] = (short)f2bf(g[0]); o[2 * j + 1] = (short)f2bf(g[1]);
     }
     *reinterpret_cast<bf16x8*>(h + i * 8) = o;

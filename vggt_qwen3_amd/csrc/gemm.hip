@@ -501,6 +501,11 @@ static int gemm_dispatch(const vq3_gemm_desc* d, const vq3_vit_qkv_epilogue* ve,
     p.vit.qn_w = ve->qn_w; p.vit.qn_b = ve->qn_b; p.vit.kn_w = ve->kn_w; p.vit.kn_b = ve->kn_b;
     p.vit.cos = (const bf16_t*)ve->cos; p.vit.sin = (const bf16_t*)ve->sin;
     p.vit.N = ve->N; p.vit.NH = ve->NH; p.vit.P = ve->tokens_per_frame; p.vit.patch_start = ve->patch_start; p.vit.Wp = ve->Wp;
+    {   // the largest table row the epilogue asks for is max(patch rows, patch columns) (positions are 1-based; 0 = special tokens)
+      const int P_ = ve->tokens_per_frame > 0 ? ve->tokens_per_frame : ve->N, np = P_ - ve->patch_start;
+      const int hp = ve->Wp > 0 && np > 0 ? (np + ve->Wp - 1) / ve->Wp : 0;
+      p.vit.rope_rows = (hp > ve->Wp ? hp : ve->Wp) + 1;
+    }
     p.vit.use_norm = ve->use_norm; p.vit.use_rope = ve->use_rope; p.vit.eps = ve->eps;
     p.vit.m_off = 0;
     p.C = ve->Q; p.ldc = d->N;          // placeholders: the staged epilogue checks their alignment, nothing is stored through them

@@ -602,6 +602,27 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
         f8c[q] = p.f8_cs ? *reinterpret_cast<const f32x4*>(p.f8_cs + n) : f32x4{1.f, 1.f, 1.f, 1.f};
       }
     }
+    // fused q|k|v store: the rows' output offsets and RoPE table rows, one thread per row, in 4 KiB above the LayerNorm pairs (never
+    // operand space); published by the barrier between staging and the row stores
+    // ... and the whole cos / sin tables (33 rows x 64 B each at 448 x 448) in 8 KiB above that: the store's table reads were two
+    // dependent global round trips per thread and tile with nothing to hide them behind
+    const char* rowinfo = nullptr;
+    const char* ropetab = nullptr;
+    if constexpr (EK == 1 && AH + BH == 4) {
+      if (p.epi == 1) {
+        char* ri = smem + 2 * BUF + 2048;
+        if (tid < BM) *reinterpret_cast<int4*>(ri + 16 * tid) = vit_row_info(p, m0 + tid);
+        rowinfo = ri;
+        if (p.vit.use_rope && p.vit.rope_rows <= 64) {
+          char* tb = ri + 4096;
+          const int nch = p.vit.rope_rows * 4, half = tid >> 8, ch = tid & 255;       // 16-byte chunks per table; threads 0-255: cos, 256-511: sin
+          if (ch < nch)
+            *reinterpret_cast<u32x4*>(tb + 4096 * half + 16 * ch) =
+                *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(half ? p.vit.sin : p.vit.cos) + 16 * ch);
+          ropetab = tb;
+        }
+      }
+    }
     auto stage_all = [&](auto act_tag, auto mode_tag, auto ln_tag) {
       constexpr int ACT = decltype(act_tag)::value, MODE = decltype(mode_tag)::value;
       constexpr bool LN = LN_FUSED && decltype(ln_tag)::value;
@@ -643,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v6_kernel(GemmParams p) {
     if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile's K tiles 0 and 1 has landed
     __syncthreads();
     V6_STAMP(3);    // C image staged (and the next tile's first operands landed)
-    staged_store<BM, BN, (EK == 3 ? 0 : EK)>(p, smem_c, coff, roff, m0, n0, tid, 512, &pre);     // (EK == 4: gate|up and act leave together)
+    staged_store<BM, BN, (EK == 3 ? 0 : EK)>(p, smem_c, coff, roff, m0, n0, tid, 512, &pre, rowinfo, ropetab);     // (EK == 4: gate|up and act leave together)
     V6_STAMP(4);    // row stores issued
   } else {
     if (more) {
@@ -761,7 +782,7 @@ int sk_plan(const GemmParams& p, int nbatch, int ncu, int* full, int* rem, int k
 template <int AH, int BH>
 int launch_v6(GemmParams& p, int nbatch, hipStream_t stream, bool split = false) {
   // (two-phase variants: two K-tile buffers of the NEXT tile + the C image of the current one, or three K-tile buffers: 160 KiB)
-  constexpr int SMEM = (AH + BH == 4) ? 2 * 4 * HALF + 2048 : 2 * 3 * HALF + 128 * AH * 128 * BH * 2;   // (+ 2 KiB: LayerNorm pairs above the C image)
+  constexpr int SMEM = (AH + BH == 4) ? 2 * 4 * HALF + 2048 + 4096 + 8192 : 2 * 3 * HALF + 128 * AH * 128 * BH * 2;   // (+ 2 KiB: LayerNorm pairs above the C image, + 4 KiB: the fused q|k|v store's row table, + 8 KiB: its cos / sin tables)
   static_assert(SMEM <= 160 * 1024 && (AH + BH == 4 || SMEM >= 3 * (AH + BH) * HALF), "LDS budget");
   static bool attr_done = false;
   if (!attr_done) {

@@ -15,6 +15,7 @@ struct VitQkvEpi {
   const float *qn_w, *qn_b, *kn_w, *kn_b;  // [64] each (use_norm)
   const bf16_t *cos, *sin;                 // [maxpos + 1, 32] (use_rope)
   int N, NH, P, patch_start, Wp, use_norm, use_rope;
+  int rope_rows;   // rows of the cos / sin tables the epilogue can ask for: max(patch rows, patch columns) + 1 (host; <= 64: the 256 x 256 kernel keeps both tables in LDS)
   int m_off;       // token index of this launch's row 0 (the row-tail launch of gemm.hip: launch_split_rows starts past 0)
   float eps;
 };
@@ -106,8 +107,9 @@ __device__ __forceinline__ f32x4 ln_apply(const f32x4& a, float mu, float rs, co
   return o;
 }
 
+template <bool F32_RESULT = false>          // (a result that stays f32 takes the 1e-5 form of GELU, one rounded to bf16 the cheaper 2.5e-4 one)
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == 1) return gelu_erf(v);
+  if (act == 1) return F32_RESULT ? gelu_erf(v) : gelu_erf_b(v);
   if (act == 2) return silu_f(v);
   return v;
 }
@@ -189,7 +191,7 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, long coff, long 
   if (p.act) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      v[r] = apply_act(v[r], p.act);
+      v[r] = apply_act<OUT_F32>(v[r], p.act);
       if (!OUT_F32) v[r] = rbf(v[r]);
     }
   }
@@ -281,7 +283,7 @@ __device__ __forceinline__ void store_quad_pre(const GemmParams& p, long coff, i
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
   if (p.act == 1) {
-    const f32x2_t g0 = gelu_erf2(f32x2_t{v[0], v[1]}), g1 = gelu_erf2(f32x2_t{v[2], v[3]});
+    const f32x2_t g0 = gelu_erf2_b(f32x2_t{v[0], v[1]}), g1 = gelu_erf2_b(f32x2_t{v[2], v[3]});
     v[0] = rbf(g0[0]); v[1] = rbf(g0[1]); v[2] = rbf(g1[0]); v[3] = rbf(g1[1]);
   } else if (p.act) {
 #pragma unroll
@@ -363,7 +365,7 @@ __device__ __forceinline__ void stage_quad(const GemmParams& p, char* smem, int 
   if (has_bias) { v0 += f32x2_t{bias_v[0], bias_v[1]}; v1 += f32x2_t{bias_v[2], bias_v[3]}; }
   if (act || has_cs) {
     v0 = rbf2(v0); v1 = rbf2(v1);
-    if (act == 1) { v0 = gelu_erf2(v0); v1 = gelu_erf2(v1); }
+    if (act == 1) { v0 = gelu_erf2_b(v0); v1 = gelu_erf2_b(v1); }
     else if (act) { v0 = f32x2_t{apply_act(v0[0], act), apply_act(v0[1], act)}; v1 = f32x2_t{apply_act(v1[0], act), apply_act(v1[1], act)}; }
     if (has_cs) {
       if (act) { v0 = rbf2(v0); v1 = rbf2(v1); }
@@ -387,7 +389,8 @@ __device__ __forceinline__ void stage_quad(const GemmParams& p, char* smem, int 
   } while (0)
 
 template <int BM, int BN>
-__device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* smem, int m0, int n0, int tid, int nthreads);
+__device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* smem, int m0, int n0, int tid, int nthreads, const char* rowinfo = nullptr,
+                                              const char* ropetab = nullptr);
 
 // phase 2 (after a workgroup barrier): `nthreads` threads (tid 0 .. nthreads-1) move the BM x BN image out as whole rows,
 // adding the residual (rounded, as PyTorch's bf16 add) and / or the old C (accumulate) on the way. Needs p.vec_ok, ldc % 8 == 0
@@ -422,7 +425,7 @@ __device__ __forceinline__ void staged_prefetch(const GemmParams& p, long coff, 
 
 template <int BM, int BN, int EPIK = -1>
 __device__ __forceinline__ void staged_store(const GemmParams& p, const char* smem, long coff, long roff, int m0, int n0, int tid,
-                                             int nthreads, const EpiPre* pre = nullptr) {
+                                             int nthreads, const EpiPre* pre = nullptr, const char* rowinfo = nullptr, const char* ropetab = nullptr) {
   constexpr int CPR = BN / 8;                  // 16-byte chunks per row
   if constexpr (EPIK == 4) {
     // SwiGLU forward (modeling_qwen3.py:81-83): the tile's columns are [BN/2 gate | the same BN/2 up columns] (the kernel stages the
@@ -460,7 +463,7 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
     return;
   }
   if ((EPIK < 0 || EPIK == 1) && p.epi == 1) {
-    vit_qkv_store<BM, BN>(p, smem, m0, n0, tid, nthreads);
+    vit_qkv_store<BM, BN>(p, smem, m0, n0, tid, nthreads, rowinfo, ropetab);
     return;
   }
   if ((EPIK < 0 || EPIK == 2) && p.epi == 2) {
@@ -495,7 +498,7 @@ __device__ __forceinline__ void staged_store(const GemmParams& p, const char* sm
             const float df = bf2f((bf16_t)((dv[k] >> (16 * hgh)) & 0xffff));
             const float gf = bf2f((bf16_t)((gv[u][k] >> (16 * hgh)) & 0xffff));
             const float uf = bf2f((bf16_t)((uv[u][k] >> (16 * hgh)) & 0xffff));
-            const float sg = 1.f / (1.f + __expf(-gf));
+            const float sg = sigmoid_f(gf);
             r_g[hgh] = df * uf * (sg * (1.f + gf * (1.f - sg)));
             r_u[hgh] = df * (gf * sg);
           }
@@ -605,8 +608,33 @@ __device__ __forceinline__ void divmod_f(int x, int d, float inv, int& q, int& r
   else if (r >= d) { r -= d; ++q; }
 }
 
+// What the fused q|k|v store needs to know about a ROW of the tile, worked out once per row (vit_row_info, one thread per row, into
+// LDS) instead of once per (row, 16-byte chunk) by each of the BN / 8 threads that share the row: three divisions by run-time
+// divisors through the float reciprocal are ~30 VALU instructions, and a 256 x 256 tile asked for them 16 times per thread.
+//   x: the row's element offset ((group * NH) * N + token) * 64 without the head term, low / high word (-1 / -1: row past M);
+//   z, w: 32 * (patch row + 1), 32 * (patch column + 1) - the rows of the cos / sin tables (0 for the special tokens)
+__device__ __forceinline__ int4 vit_row_info(const GemmParams& p, int m) {
+  const VitQkvEpi& e = p.vit;
+  if (m >= p.M) return int4{-1, -1, 0, 0};
+  const float invN = 1.f / (float)e.N, invP = 1.f / (float)(e.P > 0 ? e.P : 1), invW = 1.f / (float)(e.Wp > 0 ? e.Wp : 1);
+  int gi, ti;
+  divmod_f(m + e.m_off, e.N, invN, gi, ti);
+  int py = 0, px = 0;
+  if (e.use_rope) {
+    int fr, tp = ti;
+    if (e.P != e.N) divmod_f(ti, e.P, invP, fr, tp);
+    if (tp >= e.patch_start) {
+      divmod_f(tp - e.patch_start, e.Wp, invW, py, px);
+      ++py; ++px;
+    }
+  }
+  const long ob = ((long)gi * e.NH * e.N + ti) * 64;
+  return int4{(int)(ob & 0xffffffffL), (int)(ob >> 32), py * 32, px * 32};
+}
+
 template <int BM, int BN>
-__device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* smem, int m0, int n0, int tid, int nthreads) {
+__device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* smem, int m0, int n0, int tid, int nthreads, const char* rowinfo,
+                                              const char* ropetab) {        // ropetab: LDS copies of the cos (at 0) and sin (at 4096) tables, or null
   constexpr int CPR = BN / 8;
   const VitQkvEpi& e = p.vit;
   const int C = e.NH * 64;
@@ -629,58 +657,87 @@ __device__ __forceinline__ void vit_qkv_store(const GemmParams& p, const char* s
   for (int row0 = tid / CPR; row0 < BM; row0 += rpp * EPI_U) {
     // token coordinates and the cos / sin rows of EPI_U passes first (they depend on the row only), then the arithmetic: the table
     // reads' round trip is paid once per batch. Rows past M are computed on row M - 1 and not stored, so all lanes stay in step.
-    int gi[EPI_U], ti[EPI_U];
+    long ob[EPI_U];                                      // element offset of the row's head 0, feature 0
     bool ok[EPI_U];
     u32x4 cr[EPI_U], sr[EPI_U];
 #pragma unroll
     for (int u = 0; u < EPI_U; ++u) {
       const int row = row0 + u * rpp, m = m0 + row;
       ok[u] = row < BM && m < p.M;
-      divmod_f((ok[u] ? m : p.M - 1) + e.m_off, e.N, invN, gi[u], ti[u]);
-      if (rope) {
-        int fr, tp = ti[u];
-        if (e.P != e.N) divmod_f(ti[u], e.P, invP, fr, tp);
+      int pos32;
+      if (rowinfo) {
+        const int4 ri = *reinterpret_cast<const int4*>(rowinfo + 16 * (row < BM ? row : BM - 1));
+        ob[u] = ((long)ri.y << 32) | (unsigned)ri.x;
+        pos32 = d0 < 32 ? ri.z : ri.w;
+      } else {
+        int gi, ti;
+        divmod_f((ok[u] ? m : p.M - 1) + e.m_off, e.N, invN, gi, ti);
+        ob[u] = ((long)gi * e.NH * e.N + ti) * 64;
         int py = 0, px = 0;
-        if (tp >= e.patch_start) {
-          divmod_f(tp - e.patch_start, e.Wp, invW, py, px);
-          ++py; ++px;
+        if (rope) {
+          int fr, tp = ti;
+          if (e.P != e.N) divmod_f(ti, e.P, invP, fr, tp);
+          if (tp >= e.patch_start) {
+            divmod_f(tp - e.patch_start, e.Wp, invW, py, px);
+            ++py; ++px;
+          }
         }
-        const int pos = d0 < 32 ? py : px;
-        cr[u] = *reinterpret_cast<const u32x4*>(e.cos + pos * 32 + (d0 & 31));
-        sr[u] = *reinterpret_cast<const u32x4*>(e.sin + pos * 32 + (d0 & 31));
+        pos32 = (d0 < 32 ? py : px) * 32;
+      }
+      if (rope) {
+        if (ropetab) {
+          cr[u] = *reinterpret_cast<const u32x4*>(ropetab + 2 * (pos32 + (d0 & 31)));
+          sr[u] = *reinterpret_cast<const u32x4*>(ropetab + 4096 + 2 * (pos32 + (d0 & 31)));
+        } else {
+          cr[u] = *reinterpret_cast<const u32x4*>(e.cos + pos32 + (d0 & 31));
+          sr[u] = *reinterpret_cast<const u32x4*>(e.sin + pos32 + (d0 & 31));
+        }
       }
     }
 #pragma unroll
     for (int u = 0; u < EPI_U; ++u) {
       const int row = row0 + u * rpp;
       const u32x4 sv = *reinterpret_cast<const u32x4*>(smem + cstage_off<BN>(row < BM ? row : BM - 1, c));
-      float x[8];
+      // Same arithmetic and rounding points as before, in fewer VALU issue slots: roundings through bf16 pair-wise (one conversion + two
+      // unpacks per pair instead of a conversion + unpack per value), none before the final pack (the conversion is idempotent), the
+      // rotate-half sign folded into the packed sine words once per row ((-p) s == p (-s) bit for bit), and the v columns - no norm, no
+      // rotation - leave as the staged dwords they are.
+      u32x4 o = sv;
+      if (norm || rope) {
+        float x[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { x[2 * k] = bf2f((bf16_t)(sv[k] & 0xffff)); x[2 * k + 1] = bf2f((bf16_t)(sv[k] >> 16)); }
-      if (norm) {
-        const float mean = sum8(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * (1.f / 64.f);
-        float sq = 0.f;
+        for (int k = 0; k < 4; ++k) { x[2 * k] = bf2f((bf16_t)(sv[k] & 0xffff)); x[2 * k + 1] = bf2f((bf16_t)(sv[k] >> 16)); }
+        if (norm) {
+          const float mean = sum8(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * (1.f / 64.f);
+          float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { x[j] -= mean; sq = fmaf(x[j], x[j], sq); }
-        const float rs = rsqrtf(sum8(sq) * (1.f / 64.f) + e.eps);
+          for (int j = 0; j < 8; ++j) { x[j] -= mean; sq = fmaf(x[j], x[j], sq); }
+          const float rs = rsqrtf(sum8(sq) * (1.f / 64.f) + e.eps);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = rbf(x[j] * rs * w8[j] + b8[j]);
-      }
-      if (rope) {
+          for (int k = 0; k < 4; ++k) {
+            const float t0 = x[2 * k] * rs * w8[2 * k] + b8[2 * k], t1 = x[2 * k + 1] * rs * w8[2 * k + 1] + b8[2 * k + 1];
+            if (rope) {
+              const f32x2_t t = rbf2(f32x2_t{t0, t1});
+              x[2 * k] = t[0]; x[2 * k + 1] = t[1];
+            } else {
+              o[k] = pack2bf(t0, t1);
+            }
+          }
+        }
+        if (rope) {
+          const unsigned sflip = neg ? 0x80008000u : 0u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float cj = bf2f((bf16_t)((cr[u][j >> 1] >> ((j & 1) * 16)) & 0xffff));
-          const float sj = bf2f((bf16_t)((sr[u][j >> 1] >> ((j & 1) * 16)) & 0xffff));
-          const float pj = dpp_mov<0x4E>(x[j]);                                                  // feature e ^ 16: lane ^ 2
-          const float rj = neg ? -pj : pj;
-          x[j] = rbf(rbf(x[j] * cj) + rbf(rj * sj));
+          for (int k = 0; k < 4; ++k) {
+            const unsigned cw = cr[u][k], sw = sr[u][k] ^ sflip;
+            const float p0 = dpp_mov<0x4E>(x[2 * k]), p1 = dpp_mov<0x4E>(x[2 * k + 1]);              // feature e ^ 16: lane ^ 2
+            const f32x2_t a = rbf2(f32x2_t{x[2 * k] * bf2f((bf16_t)(cw & 0xffff)), x[2 * k + 1] * bf2f((bf16_t)(cw >> 16))});
+            const f32x2_t b = rbf2(f32x2_t{p0 * bf2f((bf16_t)(sw & 0xffff)), p1 * bf2f((bf16_t)(sw >> 16))});
+            o[k] = pack2bf(a[0] + b[0], a[1] + b[1]);
+          }
         }
       }
       if (!ok[u]) continue;
-      u32x4 o;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = pack2bf(x[2 * k], x[2 * k + 1]);
-      *reinterpret_cast<u32x4*>(base + (((long)gi[u] * e.NH + head) * e.N + ti[u]) * 64 + d0) = o;
+      *reinterpret_cast<u32x4*>(base + ob[u] + (long)head * e.N * 64 + d0) = o;
     }
   }
 }
