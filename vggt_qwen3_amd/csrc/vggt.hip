@@ -205,6 +205,9 @@ __global__ __launch_bounds__(256) void vit_qkprep4_kernel(const bf16_t* __restri
 //                             the textbook order (rescale first, subtract, then exponentiate).
 // LDS images: K rows of 128 B with 16-byte chunks XOR (row >> 1) & 7 (ds_read_b128, lane = key row: conflict-free);
 // V rows of 128 B with chunk bit 2 XOR (row >> 1) & 1, so the 4 key rows x 64 B a 32-lane half reads cover all 64 banks.
+typedef __bf16 fa_bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fa_bf8 __attribute__((ext_vector_type(8)));
+typedef float fa_f32x8 __attribute__((ext_vector_type(8)));
 constexpr int FA_KV = 64;
 constexpr float FA_THR = 6.0f;
 #ifndef FA_LSUM_MFMA
@@ -250,6 +253,9 @@ constexpr float FA_THR = 6.0f;
 #ifndef FA_NOMAX_LSUM
 #define FA_NOMAX_LSUM 0 // the kernels without a running maximum, two query blocks per wave: row sums on the matrix pipe (0: packed VALU adds)
 #endif
+#ifndef FA_DOT2SUM
+#define FA_DOT2SUM 1   // VALU row sums as v_dot2c_f32_bf16 on the PACKED P words the P.V MFMA reads (one issue slot per two values, and the
+#endif                 // sums are those of the bf16-rounded weights the numerator uses); 0: packed f32 adds in tree form at the exponentials
 #ifndef FA_PHASED
 #define FA_PHASED 0    // bit 0: steady-state tile of the VAR 1 kernel = all exponentials, then all P.V MFMAs (0: the interleaved order); bit 1: the same in tile_body
 #endif
@@ -759,9 +765,9 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       _Pragma("unroll") for (int j = 0; j < 8; j += 4) {                                                                \
         constexpr int e_ = 8 * ((U) & 1);                                                                               \
         if ((U) < 2) { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) s0[qb][e_ + j + jj] = FA_EXP2(s0[qb][e_ + j + jj]);              \
-                       if (!MSUM && FA_X != 2) FA_PSADD4(ps[qb], s0[qb][e_ + j], s0[qb][e_ + j + 1], s0[qb][e_ + j + 2], s0[qb][e_ + j + 3]); } \
+                       if (!MSUM && FA_X != 2 && !FA_DOT2SUM) FA_PSADD4(ps[qb], s0[qb][e_ + j], s0[qb][e_ + j + 1], s0[qb][e_ + j + 2], s0[qb][e_ + j + 3]); } \
         else { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) s1[qb][e_ + j + jj] = FA_EXP2(s1[qb][e_ + j + jj]);                      \
-               if (!MSUM && FA_X != 2) FA_PSADD4(ps[qb], s1[qb][e_ + j], s1[qb][e_ + j + 1], s1[qb][e_ + j + 2], s1[qb][e_ + j + 3]); }   \
+               if (!MSUM && FA_X != 2 && !FA_DOT2SUM) FA_PSADD4(ps[qb], s1[qb][e_ + j], s1[qb][e_ + j + 1], s1[qb][e_ + j + 2], s1[qb][e_ + j + 3]); }   \
       }                                                                                                                 \
     }                                                                                                                   \
   } while (0)
@@ -771,12 +777,22 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     const u32x4 tb = {vb[BUFI][0][0], vb[BUFI][0][1], vb[BUFI][1][0], vb[BUFI][1][1]};                                  \
     FA_PRIO_HI();                                                                                                       \
     _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                                 \
-      bf16x8 pf;                                                                                                        \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                     \
-        pf[j] = (short)f2bf((U) < 2 ? s0[qb][8 * ((U) & 1) + j] : s1[qb][8 * ((U) & 1) + j]);                            \
+      fa_f32x8 pv;                                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) pv[j] = (U) < 2 ? s0[qb][8 * ((U) & 1) + j] : s1[qb][8 * ((U) & 1) + j]; \
+      const fa_bf8 pb = __builtin_convertvector(pv, fa_bf8);          /* four v_cvt_pk_bf16_f32 */                     \
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pb);                                                                 \
       o0[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ta), pf, o0[qb], 0, 0, 0);            \
       o1[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tb), pf, o1[qb], 0, 0, 0);            \
       if (LSUM) lacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf, lacc[qb], 0, 0, 0);                       \
+      if (!MSUM && FA_DOT2SUM && FA_X != 2) {      /* (sub-vectors by shufflevector: hipcc 7.2 folds a bit_cast of a vector ELEMENT to element 0) */ \
+        const fa_bf2 one2 = {(__bf16)1.0f, (__bf16)1.0f};                                                               \
+        float sa = ps[qb][0], sb = ps[qb][1];                                                                           \
+        sa = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(pb, pb, 0, 1), one2, sa, false);                   \
+        sb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(pb, pb, 2, 3), one2, sb, false);                   \
+        sa = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(pb, pb, 4, 5), one2, sa, false);                   \
+        sb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(pb, pb, 6, 7), one2, sb, false);                   \
+        ps[qb] = f32x2_t{sa, sb};                                                                                       \
+      }                                                                                                                 \
       if (LSUM4) {                                                                                                      \
         lacc4[qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, bf16x4{pf[0], pf[1], pf[2], pf[3]}, lacc4[qb], 0, 0, 0); \
         lacc4[qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, bf16x4{pf[4], pf[5], pf[6], pf[7]}, lacc4[qb], 0, 0, 0); \
@@ -933,7 +949,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         for (int i = 0; i < 16; i += 4) {
 #pragma unroll
           for (int ii = 0; ii < 4; ++ii) s0[qb][i + ii] = FA_EXP2(s0[qb][i + ii]);
-          if (!MSUM && FA_X != 2) FA_PSADD4(ps[qb], s0[qb][i], s0[qb][i + 1], s0[qb][i + 2], s0[qb][i + 3]);
+          if (!MSUM && FA_X != 2 && !FA_DOT2SUM) FA_PSADD4(ps[qb], s0[qb][i], s0[qb][i + 1], s0[qb][i + 2], s0[qb][i + 3]);
         }
       }
 #if FA_PIN_EXP
@@ -996,7 +1012,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
             if (LSUM) lacc[qb][i] *= alpha;
             if (LSUM4 && i < 4) lacc4[qb][i] *= alpha;
             s0[qb][i] = __builtin_amdgcn_exp2f(s0[qb][i] - adv);
-            if (!MSUM) ps[qb][i & 1] += s0[qb][i];
+            if (!MSUM && !FA_DOT2SUM) ps[qb][i & 1] += s0[qb][i];
             s1[qb][i] -= adv;
           }
           rel[qb] = (t > 0 && !(adv > 0.f)) ? rel[qb] : 0.f;
