@@ -7,8 +7,10 @@ without a running maximum, vq3_flash_attn_fwd_bounded; the operands are unit nor
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import os
 import torch
 from vggt_qwen3_amd import ops
+SAME = os.environ.get('FLASH_BENCH_SAME') == '1'      # one operand set only (rows stay in the caches): how much of the time is memory latency
 
 shapes = [(6, 16, 1029), (60, 16, 1029), (1, 16, 8232), (6, 16, 8232), (48, 16, 8232)]
 if len(sys.argv) > 1 and sys.argv[1] == "small":
@@ -23,12 +25,12 @@ for G, NH, N in shapes:
     line = f"G={G} NH={NH} N={N}:"
     for bound in (None, 24.0):
         for i in range(3):
-            ops.flash_attn(*sets[i % 2], out=out, score_bound=bound)
+            ops.flash_attn(*sets[0 if SAME else i % 2], out=out, score_bound=bound)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         it = 10 if N < 4096 or G < 48 else 4
         e0.record()
         for i in range(it):
-            ops.flash_attn(*sets[i % 2], out=out, score_bound=bound)
+            ops.flash_attn(*sets[0 if SAME else i % 2], out=out, score_bound=bound)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / it
         line += f" {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s" + ("   | bounded:" if bound is None else "")
