@@ -12,6 +12,8 @@ from vggt_qwen3_amd import ops
 
 BF16 = torch.bfloat16
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 12000
+if len(sys.argv) > 2:
+    ops.gemm_force_config(int(sys.argv[2]))      # (e.g. 25: the last round's tiles split along K)
 H, I = 2560, 9728
 NCOPY = 4
 

@@ -240,7 +240,7 @@ constexpr float FA_THR = 6.0f;
 #define FA_PKSUM 1     // VALU row sums (the kernels without the matrix-pipe sums) as v_pk_add_f32: two exponentials per add instruction
 #endif
 #ifndef FA_X
-#define FA_X 0         // diagnostic builds only (wrong results): 1 the exponentials become multiplies, 2 no row sums, 3 no growth scan
+#define FA_X 0         // diagnostic builds only (wrong results): 1 the exponentials become multiplies, 2 no row sums, 3 no growth scan, 4 no barrier between key tiles
 #endif
 #if FA_X == 1
 #define FA_EXP2(x) ((x) * 1.0009765625f)
@@ -897,7 +897,9 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     }
     }   // active
     if (more) store_tile(STG ^ 1);
+#if FA_X != 4
     __syncthreads();
+#endif
   };
   // Steady-state tile (not the first, no key tail; two query blocks per wave): the scores of keys 32-63 are multiplied WHILE keys
   // 0-31 are scanned for growth and exponentiated - the deferred maximum makes that legal: the exponentials use the stale scale, the
@@ -1076,7 +1078,9 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       }
     }
     if (more) store_tile(STG ^ 1);
+#if FA_X != 4
     __syncthreads();
+#endif
   };
   constexpr bool FAST = (QB == 2) && FA_QK_OVERLAP && VAR == 1 && !NOMAX;
   for (int t = 0; t < nt; t += 2) {
