@@ -232,13 +232,6 @@ constexpr float FA_THR = 6.0f;
 #ifndef FA_LSUM_VAR1
 #define FA_LSUM_VAR1 0 // 1: row sums on the matrix pipe in the VAR 1 kernel too (spills 8 registers even with the DMA staging: off)
 #endif
-#ifndef FA_LSUM4
-#define FA_LSUM4 0     // row sums on the matrix pipe by v_mfma_f32_4x4x4_16b_bf16 (16 blocks of 4 x 4, A = ones: every lane gets the sum of the
-#endif                 // four bf16 values IT supplied as B): two 8-cycle instructions and 4 accumulator registers per 16-key chunk and query
-                       // block where the 32 x 32 x 16 form takes one 32-cycle instruction and 16 registers. Bit mask: 1 = VAR 1, 2 = VAR 0, 4 = QB 1
-#ifndef FA_PKSUM
-#define FA_PKSUM 1     // VALU row sums (the kernels without the matrix-pipe sums) as v_pk_add_f32: two exponentials per add instruction
-#endif
 #ifndef FA_X
 #define FA_X 0         // diagnostic builds only (wrong results): 1 the exponentials become multiplies, 2 no row sums, 3 no growth scan, 4 no barrier between key tiles
 #endif
@@ -248,7 +241,7 @@ constexpr float FA_THR = 6.0f;
 #define FA_EXP2(x) __builtin_amdgcn_exp2f(x)
 #endif
 #ifndef FA_MIXMODE
-#define FA_MIXMODE 2   // P.V sections: 0 = hint "one MFMA, six VALU, ...", 1 = no hint, 2 = hint "the MFMAs first, then the VALU work"
+#define FA_MIXMODE 2   // P.V sections, scheduler hint: 2 = "the MFMAs of a chunk first, then the next chunk's VALU work"; 0 = "one MFMA, six VALU, ..." (2.5 % slower)
 #endif
 #ifndef FA_NOMAX_LSUM
 #define FA_NOMAX_LSUM 0 // the kernels without a running maximum, two query blocks per wave: row sums on the matrix pipe (0: packed VALU adds)
@@ -256,12 +249,6 @@ constexpr float FA_THR = 6.0f;
 #ifndef FA_DOT2SUM
 #define FA_DOT2SUM 1   // VALU row sums as v_dot2c_f32_bf16 on the PACKED P words the P.V MFMA reads (one issue slot per two values, and the
 #endif                 // sums are those of the bf16-rounded weights the numerator uses); 0: packed f32 adds in tree form at the exponentials
-#ifndef FA_PHASED
-#define FA_PHASED 0    // bit 0: steady-state tile of the VAR 1 kernel = all exponentials, then all P.V MFMAs (0: the interleaved order); bit 1: the same in tile_body
-#endif
-#ifndef FA_PIN_EXP
-#define FA_PIN_EXP 0
-#endif
 #ifndef FA_QK_HINT
 #define FA_QK_HINT 0
 #endif
@@ -506,14 +493,9 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
   // of the query's lane (both half-waves: the MFMA sums over all 16 keys of the chunk) - the sums of the bf16-rounded P, i.e. exactly the
   // weights the numerator uses. PMC (profiles/r3_flash_pmc.txt): the VALU is the busier pipe of this kernel (61 % against 43 %) and the
   // two overlap little; this moves 68 of ~300 vector instructions per tile (the adds + the cross-half exchange) to 8 MFMAs.
-  constexpr bool LSUM4 = (QB == 2 && VAR == 1 && (FA_LSUM4 & 1)) || (QB == 2 && VAR == 0 && (FA_LSUM4 & 2)) || (QB == 1 && (FA_LSUM4 & 4));
-  constexpr bool LSUM = !LSUM4 && FA_LSUM_MFMA && QB == 2 && (NOMAX ? (FA_NOMAX_LSUM != 0) : (VAR == 0 || FA_LSUM_VAR1));      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
-  constexpr bool MSUM = LSUM || LSUM4;                     // row sums on the matrix pipe (either form): no VALU partial sums
+  constexpr bool LSUM = FA_LSUM_MFMA && QB == 2 && (NOMAX ? (FA_NOMAX_LSUM != 0) : (VAR == 0 || FA_LSUM_VAR1));      // (one query block per wave: 168 registers = three waves per SIMD; the 20 extra would cost the third)
+  constexpr bool MSUM = LSUM;                              // row sums on the matrix pipe: no VALU partial sums
   f32x16 lacc[LSUM ? QB : 1];
-  f32x4 lacc4[LSUM4 ? QB : 1];
-  bf16x4 ones4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) ones4[j] = (short)0x3F80;
   bf16x8 ones8;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones8[j] = (short)0x3F80;
@@ -529,10 +511,6 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     if (LSUM) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) lacc[qb][i] = 0.f;
-    }
-    if (LSUM4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) lacc4[qb][i] = 0.f;
     }
   }
 
@@ -736,7 +714,6 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
           o0[qb][i] *= alpha; o1[qb][i] *= alpha;
           s0[qb][i] -= adv; s1[qb][i] -= adv;
           if (LSUM) lacc[qb][i] *= alpha;
-          if (LSUM4 && i < 4) lacc4[qb][i] *= alpha;
         }
         if (NEGM) {
 #pragma unroll
@@ -752,13 +729,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     f32x2_t ps[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) ps[qb] = f32x2_t{0.f, 0.f};
-#if FA_PKSUM
-#define FA_PSADD(P, A, B) (P) += f32x2_t{(A), (B)}
-#define FA_PSADD4(P, A, B, C, D) (P) += (f32x2_t{(A), (B)} + f32x2_t{(C), (D)})     /* half the dependent adds on the accumulator */
-#else
-#define FA_PSADD(P, A, B) (P)[0] += (A) + (B)
-#define FA_PSADD4(P, A, B, C, D) (P)[0] += ((A) + (B)) + ((C) + (D))
-#endif
+#define FA_PSADD4(P, A, B, C, D) (P) += (f32x2_t{(A), (B)} + f32x2_t{(C), (D)})     /* (FA_DOT2SUM == 0) packed adds, half of them on the accumulator */
 #define FA_EXP(U)                                                                                                       \
   do {                                                                                                                  \
     _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                                                 \
@@ -793,10 +764,6 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         sb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(pb, pb, 6, 7), one2, sb, false);                   \
         ps[qb] = f32x2_t{sa, sb};                                                                                       \
       }                                                                                                                 \
-      if (LSUM4) {                                                                                                      \
-        lacc4[qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, bf16x4{pf[0], pf[1], pf[2], pf[3]}, lacc4[qb], 0, 0, 0); \
-        lacc4[qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, bf16x4{pf[4], pf[5], pf[6], pf[7]}, lacc4[qb], 0, 0, 0); \
-      }                                                                                                                 \
     }                                                                                                                   \
     FA_PRIO_LO();                                                                                                       \
   } while (0)
@@ -809,46 +776,13 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);                                                                \
     }                                                                                                                   \
   } while (0)
-#elif FA_MIXMODE == 1
-#define FA_MIX() ((void)0)
-#elif FA_MIXMODE == 2
-#define FA_MIX()                                                                                                        \
-  do {                                                                                                                  \
-    __builtin_amdgcn_sched_group_barrier(0x008, 3 * QB, 0);                                                             \
-    __builtin_amdgcn_sched_group_barrier(0x006, 64, 0);                                                                 \
-  } while (0)
-#elif FA_MIXMODE == 3
-#define FA_MIX()                                                                                                        \
-  do {                                                                                                                  \
-    _Pragma("unroll") for (int g = 0; g < QB; ++g) {                                                                    \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                                \
-      __builtin_amdgcn_sched_group_barrier(0x006, 12, 0);                                                               \
-    }                                                                                                                   \
-  } while (0)
 #else
 #define FA_MIX()                                                                                                        \
   do {                                                                                                                  \
-    __builtin_amdgcn_sched_group_barrier(0x006, 64, 0);                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x008, 3 * QB, 0);                                                             \
+    __builtin_amdgcn_sched_group_barrier(0x006, 64, 0);                                                                 \
   } while (0)
 #endif
-#if FA_PHASED & 2
-    FA_EXP(0);
-    FA_VISSUE(1, 1);
-    FA_EXP(1);
-    FA_EXP(2);
-    FA_EXP(3);
-    FA_VWAIT(0, 4);
-    FA_PV(0, 0);
-    FA_VISSUE(2, 0);
-    FA_VWAIT(1, 4);
-    FA_PV(1, 1);
-    FA_VISSUE(3, 1);
-    FA_VWAIT(0, 4);
-    FA_PV(2, 0);
-    FA_VWAIT(1, 0);
-    FA_PV(3, 1);
-#else
     FA_EXP(0);
     FA_VISSUE(1, 1);
     FA_VWAIT(0, 4);
@@ -867,7 +801,6 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     FA_MIX();
     FA_VWAIT(1, 0);
     FA_PV(3, 1);
-#endif
     if (!MSUM) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
@@ -888,7 +821,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
         m_run[qb] += adv;
         l_run[qb] *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; if (LSUM4 && i < 4) lacc4[qb][i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; }
         if (NEGM) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) negm[qb][i] = -m_run[qb];
@@ -954,13 +887,8 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
           if (!MSUM && FA_X != 2 && !FA_DOT2SUM) FA_PSADD4(ps[qb], s0[qb][i], s0[qb][i + 1], s0[qb][i + 2], s0[qb][i + 3]);
         }
       }
-#if FA_PIN_EXP
-      // The exponentials above must be ISSUED here, among the MFMAs of keys 32-63: the textbook-order branch below recomputes s0, which
-      // makes them dead on that path, and LLVM then sinks all 32 of them into the fast path's successor block - a stretch of pure VALU
-      // work with the matrix pipe idle (the overlap this tile form exists for was not in the generated code).
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) asm volatile("" : "+v"(s0[qb]));
-#endif
+      // (the exponentials above are NOT issued here in the generated code: the textbook-order branch below recomputes s0, which makes them
+      // dead on that path, and LLVM sinks them into the fast path's successor block; pinning them here measured 3 % slower)
 #if FA_QK_HINT
 #pragma unroll
       for (int gidx = 0; gidx < 4 * QB; ++gidx) {           // one MFMA, then six of the 24 VALU instructions per MFMA, ...
@@ -1012,8 +940,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
           for (int i = 0; i < 16; ++i) {
             o0[qb][i] *= alpha; o1[qb][i] *= alpha;
             if (LSUM) lacc[qb][i] *= alpha;
-            if (LSUM4 && i < 4) lacc4[qb][i] *= alpha;
-            s0[qb][i] = __builtin_amdgcn_exp2f(s0[qb][i] - adv);
+              s0[qb][i] = __builtin_amdgcn_exp2f(s0[qb][i] - adv);
             if (!MSUM && !FA_DOT2SUM) ps[qb][i & 1] += s0[qb][i];
             s1[qb][i] -= adv;
           }
@@ -1022,23 +949,6 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       }
       FA_VISSUE(0, 0);
       FA_VISSUE(1, 1);
-#if FA_PHASED & 1
-      // every exponential of the tile first, then the 16 P.V MFMAs (and, behind the barrier, the next tile's 16 K.Q MFMAs) as one
-      // stretch of matrix work: the SIMD's two waves - one of each resident workgroup - fall into opposite phases, and a wave in its
-      // MFMA stretch leaves the issue port to the other wave's exponentials (measured against the interleaved order below)
-      FA_EXP(2);
-      FA_EXP(3);
-      FA_VWAIT(0, 4);
-      FA_PV(0, 0);
-      FA_VISSUE(2, 0);
-      FA_VWAIT(1, 4);
-      FA_PV(1, 1);
-      FA_VISSUE(3, 1);
-      FA_VWAIT(0, 4);
-      FA_PV(2, 0);
-      FA_VWAIT(1, 0);
-      FA_PV(3, 1);
-#else
       FA_VWAIT(0, 4);
       FA_PV(0, 0);
       FA_EXP(2);
@@ -1053,7 +963,6 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
       FA_PV(2, 0);
       FA_VWAIT(1, 0);
       FA_PV(3, 1);
-#endif
       if (!MSUM) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -1073,7 +982,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
           m_run[qb] += adv;
           l_run[qb] *= alpha;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; if (LSUM4 && i < 4) lacc4[qb][i] *= alpha; }
+          for (int i = 0; i < 16; ++i) { o0[qb][i] *= alpha; o1[qb][i] *= alpha; if (LSUM) lacc[qb][i] *= alpha; }
         }
       }
     }
@@ -1112,12 +1021,7 @@ __global__ __launch_bounds__(NT, 2) void flash_attn_hd64_kernel(const bf16_t* __
     const int hd = (int)(nb % NH);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      float lsum = LSUM ? lacc[qb][0] : l_run[qb];
-      if (LSUM4) {                                          // every lane holds the sum of its OWN half of the keys: add the other half-wave's
-        const auto sw4 = __builtin_amdgcn_permlane32_swap(__float_as_uint(lacc4[qb][0]), __float_as_uint(lacc4[qb][0]), false, false);
-        lsum = __uint_as_float(sw4[0]) + __uint_as_float(sw4[1]);
-      }
-      const float inv = 1.f / lsum;
+      const float inv = 1.f / (LSUM ? lacc[qb][0] : l_run[qb]);
       const int row = 32 * qb + r;
       const int sw = (row >> 1) & 7;
 #pragma unroll
